@@ -1,0 +1,263 @@
+"""Deterministic synthetic bundle-adjustment scenes.
+
+Numpy only.  Used by tests/, bench.py and __graft_entry__.smoke() to feed the same
+seeded problem to the HIP path and to the oracle.
+
+Scene parameters follow the reference's research simulator
+(/root/reference/matlab/simulate_vins.py:81-92,116-125,155-156,199): pinhole camera
+fx=198.969 fy=198.1284 u0=329.9368 v0=240.1017 at 640x480, a closed "curvy square"
+trajectory at height -1.5 m, pixel noise sigma 1.5, and the IMU noise constants of
+/root/reference/include/ba/Types.h:33-36.
+
+Poses are 7-vectors [tx,ty,tz,qx,qy,qz,qw]; the camera looks along +z of the pose
+frame (T_vs = identity), x right, y down; world z points down.
+"""
+import numpy as np
+
+CAM_PARAMS = np.array([198.969, 198.1284, 329.9368, 240.1017])
+IMG_W, IMG_H = 640.0, 480.0
+GRAVITY = np.array([0.0, 0.0, 9.8007])  # world z is down (reference: ba::Gravity, Types.h:39)
+
+
+def rot_to_quat(R):
+    """Rotation matrices (...,3,3) -> quaternions (...,4) in (x,y,z,w) order."""
+    R = np.asarray(R)
+    m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+    q = np.empty(R.shape[:-2] + (4,))
+    tr = m00 + m11 + m22
+    # four candidate branches, pick the numerically best per element
+    w = np.sqrt(np.maximum(0.0, 1 + tr)) / 2
+    x = np.sqrt(np.maximum(0.0, 1 + m00 - m11 - m22)) / 2
+    y = np.sqrt(np.maximum(0.0, 1 - m00 + m11 - m22)) / 2
+    z = np.sqrt(np.maximum(0.0, 1 - m00 - m11 + m22)) / 2
+    best = np.argmax(np.stack([w, x, y, z], -1), -1)
+    for k in range(4):
+        sel = best == k
+        if not np.any(sel):
+            continue
+        Rs = R[sel]
+        if k == 0:
+            ww = w[sel]
+            q[sel] = np.stack([(Rs[:, 2, 1] - Rs[:, 1, 2]) / (4 * ww),
+                               (Rs[:, 0, 2] - Rs[:, 2, 0]) / (4 * ww),
+                               (Rs[:, 1, 0] - Rs[:, 0, 1]) / (4 * ww), ww], -1)
+        elif k == 1:
+            xx = x[sel]
+            q[sel] = np.stack([xx, (Rs[:, 0, 1] + Rs[:, 1, 0]) / (4 * xx),
+                               (Rs[:, 0, 2] + Rs[:, 2, 0]) / (4 * xx),
+                               (Rs[:, 2, 1] - Rs[:, 1, 2]) / (4 * xx)], -1)
+        elif k == 2:
+            yy = y[sel]
+            q[sel] = np.stack([(Rs[:, 0, 1] + Rs[:, 1, 0]) / (4 * yy), yy,
+                               (Rs[:, 1, 2] + Rs[:, 2, 1]) / (4 * yy),
+                               (Rs[:, 0, 2] - Rs[:, 2, 0]) / (4 * yy)], -1)
+        else:
+            zz = z[sel]
+            q[sel] = np.stack([(Rs[:, 0, 2] + Rs[:, 2, 0]) / (4 * zz),
+                               (Rs[:, 1, 2] + Rs[:, 2, 1]) / (4 * zz), zz,
+                               (Rs[:, 1, 0] - Rs[:, 0, 1]) / (4 * zz)], -1)
+    return q
+
+
+def quat_to_rot(q):
+    q = np.asarray(q)
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0] = 1 - 2 * (y * y + z * z)
+    R[..., 0, 1] = 2 * (x * y - w * z)
+    R[..., 0, 2] = 2 * (x * z + w * y)
+    R[..., 1, 0] = 2 * (x * y + w * z)
+    R[..., 1, 1] = 1 - 2 * (x * x + z * z)
+    R[..., 1, 2] = 2 * (y * z - w * x)
+    R[..., 2, 0] = 2 * (x * z - w * y)
+    R[..., 2, 1] = 2 * (y * z + w * x)
+    R[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz], -1)
+
+
+def quat_exp(w):
+    w = np.asarray(w)
+    th = np.linalg.norm(w, axis=-1, keepdims=True)
+    half = 0.5 * th
+    s = np.where(th < 1e-10, 0.5 - th * th / 48.0, np.sin(half) / np.where(th < 1e-10, 1.0, th))
+    return np.concatenate([s * w, np.cos(half)], -1)
+
+
+def trajectory(P, radius=7.5, height=-1.5):
+    """Ground-truth poses on a closed curvy square; camera z along the direction of travel."""
+    s = np.arange(P) / float(P) * 2 * np.pi
+    r = radius * (1.0 + 0.15 * np.cos(4 * s))
+    pos = np.stack([r * np.cos(s), r * np.sin(s), height + 0.3 * np.sin(3 * s)], -1)
+    dr = -radius * 0.6 * np.sin(4 * s)
+    vel = np.stack([dr * np.cos(s) - r * np.sin(s), dr * np.sin(s) + r * np.cos(s),
+                    0.9 * np.cos(3 * s)], -1)
+    zc = vel / np.linalg.norm(vel, axis=-1, keepdims=True)
+    down = np.array([0.0, 0.0, 1.0])
+    xc = np.cross(np.broadcast_to(down, zc.shape), zc)
+    xc /= np.linalg.norm(xc, axis=-1, keepdims=True)
+    yc = np.cross(zc, xc)
+    R = np.stack([xc, yc, zc], -1)  # columns = camera axes in the world
+    return np.concatenate([pos, rot_to_quat(R)], -1), vel
+
+
+def project(poses7, pts):
+    """Pinhole projection of world points (N,3) into poses (N,7) (T_vs = I). -> (uv, depth)."""
+    R = quat_to_rot(poses7[..., 3:7])
+    pc = np.einsum('...ji,...j->...i', R, pts - poses7[..., :3])
+    z = pc[..., 2]
+    zs = np.where(np.abs(z) < 1e-12, 1e-12, z)
+    uv = np.stack([CAM_PARAMS[0] * pc[..., 0] / zs + CAM_PARAMS[2],
+                   CAM_PARAMS[1] * pc[..., 1] / zs + CAM_PARAMS[3]], -1)
+    return uv, z
+
+
+class Scene:
+    """Container of one synthetic problem (ground truth + perturbed initial state)."""
+    pass
+
+
+def make_scene(num_poses, num_landmarks, obs_per_landmark=10, lm_dim=1, seed=0,
+               pixel_sigma=1.5, outlier_frac=0.02, trans_sigma=0.05, rot_sigma=0.01,
+               depth_sigma=0.05, lm_range=None, window=None, chunk=200000, exact_poses=2):
+    """Build a scene with exactly `obs_per_landmark` ACCEPTED projection residuals per landmark.
+
+    lm_dim == 1 (inverse depth): the first chosen pose is the landmark's reference pose; its
+    own observation only sets z_ref and is rejected by AddProjectionResidual
+    (/root/reference/include/ba/BundleAdjuster.h:489-501), so k+1 poses are chosen.
+    lm_dim == 3: k poses, the first is still recorded as the (unused) reference pose.
+
+    `lm_range` restricts generation to landmark ids [lo, hi) of the same global scene —
+    every landmark is drawn from its own counter-based stream, so shards of one scene can
+    be generated independently (multi-GPU landmark sharding).
+    """
+    P, Ltot, k = int(num_poses), int(num_landmarks), int(obs_per_landmark)
+    lo, hi = (0, Ltot) if lm_range is None else lm_range
+    L = hi - lo
+    nsel = k + 1 if lm_dim == 1 else k
+    gt_poses, vel = trajectory(P)
+    if window is None:
+        window = max(nsel + 2, min(P // 2 - 1, max(24, P // 8)))
+    ncand = min(2 * window, max(4 * nsel, 48))
+
+    sc = Scene()
+    sc.lm_dim, sc.num_poses, sc.num_landmarks_total, sc.lm_lo = lm_dim, P, Ltot, lo
+    sc.cam_params = CAM_PARAMS.copy()
+    sc.gt_poses = gt_poses
+    sc.gt_vel = vel
+
+    # perturbed initial poses; the first `exact_poses` are left at ground truth so that
+    # holding them inactive fixes the 7-dof gauge (scale included) without bias
+    rng_p = np.random.Generator(np.random.PCG64([seed, 0xBA5E, 1]))
+    dt = rng_p.normal(0.0, trans_sigma, (P, 3))
+    dw = rng_p.normal(0.0, rot_sigma, (P, 3))
+    dt[:exact_poses] = 0
+    dw[:exact_poses] = 0
+    init = gt_poses.copy()
+    init[:, :3] += dt
+    init[:, 3:7] = quat_mul(gt_poses[:, 3:7], quat_exp(dw))
+    init[:, 3:7] /= np.linalg.norm(init[:, 3:7], axis=-1, keepdims=True)
+    sc.poses = init
+
+    x_w = np.empty((L, 4))
+    ref_pose = np.empty(L, dtype=np.uint32)
+    sel_poses = np.empty((L, nsel), dtype=np.uint32)
+    z_all = np.empty((L, nsel, 2))
+    for c0 in range(0, L, chunk):
+        c1 = min(L, c0 + chunk)
+        n = c1 - c0
+        # one stream per chunk start (chunks are aligned to the global landmark index)
+        todo = np.arange(n)
+        attempt = 0
+        while todo.size:
+            rng = np.random.Generator(np.random.PCG64([seed, 0xBA5E, 2, lo + c0, attempt]))
+            m = todo.size
+            anchor = rng.integers(0, P, m)
+            uv = np.stack([rng.uniform(20, IMG_W - 20, m), rng.uniform(20, IMG_H - 20, m)], -1)
+            depth = rng.uniform(2.0, 40.0, m)
+            ap = gt_poses[anchor]
+            ray = np.stack([(uv[:, 0] - CAM_PARAMS[2]) / CAM_PARAMS[0],
+                            (uv[:, 1] - CAM_PARAMS[3]) / CAM_PARAMS[1], np.ones(m)], -1)
+            pts = ap[:, :3] + np.einsum('nij,nj->ni', quat_to_rot(ap[:, 3:7]), ray * depth[:, None])
+            # candidate poses: distinct offsets around the anchor
+            offs = np.argsort(rng.random((m, 2 * window)), axis=1)[:, :ncand] - window
+            offs = np.where(offs >= 0, offs + 1, offs)  # skip 0 (the anchor itself)
+            cand = (anchor[:, None] + offs) % P
+            cuv, cz = project(gt_poses[cand], pts[:, None, :])
+            vis = (cz > 0.5) & (cuv[..., 0] > 0) & (cuv[..., 0] < IMG_W) & \
+                  (cuv[..., 1] > 0) & (cuv[..., 1] < IMG_H)
+            # distinct candidates only (wrap-around may alias when 2*window >= P)
+            order = np.argsort(~vis, axis=1, kind='stable')  # visible first, original order kept
+            nvis = vis.sum(1)
+            ok = nvis >= (nsel - 1)
+            good = np.nonzero(ok)[0]
+            if good.size:
+                gi = todo[good]
+                picks = np.take_along_axis(cand[good], order[good, :nsel - 1], 1)
+                sel = np.concatenate([anchor[good, None], picks], 1)
+                # reject rows with duplicate poses
+                srt = np.sort(sel, 1)
+                dup = (srt[:, 1:] == srt[:, :-1]).any(1)
+                keep = ~dup
+                gi, sel, good = gi[keep], sel[keep], good[keep]
+                x_w[c0 + gi, :3] = pts[good]
+                x_w[c0 + gi, 3] = 1.0
+                ref_pose[c0 + gi] = sel[:, 0]
+                sel_poses[c0 + gi] = sel
+                zz, _ = project(gt_poses[sel], pts[good][:, None, :])
+                z_all[c0 + gi] = zz
+                done = np.zeros(m, dtype=bool)
+                done[good] = True
+                todo = todo[~done]
+            attempt += 1
+            if attempt > 200:
+                raise RuntimeError("scene generation did not converge")
+    # measurement noise + gross outliers
+    rng_n = np.random.Generator(np.random.PCG64([seed, 0xBA5E, 3, lo]))
+    z_all += rng_n.normal(0.0, pixel_sigma, z_all.shape)
+    out = rng_n.random(z_all.shape[:2]) < outlier_frac
+    zo = np.stack([rng_n.uniform(0, IMG_W, z_all.shape[:2]), rng_n.uniform(0, IMG_H, z_all.shape[:2])], -1)
+    z_all = np.where(out[..., None], zo, z_all)
+    # landmark initialisation as a tracker does it: back-project the (noisy) reference
+    # observation from the current ESTIMATE of the reference pose at a perturbed depth,
+    # so the inverse-depth ray of lm_dim == 1 agrees with z_ref.
+    z_ref = z_all[:, 0, :]
+    ray = np.stack([(z_ref[:, 0] - CAM_PARAMS[2]) / CAM_PARAMS[0],
+                    (z_ref[:, 1] - CAM_PARAMS[3]) / CAM_PARAMS[1], np.ones(L)], -1)
+    gp = gt_poses[ref_pose]
+    depth = np.einsum('nij,nj->ni', np.transpose(quat_to_rot(gp[:, 3:7]), (0, 2, 1)),
+                      x_w[:, :3] - gp[:, :3])[:, 2]
+    scale = 1.0 / (1.0 + rng_n.normal(0.0, depth_sigma, L))
+    ip = init[ref_pose]
+    x_init = x_w.copy()
+    x_init[:, :3] = ip[:, :3] + np.einsum('nij,nj->ni', quat_to_rot(ip[:, 3:7]),
+                                          ray * (depth * scale)[:, None])
+    sc.gt_landmarks = x_w
+    sc.landmarks = x_init
+    sc.lm_ref_pose = ref_pose
+    sc.num_landmarks = L
+    # observation table in insertion order: for each landmark, its chosen poses in order
+    sc.obs_pose = sel_poses.reshape(-1)
+    sc.obs_lm = np.repeat(np.arange(L, dtype=np.uint32), nsel)
+    sc.obs_z = z_all.reshape(-1, 2)
+    sc.obs_per_landmark = k
+    return sc
+
+
+def add_scene_to(ba, sc, pose_dim=6, active=None):
+    """Feed a Scene through a reference-style API object (oracle or ba_amd adjuster)."""
+    ba.AddCamera(sc.cam_params)
+    P = sc.num_poses
+    act = np.ones(P, dtype=np.uint8) if active is None else np.asarray(active, dtype=np.uint8)
+    v = getattr(sc, 'init_vel', None)
+    ba.add_poses(sc.poses, v_w=v, is_active=act, time=getattr(sc, 'pose_time', None))
+    ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    return ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)

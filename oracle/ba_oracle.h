@@ -1,0 +1,149 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * C interface of the CPU restatement of arpg/ba's BundleAdjuster<> Gauss-Newton
+ * path (oracle/ba_oracle.cpp).  It mirrors the reference's public API
+ * (/root/reference/include/ba/BundleAdjuster.h:177-631) call for call so that
+ * parity tests read like reference usage.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library; the product path
+ * (ba_amd/, include/) never does.
+ *
+ * PARITY UNPINNED: the reference cannot be built in this image (Eigen, Sophus,
+ * Calibu, TBB absent) and holds no golden numeric vectors; the restatement is
+ * pinned by finite-difference Jacobian checks at the reference's thresholds and by
+ * dense-algebra identities (tests/test_oracle_*.py).
+ *
+ * 7-vectors describing a rigid transform are [tx,ty,tz,qx,qy,qz,qw]
+ * (translation, then quaternion coefficients in Eigen order).
+ */
+#ifndef BA_ORACLE_H
+#define BA_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ba orc_ba;
+
+/* ba::Options<double>, BundleAdjuster.h:72-107 (same defaults via orc_default_options). */
+typedef struct {
+  double trust_region_size;
+  double gyro_sigma, accel_sigma, gyro_bias_sigma, accel_bias_sigma;
+  double projection_outlier_threshold;
+  double error_change_threshold, param_change_threshold;
+  uint32_t dogleg_max_inner_iterations;
+  int apply_results, use_dogleg, use_triangular_matrices, use_sparse_solver;
+  int regularize_biases_in_batch, enable_auto_regularization;
+  int use_robust_norm_for_proj_residuals, use_robust_norm_for_inertial_residuals;
+} orc_options;
+
+/* ba::SolutionSummary<double>, BundleAdjuster.h:48-70 (+ the four error sums of GetErrors). */
+typedef struct {
+  uint32_t num_proj_residuals, num_inertial_residuals;
+  uint32_t num_cond_proj_residuals, num_cond_inertial_residuals;
+  double cond_proj_error, cond_inertial_error, proj_error, inertial_error;
+  double delta_norm, pre_solve_norm, post_solve_norm;
+  int result; /* OptimizationResult */
+  double unary_error, binary_error;
+  uint32_t iterations_run;
+  double trust_region_size;
+} orc_summary;
+
+void orc_default_options(orc_options* o);
+
+orc_ba* orc_create(int lm_dim, int pose_dim);
+void orc_destroy(orc_ba* h);
+void orc_init(orc_ba* h, const orc_options* o);
+void orc_set_gravity(orc_ba* h, const double g[3]);
+uint32_t orc_add_camera(orc_ba* h, const double params[4], const double t_vs[7]);
+uint32_t orc_add_pose(orc_ba* h, const double t_wp[7], const double v_w[3],
+                      const double b[6], int is_active, double time);
+uint32_t orc_add_landmark(orc_ba* h, const double x_w[4], uint32_t ref_pose_id,
+                          uint32_t ref_cam_id, int is_active);
+uint32_t orc_add_projection_residual(orc_ba* h, const double z[2], uint32_t meas_pose_id,
+                                     uint32_t landmark_id, uint32_t cam_id, double weight);
+uint32_t orc_add_unary_constraint(orc_ba* h, uint32_t pose_id, const double t_wv[7],
+                                  const double cov[36], int use_rotation);
+uint32_t orc_add_binary_constraint(orc_ba* h, uint32_t pose1_id, uint32_t pose2_id,
+                                   const double t_12[7], const double cov[36],
+                                   double weight, int use_rotation);
+/* meas: n rows of [wx,wy,wz,ax,ay,az,time] */
+uint32_t orc_add_imu_residual(orc_ba* h, uint32_t pose1_id, uint32_t pose2_id,
+                              const double* meas, uint32_t n, double weight);
+void orc_regularize_pose(orc_ba* h, uint32_t pose_id, int translation, int gravity,
+                         int bias, int rotation);
+void orc_set_root_pose_id(orc_ba* h, uint32_t id);
+
+/* bulk adders (same semantics as n single calls; ids returned in out_ids if non-null) */
+void orc_add_poses(orc_ba* h, uint32_t n, const double* t_wp, const double* v_w,
+                   const double* b, const uint8_t* is_active, const double* time);
+void orc_add_landmarks(orc_ba* h, uint32_t n, const double* x_w, const uint32_t* ref_pose_id,
+                       const uint32_t* ref_cam_id, const uint8_t* is_active);
+void orc_add_projection_residuals(orc_ba* h, uint32_t n, const double* z,
+                                  const uint32_t* meas_pose_id, const uint32_t* landmark_id,
+                                  const uint32_t* cam_id, const double* weight,
+                                  uint32_t* out_ids);
+
+void orc_solve(orc_ba* h, uint32_t max_iter, double gn_damping, int error_increase_allowed);
+
+/* results */
+uint32_t orc_num_poses(const orc_ba* h);
+uint32_t orc_num_landmarks(const orc_ba* h);
+uint32_t orc_num_proj_residuals(const orc_ba* h);
+void orc_get_pose(const orc_ba* h, uint32_t id, double t_wp[7], double v_w[3], double b[6]);
+void orc_get_poses(const orc_ba* h, double* t_wp, double* v_w, double* b);
+void orc_get_landmark(const orc_ba* h, uint32_t id, double x_w[4]);
+void orc_get_landmarks(const orc_ba* h, double* x_w);
+int orc_is_landmark_reliable(const orc_ba* h, uint32_t id);
+double orc_landmark_outlier_ratio(const orc_ba* h, uint32_t id);
+void orc_get_summary(const orc_ba* h, orc_summary* s);
+
+/* parity/debug taps: state of the LAST executed Solve iteration */
+uint32_t orc_num_pose_params(const orc_ba* h);   /* n = PoseDim * active poses */
+uint32_t orc_num_lm_params(const orc_ba* h);     /* LmDim * active landmarks */
+void orc_get_S(const orc_ba* h, double* s_nxn);  /* reduced matrix as the reference
+                                                    leaves it in s_ (block-upper when
+                                                    use_triangular_matrices) */
+void orc_get_rhs(const orc_ba* h, double* rhs_n);        /* rhs_p_sc */
+void orc_get_rhs_p(const orc_ba* h, double* rhs_n);      /* rhs_p_ (before Schur) */
+void orc_get_rhs_l(const orc_ba* h, double* rhs_l);
+void orc_get_delta_p(const orc_ba* h, double* d);        /* applied pose step */
+void orc_get_delta_l(const orc_ba* h, double* d);
+void orc_get_proj_weights(const orc_ba* h, double* w);   /* per residual id */
+void orc_get_proj_residuals(const orc_ba* h, double* r2);/* per residual id, 2 each */
+/* per-residual Jacobians of the last BuildProblem (dz_dx_meas 2x6, dz_dx_ref 2x6,
+   dz_dlm 2xLm), row-major, unmasked/unweighted as stored in the residual. */
+void orc_get_proj_jacobians(const orc_ba* h, double* j_meas, double* j_ref, double* j_lm);
+void orc_get_imu_jacobians(const orc_ba* h, uint32_t id, double* dz_dx1, double* dz_dx2,
+                           double* cov_inv, double* residual); /* 15x15,15x15,15x15,15 */
+void orc_get_binary_jacobians(const orc_ba* h, uint32_t id, double* dz_dx1, double* dz_dx2,
+                              double* residual);
+void orc_get_unary_jacobian(const orc_ba* h, uint32_t id, double* dz_dx, double* residual);
+
+/* phase timers of the last Solve (seconds, summed over iterations), named after the
+   reference's StartTimer/PrintTimer sites (Utils.h:51-62). */
+typedef struct {
+  double build_problem, j_evaluation_proj, jtj, schur_complement, solve,
+         back_substitution, evaluate_residuals, apply_update, total;
+} orc_timers;
+void orc_get_timers(const orc_ba* h, orc_timers* t);
+
+/* stand-alone math taps for finite-difference tests */
+void orc_math_dlog_dq(const double q[4], double out3x4[12]);
+void orc_math_so3_log(const double q[4], double out[3]);
+void orc_math_so3_exp(const double w[3], double q[4]);
+void orc_math_exp_decoupled(const double t[7], const double x[6], double out[7]);
+void orc_math_log_decoupled(const double a[7], const double b[7], double out[6]);
+void orc_math_se3_mul(const double a[7], const double b[7], double out[7]);
+void orc_math_se3_inv(const double a[7], double out[7]);
+void orc_math_dense_solve_upper(uint32_t n, const double* s, const double* rhs, double* x);
+/* IntegrateResidual (Types.h:662-738): pose [t7,v3], returns [t7,v3] and optional
+   10x6 bias Jacobian and 10x10 covariance. */
+void orc_math_integrate(const double pose_t[7], const double v[3], const double* meas,
+                        uint32_t n, const double bg[3], const double ba[3],
+                        const double g[3], const double r6[6], double out_t[7],
+                        double out_v[3], double* dpose_db_10x6, double* c_10x10);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

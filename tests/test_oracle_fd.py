@@ -1,0 +1,196 @@
+"""Pins the oracle's analytic Jacobians with central finite differences, re-creating the
+reference's own checkers (_Test_dProjectionResidual_dX, _Test_dBinaryResidual_dX,
+_Test_dUnaryResidual_dX: /root/reference/include/ba/BundleAdjusterTest.h:13-203) at the
+reference's threshold NORM_THRESHOLD = 1e-3 (/root/reference/include/ba/Utils.h:68-69).
+The reference has no golden numbers for this path: this is what pins the
+restatement."""
+import numpy as np
+import pytest
+
+from ba_amd import scene
+from helpers import accepted_obs, fill
+
+NORM_THRESHOLD = 1e-3
+EPS = 1e-6
+
+
+def _run(po, sc, lm_dim, poses, lms, pose_dim=6):
+    ba = po.OracleBundleAdjuster(lm_dim, pose_dim)
+    o = po.default_options()
+    o.use_dogleg = 0
+    o.apply_results = 0
+    o.use_robust_norm_for_proj_residuals = 0
+    ba.Init(o)
+    ba.AddCamera(sc.cam_params)
+    ba.add_poses(poses)
+    ba.add_landmarks(lms, sc.lm_ref_pose)
+    ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    ba.Solve(1)
+    return ba
+
+
+def _move_lms(sc, p, t_new):
+    """Keep the sensor-frame coordinates x_s of the landmarks anchored in pose p fixed."""
+    lm = sc.landmarks.copy()
+    rn = scene.quat_to_rot(t_new[3:7])
+    ro = scene.quat_to_rot(sc.poses[p][3:7])
+    sel = sc.lm_ref_pose == p
+    lm[sel, :3] = (lm[sel, :3] - sc.poses[p][:3]) @ ro @ rn.T + t_new[:3]
+    return lm
+
+
+def test_dlog_dq_reference_vector(oracle_lib):
+    """The one concrete input the reference's math_test holds
+    (/root/reference/applications/math_test/main.cpp:30), same eps (1e-9)."""
+    po = oracle_lib
+    q = np.array([0.000718076, 0.0139853, -4.9437e-05, 0.999902])
+    fd = np.zeros((3, 4))
+    for i in range(4):
+        e = np.zeros(4)
+        e[i] = 1e-9
+        fd[:, i] = (po.so3_log(q + e) - po.so3_log(q - e)) / 2e-9
+    assert np.linalg.norm(po.dlog_dq(q) - fd) < NORM_THRESHOLD
+
+
+def test_dlog_dq_random_and_small_angle(oracle_lib):
+    po = oracle_lib
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        q = po.so3_exp(rng.normal(0, 1.0, 3))
+        fd = np.zeros((3, 4))
+        for i in range(4):
+            e = np.zeros(4)
+            e[i] = 1e-7
+            fd[:, i] = (po.so3_log(q + e) - po.so3_log(q - e)) / 2e-7
+        assert np.linalg.norm(po.dlog_dq(q) - fd) < NORM_THRESHOLD
+    # small-angle branch (|vec| < 1e-9) must continue the nominal branch
+    a = po.dlog_dq(np.array([5e-10, 0, 0, 1.0]))
+    b = po.dlog_dq(np.array([2e-9, 0, 0, 1.0]))
+    assert np.allclose(a, b, atol=1e-6)
+
+
+def test_exp_log_decoupled_roundtrip(oracle_lib):
+    po = oracle_lib
+    rng = np.random.default_rng(6)
+    for _ in range(10):
+        t = np.concatenate([rng.normal(0, 3, 3), po.so3_exp(rng.normal(0, 0.7, 3))])
+        x = rng.normal(0, 0.2, 6)
+        t2 = po.exp_decoupled(t, x)
+        back = po.log_decoupled(t2, t)
+        assert np.allclose(back[:3], x[:3], atol=1e-12)
+        # log(R exp(w) R^-1) = R w
+        rw = scene.quat_to_rot(t[3:7]) @ x[3:]
+        assert np.allclose(back[3:], rw, atol=1e-10)
+
+
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_projection_pose_jacobians(oracle_lib, lm_dim):
+    po = oracle_lib
+    sc = scene.make_scene(24, 12, 4, lm_dim=lm_dim, seed=3)
+    ba = _run(po, sc, lm_dim, sc.poses, sc.landmarks)
+    jm, jr, _ = ba.proj_jacobians()
+    acc = accepted_obs(sc)
+    fd_m, fd_r = np.zeros_like(jm), np.zeros_like(jr)
+    for p in range(sc.num_poses):
+        for j in range(6):
+            d = np.zeros(6)
+            d[j] = EPS
+            tp, tm = po.exp_decoupled(sc.poses[p], d), po.exp_decoupled(sc.poses[p], -d)
+            pp, pm = sc.poses.copy(), sc.poses.copy()
+            pp[p], pm[p] = tp, tm
+            lp = _move_lms(sc, p, tp) if lm_dim == 1 else sc.landmarks
+            ln = _move_lms(sc, p, tm) if lm_dim == 1 else sc.landmarks
+            fd = (_run(po, sc, lm_dim, pp, lp).proj_residuals() -
+                  _run(po, sc, lm_dim, pm, ln).proj_residuals()) / (2 * EPS)
+            for rid, (m, r, _l) in enumerate(acc):
+                if m == p:
+                    fd_m[rid, :, j] = fd[rid]
+                if lm_dim == 1 and r == p and m != p:
+                    fd_r[rid, :, j] = fd[rid]
+    for rid in range(len(acc)):
+        assert np.linalg.norm(jm[rid] - fd_m[rid]) < NORM_THRESHOLD
+        if lm_dim == 1:
+            assert np.linalg.norm(jr[rid] - fd_r[rid]) < NORM_THRESHOLD
+    assert np.abs(jm).max() > 10  # the check is not vacuous
+
+
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_projection_landmark_jacobian(oracle_lib, lm_dim):
+    po = oracle_lib
+    sc = scene.make_scene(24, 12, 4, lm_dim=lm_dim, seed=4)
+    ba = _run(po, sc, lm_dim, sc.poses, sc.landmarks)
+    _, _, jl = ba.proj_jacobians()
+    acc = accepted_obs(sc)
+    for l in range(sc.num_landmarks):
+        if lm_dim == 3:
+            for j in range(3):
+                lp, ln = sc.landmarks.copy(), sc.landmarks.copy()
+                lp[l, j] += EPS
+                ln[l, j] -= EPS
+                fd = (_run(po, sc, 3, sc.poses, lp).proj_residuals() -
+                      _run(po, sc, 3, sc.poses, ln).proj_residuals()) / (2 * EPS)
+                for rid, (_m, _r, ll) in enumerate(acc):
+                    if ll == l:
+                        assert np.linalg.norm(fd[rid] - jl[rid][:, j]) < NORM_THRESHOLD
+        else:
+            # inverse depth rho of x_s = (ray, rho)/|.|: x_w = c + dir/rho along the ref ray
+            c = sc.poses[sc.lm_ref_pose[l]][:3]
+            v = sc.landmarks[l, :3] - c
+            dist = np.linalg.norm(v)
+            rho = 1.0 / dist
+            h = 1e-7
+
+            def at(r):
+                lm = sc.landmarks.copy()
+                lm[l, :3] = c + v / dist / r
+                return _run(po, sc, 1, sc.poses, lm).proj_residuals()
+            fd = (at(rho + h) - at(rho - h)) / (2 * h)
+            for rid, (_m, _r, ll) in enumerate(acc):
+                if ll == l:
+                    assert np.linalg.norm(fd[rid] - jl[rid][:, 0]) < NORM_THRESHOLD * max(1.0, np.abs(jl[rid]).max())
+
+
+def _pose_graph(po, poses, unary=None, binary=None):
+    ba = po.OracleBundleAdjuster(0, 6)
+    o = po.default_options()
+    o.use_dogleg = 0
+    o.apply_results = 0
+    ba.Init(o)
+    ba.add_poses(poses)
+    ba.SetRootPoseId(len(poses) - 1)  # keep the gauge masking away from poses 0 and 1
+    if unary is not None:
+        ba.AddUnaryConstraint(unary[0], unary[1], np.eye(6), True)
+    if binary is not None:
+        ba.AddBinaryConstraint(binary[0], binary[1], binary[2])
+    ba.Solve(1)
+    return ba
+
+
+def test_unary_and_binary_jacobians(oracle_lib):
+    """BundleAdjusterTest.h:130-203 re-created: eps 1e-6, threshold 1e-3."""
+    po = oracle_lib
+    rng = np.random.default_rng(11)
+    poses = np.stack([np.concatenate([rng.normal(0, 2, 3), po.so3_exp(rng.normal(0, 0.5, 3))])
+                      for _ in range(3)])
+    prior = np.concatenate([poses[0][:3] + 0.1, po.so3_exp(rng.normal(0, 0.5, 3))])
+    t12 = po.se3_mul(po.se3_inv(poses[0]), poses[1])
+    t12 = po.exp_decoupled(t12, rng.normal(0, 0.05, 6))
+    ju, _ = _pose_graph(po, poses, unary=(0, prior)).unary_jacobian(0)
+    j1, j2, _ = _pose_graph(po, poses, binary=(0, 1, t12)).binary_jacobians(0)
+    fu, f1, f2 = np.zeros((6, 6)), np.zeros((6, 6)), np.zeros((6, 6))
+    for j in range(6):
+        d = np.zeros(6)
+        d[j] = EPS
+        for sgn in (1, -1):
+            pp = poses.copy()
+            pp[0] = po.exp_decoupled(poses[0], sgn * d)
+            fu[:, j] += sgn * _pose_graph(po, pp, unary=(0, prior)).unary_jacobian(0)[1]
+            f1[:, j] += sgn * _pose_graph(po, pp, binary=(0, 1, t12)).binary_jacobians(0)[2]
+            pq = poses.copy()
+            pq[1] = po.exp_decoupled(poses[1], sgn * d)
+            f2[:, j] += sgn * _pose_graph(po, pq, binary=(0, 1, t12)).binary_jacobians(0)[2]
+    fu, f1, f2 = fu / (2 * EPS), f1 / (2 * EPS), f2 / (2 * EPS)
+    assert np.abs(ju).max() > 0.1 and np.abs(j1).max() > 0.1 and np.abs(j2).max() > 0.1
+    assert np.linalg.norm(ju - fu) < NORM_THRESHOLD
+    assert np.linalg.norm(j1 - f1) < NORM_THRESHOLD
+    assert np.linalg.norm(j2 - f2) < NORM_THRESHOLD
