@@ -1,0 +1,237 @@
+// Device/host math shared by the gfx950 kernels of the projection path.
+//
+// Closed forms of the reference's Jacobian chains.  The reference multiplies dense
+// 2x4 . 4x7 . 7x7 . 7x6 matrices that are mostly zeros
+// (/root/reference/include/ba/parallel_algos.h:91-110 with the helpers of
+// /root/reference/include/ba/Utils.h:295-312,451-694); with unit quaternions those
+// products collapse algebraically to
+//   dz_dx_meas = dpi . [ rho R_sw ,  -R_sv [R_pw (Xw - rho t_wp)]x ]
+//   dz_dx_ref  =       [ -rho dpi R_sw_m ,  dpi R_a [Y]x ]          (LmDim == 1)
+//   dz_dlm     = -dpi t (LmDim 1)   |   -dpi R_sw (LmDim 3)
+// where dpi is the pinhole derivative at P, R_a = R_sw_m R_wp_ref, Y = R_vs_r ray +
+// rho t_vs_r (derivation: DESIGN.md §Kernels).  BA_HD lets the same code be compiled
+// for the host so tests can compare it with the oracle without a GPU.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BA_HD __host__ __device__ __forceinline__
+#else
+#define BA_HD inline
+#endif
+
+namespace bad {
+
+struct V3 { double x, y, z; };
+
+BA_HD V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+BA_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+BA_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+BA_HD V3 operator*(V3 a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
+BA_HD V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+BA_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// 3x3 row-major
+struct M3 { double m[9]; };
+BA_HD V3 mul(const M3& R, V3 v) {
+  return v3(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z,
+            R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+            R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);
+}
+BA_HD V3 mulT(const M3& R, V3 v) {  // R^T v
+  return v3(R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z,
+            R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z,
+            R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z);
+}
+BA_HD M3 mul(const M3& A, const M3& B) {
+  M3 C;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      C.m[r * 3 + c] = A.m[r * 3] * B.m[c] + A.m[r * 3 + 1] * B.m[3 + c] + A.m[r * 3 + 2] * B.m[6 + c];
+  return C;
+}
+BA_HD M3 transpose(const M3& A) {
+  M3 T;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) T.m[r * 3 + c] = A.m[c * 3 + r];
+  return T;
+}
+// rotation matrix of a quaternion (x,y,z,w), Eigen's polynomial form
+BA_HD M3 quat_to_rot(double x, double y, double z, double w) {
+  M3 R;
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R.m[0] = 1 - (tyy + tzz); R.m[1] = txy - twz;       R.m[2] = txz + twy;
+  R.m[3] = txy + twz;       R.m[4] = 1 - (txx + tzz); R.m[5] = tyz - twx;
+  R.m[6] = txz - twy;       R.m[7] = tyz + twx;       R.m[8] = 1 - (txx + tyy);
+  return R;
+}
+// Hamilton product, (x,y,z,w) storage
+BA_HD void quat_mul(const double* a, const double* b, double* o) {
+  const double ox = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  const double oy = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  const double oz = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  const double ow = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = ox; o[1] = oy; o[2] = oz; o[3] = ow;
+}
+BA_HD void quat_normalize(double* q) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+// Sophus SO3::exp (small-angle series below 1e-10), then normalised as the SO3
+// constructor does.
+BA_HD void so3_exp(V3 w, double* q) {
+  const double th2 = dot(w, w);
+  const double th = sqrt(th2);
+  double imag, real;
+  if (th < 1e-10) {
+    const double th4 = th2 * th2;
+    imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+    real = 1.0 - 0.5 * th2 + (1.0 / 384.0) * th4;
+  } else {
+    imag = sin(0.5 * th) / th;
+    real = cos(0.5 * th);
+  }
+  q[0] = imag * w.x; q[1] = imag * w.y; q[2] = imag * w.z; q[3] = real;
+  quat_normalize(q);
+}
+// Sophus SO3::log
+BA_HD V3 so3_log(const double* q) {
+  const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+  const double n = sqrt(n2);
+  const double w = q[3];
+  double f;
+  if (n < 1e-10) {
+    f = 2.0 / w - 2.0 * n2 / (w * w * w);
+  } else if (fabs(w) < 1e-10) {
+    f = (w > 0 ? M_PI : -M_PI) / n;
+  } else {
+    f = 2.0 * atan(n / w) / n;
+  }
+  return v3(f * q[0], f * q[1], f * q[2]);
+}
+
+// Rigid transform as rotation matrix + translation: y = R x + t
+struct Rt { M3 R; V3 t; };
+BA_HD Rt compose(const Rt& a, const Rt& b) {  // a * b
+  Rt c;
+  c.R = mul(a.R, b.R);
+  c.t = mul(a.R, b.t) + a.t;
+  return c;
+}
+BA_HD Rt inverse(const Rt& a) {
+  Rt c;
+  c.R = transpose(a.R);
+  c.t = mulT(a.R, a.t) * -1.0;
+  return c;
+}
+
+struct Cam { double fx, fy, u0, v0; };
+
+// pi(P) and its 2x3 derivative rows (d0 = d u/dP, d1 = d v/dP)
+BA_HD void project(const Cam& c, V3 P, double* u, double* v) {
+  const double iz = 1.0 / P.z;
+  *u = c.fx * P.x * iz + c.u0;
+  *v = c.fy * P.y * iz + c.v0;
+}
+BA_HD void dproject(const Cam& c, V3 P, V3* d0, V3* d1) {
+  const double iz = 1.0 / P.z;
+  *d0 = v3(c.fx * iz, 0.0, -c.fx * P.x * iz * iz);
+  *d1 = v3(0.0, c.fy * iz, -c.fy * P.y * iz * iz);
+}
+
+// One projection residual with its Jacobians.
+//   LM == 1: x = (ray, rho) in the reference sensor frame; LM == 3: x = homogeneous
+//   world point.  Inputs: T_sw_m (sensor<-world of the measuring pose/camera), for
+//   LM == 1 T_ws_r (world<-reference sensor); T_wp of the measuring pose and, for the
+//   reference-pose block, T_wp_r and T_vs_r; T_sv_m = T_vs_m^-1.
+// Outputs (row-major): r[2], jm[2][6], jr[2][6], jl[2][LM].
+template <int LM>
+struct ProjJac {
+  double r[2];
+  double jm[12];
+  double jr[12];
+  double jl[2 * (LM > 0 ? LM : 1)];
+};
+
+// residual only (BundleAdjuster.cpp:155-176, parallel_algos.h:59-64)
+template <int LM>
+BA_HD V3 proj_point(const Rt& t_sw_m, const Rt& t_ws_r, const double* x) {
+  const V3 xv = v3(x[0], x[1], x[2]);
+  if (LM == 1) {
+    const Rt T = compose(t_sw_m, t_ws_r);
+    return mul(T.R, xv) + T.t * x[3];
+  }
+  return mul(t_sw_m.R, xv) + t_sw_m.t * x[3];
+}
+
+template <int LM>
+BA_HD void proj_jacobians(const Cam& cam, const double* z, const double* x,
+                          const Rt& t_sw_m, const Rt& t_ws_r, const Rt& t_wp_m,
+                          const Rt& t_sv_m, const Rt& t_wp_r, const Rt& t_vs_r,
+                          bool same_pose, ProjJac<LM>* out) {
+  const V3 xv = v3(x[0], x[1], x[2]);
+  const double rho = x[3];
+  Rt T = t_sw_m;
+  if (LM == 1) T = compose(t_sw_m, t_ws_r);
+  const V3 P = mul(T.R, xv) + T.t * rho;
+  double u, v;
+  project(cam, P, &u, &v);
+  out->r[0] = z[0] - u;
+  out->r[1] = z[1] - v;
+  V3 d0, d1;
+  dproject(cam, P, &d0, &d1);
+  // landmark block: -dpi [R | t] columns (parallel_algos.h:76-84)
+  if (LM == 1) {
+    out->jl[0] = -dot(d0, T.t);
+    out->jl[1] = -dot(d1, T.t);
+  } else if (LM == 3) {
+    const V3 a0 = mulT(T.R, d0), a1 = mulT(T.R, d1);  // rows of dpi R
+    out->jl[0] = -a0.x; out->jl[1] = -a0.y; out->jl[2] = -a0.z;
+    out->jl[3] = -a1.x; out->jl[4] = -a1.y; out->jl[5] = -a1.z;
+  }
+  if (same_pose) {  // parallel_algos.h:97-99,111-113
+    for (int i = 0; i < 12; ++i) { out->jm[i] = 0.0; out->jr[i] = 0.0; }
+    return;
+  }
+  // measuring pose block (parallel_algos.h:91-96)
+  {
+    // world point (scaled by rho for LM == 1): Xw = R_ws_r ray + rho t_ws_r
+    V3 Xw = xv;
+    if (LM == 1) Xw = mul(t_ws_r.R, xv) + t_ws_r.t * rho;
+    // point in the vehicle frame of the measuring pose, R_pw (Xw - rho t_wp)
+    const V3 Pp = mulT(t_wp_m.R, Xw - t_wp_m.t * rho);
+    // translation columns: rho dpi R_sw
+    const V3 a0 = mulT(t_sw_m.R, d0), a1 = mulT(t_sw_m.R, d1);
+    out->jm[0] = rho * a0.x; out->jm[1] = rho * a0.y; out->jm[2] = rho * a0.z;
+    out->jm[6] = rho * a1.x; out->jm[7] = rho * a1.y; out->jm[8] = rho * a1.z;
+    // rotation columns: -dpi R_sv [Pp]x ; row^T [Pp]x = (row x ... ) -> -(b x Pp)... :
+    // (b^T [p]x)_j = (p x b)_j * -1 = (b x p)_j  =>  -b^T [p]x = p x b
+    const V3 b0 = mulT(t_sv_m.R, d0), b1 = mulT(t_sv_m.R, d1);  // rows of dpi R_sv
+    const V3 c0 = cross(Pp, b0), c1 = cross(Pp, b1);
+    out->jm[3] = c0.x; out->jm[4] = c0.y; out->jm[5] = c0.z;
+    out->jm[9] = c1.x; out->jm[10] = c1.y; out->jm[11] = c1.z;
+  }
+  if (LM == 1) {
+    // reference pose block (parallel_algos.h:104-110)
+    const V3 a0 = mulT(t_sw_m.R, d0), a1 = mulT(t_sw_m.R, d1);  // rows of dpi R_sw_m
+    out->jr[0] = -rho * a0.x; out->jr[1] = -rho * a0.y; out->jr[2] = -rho * a0.z;
+    out->jr[6] = -rho * a1.x; out->jr[7] = -rho * a1.y; out->jr[8] = -rho * a1.z;
+    // rows of dpi R_a, R_a = R_sw_m R_wp_r ; then (row^T [Y]x) = Y-cross: b^T [y]x = (b x y)... sign below
+    const V3 e0 = mulT(t_wp_r.R, a0), e1 = mulT(t_wp_r.R, a1);
+    const V3 Y = mul(t_vs_r.R, xv) + t_vs_r.t * rho;
+    // b^T [y]x = -(y x b)^T ... using (b^T [y]x)_j = sum_i b_i eps_{i k j} ... = (b x y)_j
+    const V3 f0 = cross(e0, Y), f1 = cross(e1, Y);
+    out->jr[3] = f0.x; out->jr[4] = f0.y; out->jr[5] = f0.z;
+    out->jr[9] = f1.x; out->jr[10] = f1.y; out->jr[11] = f1.z;
+  } else {
+    for (int i = 0; i < 12; ++i) out->jr[i] = 0.0;
+  }
+}
+
+}  // namespace bad

@@ -1,0 +1,162 @@
+// Internal declarations of the gfx950 engine behind include/ba_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ba_hip.h"
+
+namespace bae {
+
+// ---- small RAII-less device buffer (engine owns and frees explicitly) -------------
+template <typename T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    release();
+    if (count == 0) { n = 0; return hipSuccess; }
+    hipError_t err = hipMalloc((void**)&p, count * sizeof(T));
+    if (err == hipSuccess) n = count;
+    return err;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+// Rigid transform in matrix form as stored on the device: R row-major (9) then t (3).
+static const int kRt = 12;
+// Pose state row: t(3) q(4) v(3) b(6)
+static const int kPoseState = 16;
+// one factor row: 6 doubles (see DESIGN.md "factor rows")
+static const int kRow = 6;
+
+struct Problem {  // host copies, reference ids
+  uint32_t num_cams = 0, num_poses = 0, num_lms = 0, num_proj = 0;
+  uint32_t num_unary = 0, num_binary = 0, num_imu = 0;
+  std::vector<double> cam_params, cam_tvs;                 // [C][4], [C][7]
+  std::vector<double> pose_state;                          // [P][16]
+  std::vector<uint8_t> pose_active;
+  std::vector<double> lm_xw;                               // [L][4]
+  std::vector<uint32_t> lm_ref_pose, lm_ref_cam;
+  std::vector<uint8_t> lm_active;
+  std::vector<double> proj_z, proj_w;                      // [O][2], [O]
+  std::vector<uint32_t> proj_pose, proj_lm, proj_cam;
+  // pose-pose residuals
+  std::vector<uint32_t> un_pose; std::vector<double> un_t, un_cov_inv; std::vector<uint8_t> un_rot;
+  std::vector<uint32_t> bin_p1, bin_p2; std::vector<double> bin_t, bin_cov_inv, bin_cov_inv_sqrt, bin_w;
+  std::vector<uint8_t> bin_rot;
+  std::vector<uint32_t> imu_p1, imu_p2, imu_ptr; std::vector<double> imu_meas, imu_w;
+  double gravity[3] = {0, 0, -9.8007};
+};
+
+// Host-built structure (ba_hip_finalize)
+struct Structure {
+  uint32_t P = 0, Pact = 0, L = 0, Lact = 0, O = 0, C = 0;
+  uint32_t n = 0;         // pose_dim * Pact
+  uint32_t ld = 0;        // leading dimension of the dense reduced system (>= n+1, padded)
+  uint32_t n_inc = 0;     // pose-landmark incidences (active pose, active landmark)
+  uint32_t n_jslots = 0;  // (observation, side) slots carrying pose Jacobian rows
+  uint32_t n_rows = 0;    // factor rows
+  uint32_t n_pairs = 0;   // pose pairs (i <= j) with a block in S
+  uint64_t n_pair_entries = 0;
+  uint64_t n_rhs_entries = 0;
+  uint32_t n_ppair = 0;   // pose pairs receiving pose-pose residual blocks
+  std::vector<int32_t> pose_opt, lm_opt;
+  std::vector<uint32_t> obs_perm;  // sorted position -> residual id
+};
+
+struct Engine {
+  int lm_dim = 1, pose_dim = 6, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  ba_hip_options opt;
+  Problem prob;
+  Structure st;
+  bool finalized = false;
+  int cur = 0;  // current state buffer (0/1)
+  bool has_snapshot = false;
+  ba_hip_timers timers;
+  ba_hip_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  int rank = 0, nranks = 1;
+
+  // ---- device: static problem data
+  DBuf<double> cam;                 // [C][4 + 12 (T_vs) + 12 (T_sv)]
+  DBuf<int32_t> pose_opt, lm_opt;
+  DBuf<uint16_t> pose_mask;
+  DBuf<uint32_t> lm_ref_pose, lm_ref_cam;
+  DBuf<uint32_t> lm_ptr;            // [L+1] CSR over sorted observations
+  DBuf<double> obs_z;               // [O][2]
+  DBuf<uint32_t> obs_pose, obs_cam, obs_lm, obs_rid;
+  DBuf<double> obs_w0;
+  DBuf<int32_t> obs_jrow_m, obs_jrow_r;  // first factor row of the (obs,side) slot or -1
+  DBuf<int32_t> obs_wrow_m;              // first W factor row of the (meas pose, landmark) incidence or -1
+  DBuf<uint8_t> obs_first;               // 1 = first observation of its meas incidence
+  DBuf<int32_t> lm_wrow_r;               // first W factor row of the reference incidence or -1
+  DBuf<uint32_t> linc_ptr;               // [L+1] landmark-major incidence list
+  DBuf<uint32_t> linc_row;               // first W factor row of each incidence
+  DBuf<uint32_t> linc_pose;              // pose opt id of each incidence
+  // gather lists
+  DBuf<uint32_t> pair_ptr;               // [n_pairs+1] (64-bit offsets split? entries < 2^32 assumed)
+  DBuf<uint2> pair_ij;
+  DBuf<uint2> pair_ent;                  // (rowA, rowB)
+  DBuf<uint32_t> prhs_ptr;               // [Pact+1]
+  DBuf<uint2> prhs_ent;                  // (row, scalar index)
+
+  // ---- device: state (double buffered)
+  DBuf<double> pose_state[2];            // [P][16]
+  DBuf<double> lm_x[2];                  // [L][4]  x_s (lm_dim 1) or x_w (lm_dim 3)
+  DBuf<uint8_t> lm_reliable[2];
+  DBuf<double> lm_xw;                    // [L][4]  world points (upload / download, lm_dim 1)
+  DBuf<double> tsw, tws, twp;            // [P*C][12], [P*C][12], [P][12] for state `cur`
+  DBuf<uint32_t> lm_outliers;
+
+  // ---- device: per-iteration
+  DBuf<double> obs_e, obs_w;             // error for the median, robust weight
+  DBuf<double> obs_jl;                   // [O][2*lm] sqrt(w) * dz_dlm (dogleg J_l * rhs_l)
+  DBuf<double> frow;                     // [n_rows][6]
+  DBuf<double> scal;                     // scalars: [2*O] sqrt(w) r, then [L*lm] b_l
+  DBuf<double> lm_vinv, lm_bl;           // [L][lm*lm], [L][lm]
+  DBuf<double> A;                        // [(n+1)][ld] lower storage + rhs row
+  DBuf<double> rhs_p, rhs_sc;            // [n] unreduced / reduced (copy of A's last row)
+  DBuf<double> gn_p, gn_l, step_p, step_l;
+  DBuf<double> invdiag;                  // inverse diagonal tiles of the Cholesky factor
+  DBuf<double> partials;                 // reduction scratch
+  DBuf<double> scalars_out;              // small result block (device) + host mirror
+  DBuf<unsigned long long> hist;         // selection histograms
+  DBuf<int32_t> flags;                   // factorisation status etc.
+
+  int fail(hipError_t e, const char* what);
+  int fail_msg(const char* what);
+};
+
+#define BAE_HIP(call)                                                    \
+  do {                                                                   \
+    hipError_t _e = (call);                                              \
+    if (_e != hipSuccess) return e->fail(_e, #call);                     \
+  } while (0)
+
+// ---- kernel launchers (defined in k_*.hip); all enqueue on e->stream -------------
+int launch_pose_prep(Engine* e);                       // T_sw, T_ws, T_wp of the current state
+int launch_begin_solve(Engine* e);                     // x_s from x_w
+int launch_end_solve(Engine* e);                       // x_w from x_s
+int launch_residuals(Engine* e, int mode);             // mode 0: errors for the median; 1: EvaluateResiduals
+int launch_landmarks(Engine* e, double c_huber, int use_robust);  // Jacobians, V, W, rows
+int launch_gather_S(Engine* e);                        // pair gather -> A, rhs row, masks
+int launch_backsub(Engine* e);                         // delta_l
+int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norms2_host);
+int launch_apply_step(Engine* e);                      // state[cur] -> state[1-cur]
+int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out);
+int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out);
+int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out);
+int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status);
+
+}  // namespace bae

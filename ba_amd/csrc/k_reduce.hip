@@ -1,0 +1,405 @@
+// gfx950 kernels that assemble the reduced camera system and the scalar reductions:
+//   * k_gather_S / k_gather_rhs — deterministic gathers that replace the reference's
+//     block-sparse products jt_pr*j_pr, jt_pr*j_l*vi*jt_l*j_pr and the dense write of
+//     S = U - W V^-1 W^T (BundleAdjuster.cpp:337-354, 448-485; SparseBlockMatrixOps.h:
+//     182-254, 318-364).  Every 6x6 block of S is the sum of rank-1 products of "factor
+//     rows" emitted by k_landmarks; the list of products per pose pair is static across
+//     Gauss-Newton iterations and is built once per Solve() on the host.  No atomics: S
+//     and rhs are bitwise reproducible.
+//   * exact k-th element selection for the Huber sigma (std::nth_element,
+//     BundleAdjuster.cpp:1356-1358)
+//   * step composition, norms and the dogleg scalars (BundleAdjuster.cpp:858-1017)
+#include "engine.h"
+#include <cstring>
+
+namespace bae {
+
+// ---------------------------------------------------------------------------------
+// One wavefront per pose pair (i <= j).  Lane (r,c), r = lane / 6, c = lane % 6 < 36
+// owns element (r,c) of the 6x6 block; the entry list is wave-uniform (scalar loads),
+// the factor rows are 48-byte gathers served by L2 / Infinity Cache (rows are laid out
+// pose-major, so one pair touches two contiguous row ranges).
+// Output: lower storage of the symmetric S, row-major with leading dimension ld:
+// block (i,j), i<j, is written transposed at rows j*D.., cols i*D..; diagonal blocks in
+// full.  Masked parameters: S(idx,idx) = 1e6 (BundleAdjuster.cpp:587-598) — their rows
+// and columns are already zero because k_landmarks zeroed the Jacobian columns.
+__global__ void __launch_bounds__(256)
+k_gather_S(uint32_t npairs, const uint32_t* __restrict__ pair_ptr,
+           const uint2* __restrict__ pair_ij, const uint2* __restrict__ pair_ent,
+           const double* __restrict__ frow, int D, uint32_t ld,
+           const uint16_t* __restrict__ mask_opt, double* __restrict__ A) {
+  const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= npairs) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t e0 = pair_ptr[pair], e1 = pair_ptr[pair + 1];
+  const uint2 ij = pair_ij[pair];
+  const int r = lane / 6, c = lane - 6 * r;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  if (lane < 36) {
+    uint32_t e = e0;
+    for (; e + 4 <= e1; e += 4) {
+      const uint2 p0 = pair_ent[e], p1 = pair_ent[e + 1], p2 = pair_ent[e + 2], p3 = pair_ent[e + 3];
+      const double a0 = frow[(size_t)p0.x * kRow + r], b0 = frow[(size_t)p0.y * kRow + c];
+      const double a1 = frow[(size_t)p1.x * kRow + r], b1 = frow[(size_t)p1.y * kRow + c];
+      const double a2 = frow[(size_t)p2.x * kRow + r], b2 = frow[(size_t)p2.y * kRow + c];
+      const double a3 = frow[(size_t)p3.x * kRow + r], b3 = frow[(size_t)p3.y * kRow + c];
+      acc0 += a0 * b0; acc1 += a1 * b1; acc2 += a2 * b2; acc3 += a3 * b3;
+    }
+    for (; e < e1; ++e) {
+      const uint2 p0 = pair_ent[e];
+      acc0 += frow[(size_t)p0.x * kRow + r] * frow[(size_t)p0.y * kRow + c];
+    }
+  }
+  double acc = (acc0 + acc1) + (acc2 + acc3);
+  const uint32_t i = ij.x, j = ij.y;
+  if (i == j) {
+    const uint16_t m = mask_opt[i];
+    if (lane < 36) {
+      if (r == c && (m & (1u << r))) acc = 1e6;
+      A[((size_t)i * D + r) * ld + (size_t)i * D + c] = acc;
+    } else if (lane - 36 < D - 6) {
+      const int k = 6 + (lane - 36);
+      if (m & (1u << k)) A[((size_t)i * D + k) * ld + (size_t)i * D + k] = 1e6;
+    }
+  } else if (lane < 36) {
+    A[((size_t)j * D + c) * ld + (size_t)i * D + r] = acc;
+  }
+}
+
+// rows n..n_pad-1 of the padded system: identity
+__global__ void k_pad_diag(uint32_t n, uint32_t n_pad, uint32_t ld, double* __restrict__ A) {
+  const uint32_t k = n + blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_pad) A[(size_t)k * ld + k] = 1.0;
+}
+
+// One wavefront per active pose: rhs_p[i] = sum F[row] * scal[idx] over the pose's
+// observation rows (jt_pr * r_pr, BundleAdjuster.cpp:348-353), then minus W V^-1 rhs_l
+// over its incidences (:480-484).  Lanes = 10 entry slots x 6 components; slots are
+// combined in a fixed order.
+__global__ void __launch_bounds__(256)
+k_gather_rhs(uint32_t npose, const uint32_t* __restrict__ prhs_ptr,
+             const uint32_t* __restrict__ prhs_mid, const uint2* __restrict__ prhs_ent,
+             const double* __restrict__ frow, const double* __restrict__ scal, int D,
+             double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
+  __shared__ double red[4][2][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t i = blockIdx.x * 4 + w;
+  const bool valid = i < npose;
+  double accA = 0.0, accB = 0.0;
+  if (valid && lane < 60) {
+    const int slot = lane / 6, c = lane - 6 * slot;
+    const uint32_t e0 = prhs_ptr[i], em = prhs_mid[i], e1 = prhs_ptr[i + 1];
+    for (uint32_t e = e0 + slot; e < em; e += 10) {
+      const uint2 p = prhs_ent[e];
+      accA += frow[(size_t)p.x * kRow + c] * scal[p.y];
+    }
+    for (uint32_t e = em + slot; e < e1; e += 10) {
+      const uint2 p = prhs_ent[e];
+      accB += frow[(size_t)p.x * kRow + c] * scal[p.y];
+    }
+  }
+  red[w][0][lane] = accA;
+  red[w][1][lane] = accB;
+  __syncthreads();
+  if (valid && lane < 6) {
+    double sa = 0.0, sb = 0.0;
+    for (int s = 0; s < 10; ++s) { sa += red[w][0][s * 6 + lane]; sb += red[w][1][s * 6 + lane]; }
+    rhs_p[(size_t)i * D + lane] = sa;
+    rhs_sc[(size_t)i * D + lane] = sa + sb;
+  }
+}
+
+int launch_gather_S(Engine* e) {
+  const Structure& st = e->st;
+  const uint32_t n = st.n, ld = st.ld, n_pad = ld;
+  // zero the whole lower storage + rhs row, then identity on the padding
+  BAE_HIP(hipMemsetAsync(e->A.p, 0, (size_t)(n_pad + 1) * ld * sizeof(double), e->stream));
+  if (n_pad > n) {
+    hipLaunchKernelGGL(k_pad_diag, dim3((n_pad - n + 255) / 256), dim3(256), 0, e->stream, n, n_pad,
+                       ld, e->A.p);
+    BAE_HIP(hipGetLastError());
+  }
+  BAE_HIP(hipMemsetAsync(e->rhs_p.p, 0, e->rhs_p.bytes(), e->stream));
+  BAE_HIP(hipMemsetAsync(e->rhs_sc.p, 0, e->rhs_sc.bytes(), e->stream));
+  if (st.n_pairs > 0) {
+    hipLaunchKernelGGL(k_gather_S, dim3((st.n_pairs + 3) / 4), dim3(256), 0, e->stream, st.n_pairs,
+                       e->pair_ptr.p, e->pair_ij.p, e->pair_ent.p, e->frow.p, e->pose_dim, ld,
+                       e->pose_mask.p + st.P /* masks by opt id live after the by-id masks */,
+                       e->A.p);
+    BAE_HIP(hipGetLastError());
+  }
+  if (st.Pact > 0 && st.O > 0) {
+    hipLaunchKernelGGL(k_gather_rhs, dim3((st.Pact + 3) / 4), dim3(256), 0, e->stream, st.Pact,
+                       e->prhs_ptr.p, e->prhs_ptr.p + (st.Pact + 1), e->prhs_ent.p, e->frow.p,
+                       e->scal.p, e->pose_dim, e->rhs_p.p, e->rhs_sc.p);
+    BAE_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Fixed-order sum of `ncomp` rows of `nparts` partial sums (one block).
+__global__ void k_sum_partials(uint32_t nparts, uint32_t ncomp, const double* __restrict__ parts,
+                               double* __restrict__ out) {
+  __shared__ double red[256];
+  for (uint32_t c = 0; c < ncomp; ++c) {
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < nparts; i += 256) s += parts[(size_t)c * nparts + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+    __syncthreads();
+  }
+}
+
+int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out) {
+  if (nparts == 0) {
+    for (uint32_t c = 0; c < ncomp; ++c) host_out[c] = 0.0;
+  } else {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, e->stream, nparts, ncomp,
+                       e->partials.p, e->scalars_out.p);
+    BAE_HIP(hipGetLastError());
+    BAE_HIP(hipMemcpyAsync(host_out, e->scalars_out.p, ncomp * sizeof(double),
+                           hipMemcpyDeviceToHost, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+  }
+  if (e->allreduce && e->nranks > 1) {
+    // cross-shard sum of the scalars
+    BAE_HIP(hipMemcpyAsync(e->scalars_out.p, host_out, ncomp * sizeof(double),
+                           hipMemcpyHostToDevice, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+    if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, ncomp, 0) != 0)
+      return e->fail_msg("allreduce hook failed");
+    BAE_HIP(hipMemcpy(host_out, e->scalars_out.p, ncomp * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Exact selection of the k-th smallest of non-negative doubles by most-significant-
+// digit radix passes over their bit patterns (monotone for x >= 0): six passes of 11
+// bits; per pass an LDS-privatised 2048-bin histogram of the values whose higher bits
+// equal the prefix found so far.  The histogram is the only thing that crosses shards
+// (summed by the all-reduce hook), so the multi-GPU median is exact too.
+__global__ void __launch_bounds__(256)
+k_select_hist(uint32_t n, const double* __restrict__ v, unsigned long long prefix,
+              unsigned long long prefix_mask, int shift, unsigned int digit_mask,
+              unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int h[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+    if ((b & prefix_mask) == prefix) atomicAdd(&h[(b >> shift) & digit_mask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out) {
+  // digits from the top: bits [63:53] [52:42] [41:31] [30:20] [19:9] [8:0](9 bits, shift 0)
+  static const int shifts[6] = {53, 42, 31, 20, 9, 0};
+  unsigned long long prefix = 0, mask = 0;
+  std::vector<unsigned long long> hh(2048);
+  for (int pass = 0; pass < 6; ++pass) {
+    const int shift = shifts[pass];
+    BAE_HIP(hipMemsetAsync(e->hist.p, 0, 2048 * sizeof(unsigned long long), e->stream));
+    if (n_local > 0) {
+      uint32_t grid = (n_local + 255) / 256;
+      if (grid > 2048) grid = 2048;
+      hipLaunchKernelGGL(k_select_hist, dim3(grid), dim3(256), 0, e->stream, n_local, d_values,
+                         prefix, mask, shift, pass == 5 ? 511u : 2047u, e->hist.p);
+      BAE_HIP(hipGetLastError());
+    }
+    BAE_HIP(hipStreamSynchronize(e->stream));
+    if (e->allreduce && e->nranks > 1)
+      if (e->allreduce(e->allreduce_ctx, e->hist.p, 2048, 1) != 0)
+        return e->fail_msg("allreduce hook failed");
+    BAE_HIP(hipMemcpy(hh.data(), e->hist.p, 2048 * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
+    const int nbins = pass == 5 ? 512 : 2048;
+    int bin = 0;
+    for (; bin < nbins; ++bin) {
+      if (k < hh[bin]) break;
+      k -= hh[bin];
+    }
+    if (bin >= nbins) return e->fail_msg("select_kth: rank out of range");
+    const unsigned long long digit_mask = (pass == 5 ? 511ull : 2047ull) << shift;
+    prefix |= ((unsigned long long)bin << shift);
+    mask |= digit_mask;
+  }
+  double r;
+  memcpy(&r, &prefix, sizeof(double));
+  *out = r;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// step = coef_rhs * rhs + coef_gn * gn for poses (by opt id) and landmarks (rhs_l is
+// stored by landmark id, steps by opt id); partial squared norms per block.
+__global__ void k_compose(uint32_t n, double a, double b, const double* __restrict__ rhs,
+                          const double* __restrict__ gn, double* __restrict__ step,
+                          double* __restrict__ partials) {
+  __shared__ double red[256];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (i < n) {
+    v = a * rhs[i] + (b != 0.0 ? b * gn[i] : 0.0);
+    step[i] = v;
+  }
+  red[threadIdx.x] = v * v;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+__global__ void k_compose_lm(uint32_t L, int LM, double a, double b,
+                             const int32_t* __restrict__ lm_opt, const double* __restrict__ bl,
+                             const double* __restrict__ gn, double* __restrict__ step,
+                             double* __restrict__ partials) {
+  __shared__ double red[256];
+  const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double sq = 0.0;
+  if (l < L) {
+    const int lo = lm_opt[l];
+    if (lo >= 0) {
+      for (int k = 0; k < LM; ++k) {
+        const double v = a * bl[l * LM + k] + (b != 0.0 ? b * gn[(size_t)lo * LM + k] : 0.0);
+        step[(size_t)lo * LM + k] = v;
+        sq += v * v;
+      }
+    }
+  }
+  red[threadIdx.x] = sq;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norms2_host) {
+  const Structure& st = e->st;
+  norms2_host[0] = norms2_host[1] = 0.0;
+  if (st.n > 0) {
+    const uint32_t nb = (st.n + 255) / 256;
+    hipLaunchKernelGGL(k_compose, dim3(nb), dim3(256), 0, e->stream, st.n, coef_rhs, coef_gn,
+                       e->rhs_p.p, e->gn_p.p, e->step_p.p, e->partials.p);
+    BAE_HIP(hipGetLastError());
+    // the pose step is replicated on every shard: no cross-shard sum
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, e->stream, nb, 1u, e->partials.p,
+                       e->scalars_out.p);
+    BAE_HIP(hipGetLastError());
+    BAE_HIP(hipMemcpyAsync(&norms2_host[0], e->scalars_out.p, sizeof(double),
+                           hipMemcpyDeviceToHost, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+  }
+  if (st.L > 0 && e->lm_dim > 0 && st.Lact > 0) {
+    const uint32_t nb = (st.L + 255) / 256;
+    hipLaunchKernelGGL(k_compose_lm, dim3(nb), dim3(256), 0, e->stream, st.L, e->lm_dim, coef_rhs,
+                       coef_gn, e->lm_opt.p, e->lm_bl.p, e->gn_l.p, e->step_l.p, e->partials.p);
+    BAE_HIP(hipGetLastError());
+    int rc = sum_partials(e, nb, 1, &norms2_host[1]);  // landmarks are sharded: summed
+    if (rc) return rc;
+  } else if (e->allreduce && e->nranks > 1) {
+    int rc = sum_partials(e, 0, 1, &norms2_host[1]);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Dogleg scalars.  Pose-part dots (replicated across shards) and landmark-part dots
+// (sharded), plus ||J_pr rhs_p + J_l rhs_l||^2 over the observations
+// (BundleAdjuster.cpp:881-910).
+__global__ void k_dots_pose(uint32_t n, int gn_ok, const double* __restrict__ rhs,
+                            const double* __restrict__ gn, double* __restrict__ partials,
+                            uint32_t nparts) {
+  __shared__ double red[3][256];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double r = 0, g = 0;
+  if (i < n) { r = rhs[i]; g = gn_ok ? gn[i] : 0.0; }
+  red[0][threadIdx.x] = r * r; red[1][threadIdx.x] = g * g; red[2][threadIdx.x] = r * g;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k)
+      for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 3; ++c) partials[(size_t)c * nparts + blockIdx.x] = red[c][0];
+}
+__global__ void k_dots_lm(uint32_t L, int LM, int gn_ok, const int32_t* __restrict__ lm_opt,
+                          const double* __restrict__ bl, const double* __restrict__ gn,
+                          double* __restrict__ partials, uint32_t nparts) {
+  __shared__ double red[3][256];
+  const size_t l = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double rr = 0, gg = 0, rg = 0;
+  if (l < L) {
+    const int lo = lm_opt[l];
+    if (lo >= 0)
+      for (int k = 0; k < LM; ++k) {
+        const double r = bl[l * LM + k], g = gn_ok ? gn[(size_t)lo * LM + k] : 0.0;
+        rr += r * r; gg += g * g; rg += r * g;
+      }
+  }
+  red[0][threadIdx.x] = rr; red[1][threadIdx.x] = gg; red[2][threadIdx.x] = rg;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k)
+      for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (int c = 0; c < 3; ++c) partials[(size_t)c * nparts + blockIdx.x] = red[c][0];
+}
+// per observation: v = sqrt(w) (Jm rhs_p[m] + Jr rhs_p[r] + Jl rhs_l[l]); sum |v|^2
+__global__ void k_jrhs(uint32_t O, int D, int LM, const int32_t* __restrict__ obs_jrow_m,
+                       const int32_t* __restrict__ obs_jrow_r, const uint32_t* __restrict__ obs_pose,
+                       const uint32_t* __restrict__ obs_lm, const uint32_t* __restrict__ lm_ref_pose,
+                       const int32_t* __restrict__ pose_opt, const int32_t* __restrict__ lm_opt,
+                       const double* __restrict__ frow, const double* __restrict__ obs_jl,
+                       const double* __restrict__ rhs_p, const double* __restrict__ bl,
+                       double* __restrict__ partials) {
+  __shared__ double red[256];
+  const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double sq = 0.0;
+  if (a < O) {
+    double v0 = 0, v1 = 0;
+    const int jm = obs_jrow_m[a], jr = obs_jrow_r[a];
+    const uint32_t l = obs_lm[a];
+    if (jm >= 0) {
+      const double* g = rhs_p + (size_t)pose_opt[obs_pose[a]] * D;
+      const double* r0 = frow + (size_t)jm * kRow;
+      for (int c = 0; c < 6; ++c) { v0 += r0[c] * g[c]; v1 += r0[kRow + c] * g[c]; }
+    }
+    if (jr >= 0) {
+      const double* g = rhs_p + (size_t)pose_opt[lm_ref_pose[l]] * D;
+      const double* r0 = frow + (size_t)jr * kRow;
+      for (int c = 0; c < 6; ++c) { v0 += r0[c] * g[c]; v1 += r0[kRow + c] * g[c]; }
+    }
+    if (lm_opt[l] >= 0)
+      for (int k = 0; k < LM; ++k) {
+        v0 += obs_jl[a * 2 * LM + k] * bl[(size_t)l * LM + k];
+        v1 += obs_jl[a * 2 * LM + LM + k] * bl[(size_t)l * LM + k];
+      }
+    sq = v0 * v0 + v1 * v1;
+  }
+  red[threadIdx.x] = sq;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+}  // namespace bae

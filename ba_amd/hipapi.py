@@ -1,0 +1,285 @@
+"""ctypes binding of the C-ABI in include/ba_hip.h (ba_amd/lib/libba_hip.so).
+
+The library is the product: if it is missing or no MI355X is usable this module fails
+loudly — there is no CPU fallback anywhere in ba_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libba_hip.so")
+
+dp = C.POINTER(C.c_double)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+
+
+class Options(C.Structure):
+    _fields_ = [("projection_outlier_threshold", C.c_double),
+                ("use_robust_norm_for_proj_residuals", C.c_int32),
+                ("use_robust_norm_for_inertial_residuals", C.c_int32),
+                ("use_triangular_matrices", C.c_int32), ("reserved", C.c_int32),
+                ("gyro_sigma", C.c_double), ("accel_sigma", C.c_double),
+                ("gyro_bias_sigma", C.c_double), ("accel_bias_sigma", C.c_double)]
+
+
+class Errors(C.Structure):
+    _fields_ = [("proj_error", C.c_double), ("binary_error", C.c_double),
+                ("unary_error", C.c_double), ("inertial_error", C.c_double)]
+
+    def total(self):
+        return self.proj_error + self.binary_error + self.unary_error + self.inertial_error
+
+
+class DoglegScalars(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("rhs_p_sq", "rhs_l_sq", "j_rhs_sq", "gn_p_sq",
+                                          "gn_l_sq", "rhs_gn_p", "rhs_gn_l")]
+
+
+class StepNorms(C.Structure):
+    _fields_ = [("step_p_norm", C.c_double), ("step_l_norm", C.c_double)]
+
+
+class Timers(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("j_evaluation", "robust_weights", "jtj_schur", "solve",
+                                          "back_substitution", "evaluate_residuals",
+                                          "apply_update")]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+# every entry point include/ba_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "ba_hip_create", "ba_hip_destroy", "ba_hip_last_error", "ba_hip_set_options",
+    "ba_hip_set_cameras", "ba_hip_set_poses", "ba_hip_set_landmarks",
+    "ba_hip_set_projection_residuals", "ba_hip_set_unary_residuals",
+    "ba_hip_set_binary_residuals", "ba_hip_set_imu_residuals", "ba_hip_set_gravity",
+    "ba_hip_finalize", "ba_hip_begin_solve", "ba_hip_set_pose_masks", "ba_hip_linearize",
+    "ba_hip_solve_gn", "ba_hip_dogleg_terms", "ba_hip_compose_step", "ba_hip_apply_step",
+    "ba_hip_rollback", "ba_hip_eval_residuals", "ba_hip_end_solve", "ba_hip_get_poses",
+    "ba_hip_get_landmarks", "ba_hip_get_landmark_flags", "ba_hip_num_pose_params",
+    "ba_hip_num_lm_params", "ba_hip_get_S", "ba_hip_get_rhs", "ba_hip_get_delta_gn",
+    "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_timers", "ba_hip_device_buffer",
+    "ba_hip_set_allreduce", "ba_hip_dense_solve", "ba_hip_select_kth",
+]
+
+
+def build(force=False):
+    """Compile the gfx950 engine in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean", "-s"])
+    subprocess.check_call(["make", "-C", src, "-j4", "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "ba_amd: %s is missing — build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+                % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ba_hip_last_error.restype = C.c_char_p
+        _lib.ba_hip_num_pose_params.restype = C.c_uint32
+        _lib.ba_hip_num_lm_params.restype = C.c_uint32
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class Engine:
+    """Thin object wrapper of one ba_hip_engine (one device)."""
+
+    def __init__(self, lm_dim=1, pose_dim=6, device=0, stream=None):
+        self.L = lib()
+        self.lm_dim, self.pose_dim = lm_dim, pose_dim
+        self.h = C.c_void_p()
+        rc = self.L.ba_hip_create(lm_dim, pose_dim, device, C.c_void_p(stream), C.byref(self.h))
+        if rc != 0 or not self.h:
+            raise HipError("ba_hip_create failed (rc=%d): no usable HIP device — "
+                           "the engine has no CPU fallback" % rc)
+        self._cb = None
+
+    def close(self):
+        if self.h:
+            self.L.ba_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, positive_ok=False):
+        if rc < 0 or (rc > 0 and not positive_ok):
+            raise HipError("ba_hip call failed rc=%d: %s" %
+                           (rc, self.L.ba_hip_last_error(self.h).decode()))
+        return rc
+
+    # -- upload ----------------------------------------------------------------
+    def set_options(self, opt):
+        self._chk(self.L.ba_hip_set_options(self.h, C.byref(opt)))
+
+    def set_cameras(self, params, t_vs):
+        p, t = _d(params).reshape(-1, 4), _d(t_vs).reshape(-1, 7)
+        self._chk(self.L.ba_hip_set_cameras(self.h, p.shape[0], _p(p, dp), _p(t, dp)))
+
+    def set_poses(self, t_wp, v_w=None, b=None, is_active=None):
+        t = _d(t_wp).reshape(-1, 7)
+        v = _d(v_w) if v_w is not None else None
+        bb = _d(b) if b is not None else None
+        a = np.ascontiguousarray(is_active, dtype=np.uint8) if is_active is not None else None
+        self._chk(self.L.ba_hip_set_poses(self.h, t.shape[0], _p(t, dp), _p(v, dp), _p(bb, dp),
+                                          _p(a, u8p)))
+
+    def set_landmarks(self, x_w, ref_pose, ref_cam=None, is_active=None):
+        x = _d(x_w).reshape(-1, 4)
+        rp = np.ascontiguousarray(ref_pose, dtype=np.uint32)
+        rc = np.ascontiguousarray(ref_cam, dtype=np.uint32) if ref_cam is not None else None
+        a = np.ascontiguousarray(is_active, dtype=np.uint8) if is_active is not None else None
+        self._chk(self.L.ba_hip_set_landmarks(self.h, x.shape[0], _p(x, dp), _p(rp, u32p),
+                                              _p(rc, u32p), _p(a, u8p)))
+
+    def set_projection_residuals(self, z, pose, lm, cam=None, weight=None):
+        zz = _d(z).reshape(-1, 2)
+        pp = np.ascontiguousarray(pose, dtype=np.uint32)
+        ll = np.ascontiguousarray(lm, dtype=np.uint32)
+        cc = np.ascontiguousarray(cam, dtype=np.uint32) if cam is not None else None
+        ww = _d(weight) if weight is not None else None
+        self._chk(self.L.ba_hip_set_projection_residuals(self.h, zz.shape[0], _p(zz, dp),
+                                                         _p(pp, u32p), _p(ll, u32p), _p(cc, u32p),
+                                                         _p(ww, dp)))
+
+    def finalize(self):
+        self._chk(self.L.ba_hip_finalize(self.h))
+
+    # -- phases ----------------------------------------------------------------
+    def begin_solve(self):
+        self._chk(self.L.ba_hip_begin_solve(self.h))
+
+    def set_pose_masks(self, masks):
+        m = np.ascontiguousarray(masks, dtype=np.uint16)
+        self._chk(self.L.ba_hip_set_pose_masks(self.h, m.shape[0], _p(m, u16p)))
+
+    def linearize(self):
+        e = Errors()
+        self._chk(self.L.ba_hip_linearize(self.h, C.byref(e)))
+        return e
+
+    def solve_gn(self):
+        return self._chk(self.L.ba_hip_solve_gn(self.h), positive_ok=True)
+
+    def dogleg_terms(self, gn_available):
+        s = DoglegScalars()
+        self._chk(self.L.ba_hip_dogleg_terms(self.h, int(gn_available), C.byref(s)))
+        return s
+
+    def compose_step(self, coef_rhs, coef_gn):
+        n = StepNorms()
+        self._chk(self.L.ba_hip_compose_step(self.h, C.c_double(coef_rhs), C.c_double(coef_gn),
+                                             C.byref(n)))
+        return n
+
+    def apply_step(self):
+        self._chk(self.L.ba_hip_apply_step(self.h))
+
+    def rollback(self):
+        self._chk(self.L.ba_hip_rollback(self.h))
+
+    def eval_residuals(self):
+        e = Errors()
+        self._chk(self.L.ba_hip_eval_residuals(self.h, C.byref(e)))
+        return e
+
+    def end_solve(self):
+        self._chk(self.L.ba_hip_end_solve(self.h))
+
+    # -- results -----------------------------------------------------------------
+    def num_pose_params(self):
+        return self.L.ba_hip_num_pose_params(self.h)
+
+    def num_lm_params(self):
+        return self.L.ba_hip_num_lm_params(self.h)
+
+    def get_poses(self, n):
+        t, v, b = np.empty((n, 7)), np.empty((n, 3)), np.empty((n, 6))
+        self._chk(self.L.ba_hip_get_poses(self.h, _p(t, dp), _p(v, dp), _p(b, dp)))
+        return t, v, b
+
+    def get_landmarks(self, n):
+        x = np.empty((n, 4))
+        self._chk(self.L.ba_hip_get_landmarks(self.h, _p(x, dp)))
+        return x
+
+    def get_landmark_flags(self, n):
+        r, o = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint32)
+        self._chk(self.L.ba_hip_get_landmark_flags(self.h, _p(r, u8p), _p(o, u32p)))
+        return r, o
+
+    def get_S(self):
+        n = self.num_pose_params()
+        s = np.empty((n, n))
+        self._chk(self.L.ba_hip_get_S(self.h, _p(s, dp)))
+        return s
+
+    def get_rhs(self):
+        n, nl = self.num_pose_params(), self.num_lm_params()
+        a, b, c = np.empty(n), np.empty(n), np.zeros(max(nl, 1))
+        self._chk(self.L.ba_hip_get_rhs(self.h, _p(a, dp), _p(b, dp), _p(c, dp)))
+        return a, b, c[:nl]
+
+    def get_delta_gn(self):
+        n, nl = self.num_pose_params(), self.num_lm_params()
+        a, c = np.empty(n), np.zeros(max(nl, 1))
+        self._chk(self.L.ba_hip_get_delta_gn(self.h, _p(a, dp), _p(c, dp)))
+        return a, c[:nl]
+
+    def get_step(self):
+        n, nl = self.num_pose_params(), self.num_lm_params()
+        a, c = np.empty(n), np.zeros(max(nl, 1))
+        self._chk(self.L.ba_hip_get_step(self.h, _p(a, dp), _p(c, dp)))
+        return a, c[:nl]
+
+    def get_proj_weights(self, n):
+        w = np.empty(n)
+        self._chk(self.L.ba_hip_get_proj_weights(self.h, _p(w, dp)))
+        return w
+
+    def get_timers(self):
+        t = Timers()
+        self._chk(self.L.ba_hip_get_timers(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in Timers._fields_}
+
+    def dense_solve(self, a_lower, b):
+        a, b = _d(a_lower), _d(b)
+        x = np.empty(b.shape[0])
+        rc = self._chk(self.L.ba_hip_dense_solve(self.h, b.shape[0], _p(a, dp), _p(b, dp), _p(x, dp)),
+                       positive_ok=True)
+        return x, rc
+
+    def select_kth(self, values, k):
+        v = _d(values)
+        out = C.c_double()
+        self._chk(self.L.ba_hip_select_kth(self.h, v.shape[0], _p(v, dp), int(k), C.byref(out)))
+        return out.value

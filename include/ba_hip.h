@@ -1,0 +1,189 @@
+/*
+ * ba_hip.h — C-ABI of the MI355X (gfx950) engine behind ba::BundleAdjuster<>::Solve().
+ *
+ * The reference (arpg/ba) has no FFI layer: its boundary is the C++ class template
+ * ba::BundleAdjuster (/root/reference/include/ba/BundleAdjuster.h:111-753) whose only
+ * non-inline member is Solve() (/root/reference/src/BundleAdjuster.cpp:278-705).  This
+ * header is the boundary inserted *inside* Solve(): the host class (include/ba/
+ * BundleAdjuster.h in this repo) marshals its problem graph into flat SoA arrays once
+ * per Solve() and then drives one Gauss-Newton / dogleg iteration as a short sequence of
+ * the calls below; only scalars come back per iteration.  Each entry point names the
+ * reference code it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; every pointer argument is caller-owned host memory
+ *     that is copied during the call unless stated otherwise;
+ *   - every function returns int: 0 = ok, <0 = HIP/runtime failure (ba_hip_last_error()
+ *     gives text), >0 = numeric status mirroring ba::OptimizationResult
+ *     (BundleAdjuster.h:38-46): BA_HIP_FACTORIZATION_ERROR;
+ *   - never throws; no global state; one host thread per engine; calls are synchronous
+ *     on return (the engine's stream is drained) unless suffixed _async;
+ *   - rigid transforms are 7 doubles [tx,ty,tz,qx,qy,qz,qw]; ids are dense uint32 in
+ *     insertion order exactly as the reference's Add* calls return them;
+ *   - multi-GPU: one engine per device, each holding ALL poses and its shard of
+ *     landmarks/projection residuals; the per-iteration sums that cross shards go
+ *     through the caller-supplied all-reduce hook (ba_hip_set_allreduce), e.g. RCCL.
+ */
+#ifndef BA_HIP_H
+#define BA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BA_HIP_OK 0
+#define BA_HIP_FACTORIZATION_ERROR 4 /* ba::FactorizationError, BundleAdjuster.h:44 */
+#define BA_HIP_SOLVER_ERROR 5        /* ba::SolverError,        BundleAdjuster.h:45 */
+
+typedef struct ba_hip_engine ba_hip_engine;
+
+/* Options the device phases need (subset of ba::Options, BundleAdjuster.h:72-107). */
+typedef struct {
+  double projection_outlier_threshold;            /* BundleAdjuster.cpp:184 */
+  int32_t use_robust_norm_for_proj_residuals;     /* BundleAdjuster.cpp:1377 */
+  int32_t use_robust_norm_for_inertial_residuals; /* BundleAdjuster.cpp:1513 */
+  int32_t use_triangular_matrices;                /* only affects debug downloads of S */
+  int32_t reserved;
+  double gyro_sigma, accel_sigma, gyro_bias_sigma, accel_bias_sigma; /* BundleAdjuster.h:204-218 */
+} ba_hip_options;
+
+/* The four error sums of EvaluateResiduals / BuildProblem (BundleAdjuster.cpp:144-274,
+ * 1340-1537; BundleAdjuster.h:593-602). */
+typedef struct {
+  double proj_error, binary_error, unary_error, inertial_error;
+} ba_hip_errors;
+
+/* Scalars of the dogleg step (BundleAdjuster.cpp:858-1017): squared norms and dot
+ * products over the pose (p) and landmark (l) parts of rhs (= J^T r, unreduced) and of
+ * the Gauss-Newton step, and the steepest-descent denominator ||J rhs||^2. */
+typedef struct {
+  double rhs_p_sq, rhs_l_sq;   /* :858 numerator */
+  double j_rhs_sq;             /* :906-910 denominator */
+  double gn_p_sq, gn_l_sq;     /* :971-973 */
+  double rhs_gn_p, rhs_gn_l;   /* dot products for a, b of :994-998 */
+} ba_hip_dogleg_scalars;
+
+/* Norms of the step formed by ba_hip_compose_step (summary_.delta_norm is their sum,
+ * BundleAdjuster.cpp:26). */
+typedef struct {
+  double step_p_norm, step_l_norm;
+} ba_hip_step_norms;
+
+/* Per-phase device time of the last iteration, milliseconds (HIP events on the engine's
+ * stream); names follow the reference's PrintTimer sites (Utils.h:51-62). */
+typedef struct {
+  double j_evaluation, robust_weights, jtj_schur, solve, back_substitution,
+         evaluate_residuals, apply_update;
+} ba_hip_timers;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+/* lm_dim in {0,1,3}, pose_dim in {6,9,15} (the reference's LmSize / PoseSize template
+ * parameters, BundleAdjuster.h:111-134).  stream: a hipStream_t to run on, or NULL for
+ * an engine-owned stream.  Fails (<0) when no HIP device is usable: there is no CPU
+ * fallback. */
+int ba_hip_create(int lm_dim, int pose_dim, int device, void* stream, ba_hip_engine** out);
+void ba_hip_destroy(ba_hip_engine* e);
+const char* ba_hip_last_error(const ba_hip_engine* e);
+int ba_hip_set_options(ba_hip_engine* e, const ba_hip_options* o);
+
+/* ---- problem upload (replaces the AoS graph of Types.h:41-321) -------------------- */
+/* calibu::Rig cameras: pinhole params [fx,fy,u0,v0] and T_vs (BundleAdjuster.h:259-263) */
+int ba_hip_set_cameras(ba_hip_engine* e, uint32_t n, const double* params4, const double* t_vs7);
+/* poses_ (BundleAdjuster.h:292-323); v_w/b may be NULL (zeros) */
+int ba_hip_set_poses(ba_hip_engine* e, uint32_t n, const double* t_wp7, const double* v_w3,
+                     const double* b6, const uint8_t* is_active);
+/* landmarks_ (BundleAdjuster.h:326-367): homogeneous world point, reference pose/camera */
+int ba_hip_set_landmarks(ba_hip_engine* e, uint32_t n, const double* x_w4,
+                         const uint32_t* ref_pose_id, const uint32_t* ref_cam_id,
+                         const uint8_t* is_active);
+/* ACCEPTED projection residuals in residual-id order (BundleAdjuster.h:459-513) */
+int ba_hip_set_projection_residuals(ba_hip_engine* e, uint32_t n, const double* z2,
+                                    const uint32_t* meas_pose_id, const uint32_t* landmark_id,
+                                    const uint32_t* cam_id, const double* weight);
+/* unary_residuals_ (BundleAdjuster.h:377-407): prior pose and cov^-1 (6x6 row-major) */
+int ba_hip_set_unary_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose_id,
+                               const double* t_wp7, const double* cov_inv36,
+                               const uint8_t* use_rotation);
+/* binary_residuals_ (BundleAdjuster.h:425-456): cov^-1 and its square root as computed
+ * at Add time, weight */
+int ba_hip_set_binary_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose1_id,
+                                const uint32_t* pose2_id, const double* t_12_7,
+                                const double* cov_inv36, const double* cov_inv_sqrt36,
+                                const double* weight, const uint8_t* use_rotation);
+/* inertial_residuals_ (BundleAdjuster.h:516-546): CSR over the sample table,
+ * samples are rows [wx,wy,wz,ax,ay,az,time] (Types.h:222-244) */
+int ba_hip_set_imu_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose1_id,
+                             const uint32_t* pose2_id, const uint32_t* meas_ptr /* n+1 */,
+                             const double* meas7, const double* weight);
+int ba_hip_set_gravity(ba_hip_engine* e, const double g3[3]); /* BundleAdjuster.h:243-252 */
+/* Build the device-side structure: observation list sorted by landmark (CSR),
+ * pose-landmark incidences, per-pose-pair gather lists for the reduced matrix. */
+int ba_hip_finalize(ba_hip_engine* e);
+
+/* ---- one Solve() ------------------------------------------------------------------ */
+/* BundleAdjuster.cpp:288-296: x_s = T_sw(ref) x_w, normalised (lm_dim == 1) */
+int ba_hip_begin_solve(ba_hip_engine* e);
+/* BundleAdjuster.cpp:1237-1330 decides the masks on the host; bit i of masks[p] set =
+ * parameter i of pose p is regularised (Jacobian column zeroed, S(idx,idx) = 1e6,
+ * BundleAdjuster.cpp:587-598,1622-1629). */
+int ba_hip_set_pose_masks(ba_hip_engine* e, uint32_t n, const uint16_t* masks);
+/* BuildProblem + J^T J + Schur complement (BundleAdjuster.cpp:1166-1803, 327-598):
+ * leaves S, rhs_p_sc, rhs_p, rhs_l, V^-1, W on the device; returns the error sums
+ * BuildProblem computes (proj_error_ etc.). */
+int ba_hip_linearize(ba_hip_engine* e, ba_hip_errors* out);
+/* CalculateGn + GetLandmarkDelta (BundleAdjuster.cpp:748-833, 709-744): dense Cholesky
+ * of S, delta_p, then delta_l = V^-1 (rhs_l - W^T delta_p). */
+int ba_hip_solve_gn(ba_hip_engine* e);
+/* BundleAdjuster.cpp:858-925 + the norms/dots of :971-1004 */
+int ba_hip_dogleg_terms(ba_hip_engine* e, int gn_available, ba_hip_dogleg_scalars* out);
+/* step = coef_rhs * (rhs_p_, rhs_l_) + coef_gn * delta_gn  (BundleAdjuster.cpp:923-925,
+ * 947-950, 985, 1015-1017, 1108-1110) */
+int ba_hip_compose_step(ba_hip_engine* e, double coef_rhs, double coef_gn, ba_hip_step_norms* out);
+/* ApplyUpdate (BundleAdjuster.cpp:21-140) into the alternate state buffer; the previous
+ * state is kept as the rollback snapshot (replaces the deep copies of :1022-1028). */
+int ba_hip_apply_step(ba_hip_engine* e);
+/* restore the snapshot (BundleAdjuster.cpp:1060-1068, 1139-1149) */
+int ba_hip_rollback(ba_hip_engine* e);
+/* EvaluateResiduals (BundleAdjuster.cpp:144-274) at the current state */
+int ba_hip_eval_residuals(ba_hip_engine* e, ba_hip_errors* out);
+/* BundleAdjuster.cpp:672-678: x_w = T_ws(ref) x_s (lm_dim == 1) */
+int ba_hip_end_solve(ba_hip_engine* e);
+
+/* ---- results / debug taps ----------------------------------------------------------- */
+int ba_hip_get_poses(ba_hip_engine* e, double* t_wp7, double* v_w3, double* b6);
+int ba_hip_get_landmarks(ba_hip_engine* e, double* x_w4);
+int ba_hip_get_landmark_flags(ba_hip_engine* e, uint8_t* is_reliable, uint32_t* num_outliers);
+uint32_t ba_hip_num_pose_params(const ba_hip_engine* e);
+uint32_t ba_hip_num_lm_params(const ba_hip_engine* e);
+/* s_ as the reference leaves it (BundleAdjuster.cpp:473-477,587-598): dense n x n
+ * row-major; block (i,j) kept only for i <= j when use_triangular_matrices */
+int ba_hip_get_S(ba_hip_engine* e, double* s_nxn);
+int ba_hip_get_rhs(ba_hip_engine* e, double* rhs_p_sc, double* rhs_p, double* rhs_l);
+int ba_hip_get_delta_gn(ba_hip_engine* e, double* delta_p, double* delta_l);
+int ba_hip_get_step(ba_hip_engine* e, double* delta_p, double* delta_l);
+int ba_hip_get_proj_weights(ba_hip_engine* e, double* weight); /* per residual id */
+int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
+
+/* ---- raw device access for drivers that own streams/collectives ---------------------- */
+/* Device pointer + element count of the buffers whose cross-shard SUM defines the
+ * iteration: 0 = S (lower storage incl. rhs row), 1 = scalar block. */
+int ba_hip_device_buffer(ba_hip_engine* e, int which, void** dev_ptr, size_t* num_doubles);
+/* All-reduce hook: called on the engine's host thread, after the engine has drained its
+ * stream, for every buffer that must be summed over shards (doubles or uint64 counts).
+ * dtype: 0 = f64, 1 = u64.  Must return 0 on success.  NULL = single shard. */
+typedef int (*ba_hip_allreduce_fn)(void* ctx, void* dev_ptr, size_t count, int dtype);
+int ba_hip_set_allreduce(ba_hip_engine* e, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);
+
+/* ---- stand-alone kernels exposed for tests and benchmarks ------------------------- */
+/* Dense Cholesky solve of an SPD system given by its LOWER triangle (row-major n x n,
+ * host memory): x = A^-1 b.  Runs the same kernels ba_hip_solve_gn uses. */
+int ba_hip_dense_solve(ba_hip_engine* e, uint32_t n, const double* a_lower, const double* b, double* x);
+/* exact k-th smallest (0-based) of n non-negative doubles — the device selection behind
+ * the Huber sigma (std::nth_element at floor(N/2), BundleAdjuster.cpp:1356-1358) */
+int ba_hip_select_kth(ba_hip_engine* e, uint32_t n, const double* values, uint32_t k, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_HIP_H */
