@@ -83,6 +83,7 @@ struct Engine {
   bool finalized = false;
   int cur = 0;  // current state buffer (0/1)
   bool has_snapshot = false;
+  bool factored = false;  // A currently holds the Cholesky factor, not S
   ba_hip_timers timers;
   ba_hip_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
@@ -126,6 +127,7 @@ struct Engine {
   DBuf<double> scal;                     // scalars: [2*O] sqrt(w) r, then [L*lm] b_l
   DBuf<double> lm_vinv, lm_bl;           // [L][lm*lm], [L][lm]
   DBuf<double> A;                        // [(n+1)][ld] lower storage + rhs row
+  DBuf<double> A_keep;                   // copy of A before factorisation (debug option)
   DBuf<double> rhs_p, rhs_sc;            // [n] unreduced / reduced (copy of A's last row)
   DBuf<double> gn_p, gn_l, step_p, step_l;
   DBuf<double> invdiag;                  // inverse diagonal tiles of the Cholesky factor

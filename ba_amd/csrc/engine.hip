@@ -448,7 +448,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(prhs_ptr); REL(prhs_ent);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
-  REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(rhs_p); REL(rhs_sc); REL(gn_p);
+  REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
   REL(gn_l); REL(step_p); REL(step_l); REL(invdiag); REL(partials); REL(scalars_out); REL(hist);
   REL(flags);
 #undef REL
@@ -651,6 +651,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   if ((rc = launch_landmarks(e, c_huber, e->opt.use_robust_norm_for_proj_residuals))) return rc;
   e->timers.j_evaluation += t_l.stop_ms();
   EventTimer t_s(e->stream);
+  e->factored = false;
   if ((rc = launch_gather_S(e))) return rc;
   if (e->allreduce && e->nranks > 1) {
     // S (lower storage) and the reduced rhs row are sums over landmark shards
@@ -681,7 +682,13 @@ int ba_hip_solve_gn(ba_hip_engine* h) {
   int status = 0, rc;
   EventTimer t(e->stream);
   if (st.n > 0) {
+    if (e->opt.keep_reduced_system) {
+      BAE_HIP(e->A_keep.alloc((size_t)st.ld * st.ld));
+      BAE_HIP(hipMemcpyAsync(e->A_keep.p, e->A.p, (size_t)st.ld * st.ld * sizeof(double),
+                             hipMemcpyDeviceToDevice, e->stream));
+    }
     if ((rc = cholesky_solve(e, e->A.p, st.n, st.ld, e->gn_p.p, &status))) return rc;
+    e->factored = true;
   }
   e->timers.solve = t.stop_ms();
   EventTimer tb(e->stream);
@@ -814,7 +821,10 @@ int ba_hip_get_S(ba_hip_engine* h, double* s_nxn) {
   const uint32_t n = st.n, ld = st.ld, D = e->pose_dim;
   std::vector<double> a((size_t)n * ld);
   BAE_HIP(hipStreamSynchronize(e->stream));
-  if (n) BAE_HIP(hipMemcpy(a.data(), e->A.p, a.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (e->factored && !(e->opt.keep_reduced_system && e->A_keep.p))
+    return e->fail_msg("S was factorised in place; set keep_reduced_system to read it after ba_hip_solve_gn");
+  const double* src = e->factored ? e->A_keep.p : e->A.p;
+  if (n) BAE_HIP(hipMemcpy(a.data(), src, a.size() * sizeof(double), hipMemcpyDeviceToHost));
   // lower storage -> the reference's s_: block (i,j) kept for i <= j only when
   // use_triangular_matrices (SparseBlockMatrixOps.h:236-238), full symmetric otherwise
   for (uint32_t r = 0; r < n; ++r)

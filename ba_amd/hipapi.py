@@ -22,7 +22,7 @@ class Options(C.Structure):
     _fields_ = [("projection_outlier_threshold", C.c_double),
                 ("use_robust_norm_for_proj_residuals", C.c_int32),
                 ("use_robust_norm_for_inertial_residuals", C.c_int32),
-                ("use_triangular_matrices", C.c_int32), ("reserved", C.c_int32),
+                ("use_triangular_matrices", C.c_int32), ("keep_reduced_system", C.c_int32),
                 ("gyro_sigma", C.c_double), ("accel_sigma", C.c_double),
                 ("gyro_bias_sigma", C.c_double), ("accel_bias_sigma", C.c_double)]
 

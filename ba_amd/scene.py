@@ -127,7 +127,7 @@ class Scene:
 
 def make_scene(num_poses, num_landmarks, obs_per_landmark=10, lm_dim=1, seed=0,
                pixel_sigma=1.5, outlier_frac=0.02, trans_sigma=0.05, rot_sigma=0.01,
-               depth_sigma=0.05, lm_range=None, window=None, chunk=200000, exact_poses=2):
+               depth_sigma=0.05, lm_range=None, window=None, chunk=200000, anchors=None):
     """Build a scene with exactly `obs_per_landmark` ACCEPTED projection residuals per landmark.
 
     lm_dim == 1 (inverse depth): the first chosen pose is the landmark's reference pose; its
@@ -154,13 +154,16 @@ def make_scene(num_poses, num_landmarks, obs_per_landmark=10, lm_dim=1, seed=0,
     sc.gt_poses = gt_poses
     sc.gt_vel = vel
 
-    # perturbed initial poses; the first `exact_poses` are left at ground truth so that
-    # holding them inactive fixes the 7-dof gauge (scale included) without bias
+    # perturbed initial poses; the anchor poses (default: pose 0 and the diametrically
+    # opposite pose P/2) are left at ground truth so that holding them inactive fixes the
+    # 7-dof gauge (scale included) with a long baseline and without bias
     rng_p = np.random.Generator(np.random.PCG64([seed, 0xBA5E, 1]))
     dt = rng_p.normal(0.0, trans_sigma, (P, 3))
     dw = rng_p.normal(0.0, rot_sigma, (P, 3))
-    dt[:exact_poses] = 0
-    dw[:exact_poses] = 0
+    anchors = (0, P // 2) if anchors is None else tuple(anchors)
+    sc.anchor_poses = np.array(anchors, dtype=np.int64)
+    dt[sc.anchor_poses] = 0
+    dw[sc.anchor_poses] = 0
     init = gt_poses.copy()
     init[:, :3] += dt
     init[:, 3:7] = quat_mul(gt_poses[:, 3:7], quat_exp(dw))
@@ -224,6 +227,7 @@ def make_scene(num_poses, num_landmarks, obs_per_landmark=10, lm_dim=1, seed=0,
     rng_n = np.random.Generator(np.random.PCG64([seed, 0xBA5E, 3, lo]))
     z_all += rng_n.normal(0.0, pixel_sigma, z_all.shape)
     out = rng_n.random(z_all.shape[:2]) < outlier_frac
+    out[:, 0] = False  # the reference observation defines the feature: mismatches happen in the other frames
     zo = np.stack([rng_n.uniform(0, IMG_W, z_all.shape[:2]), rng_n.uniform(0, IMG_H, z_all.shape[:2])], -1)
     z_all = np.where(out[..., None], zo, z_all)
     # landmark initialisation as a tracker does it: back-project the (noisy) reference

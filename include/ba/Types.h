@@ -1,0 +1,183 @@
+// Value types of the MI355X-native ba::BundleAdjuster host layer.
+//
+// The reference's public signatures mention Eigen, Sophus and Calibu types
+// (/root/reference/include/ba/BundleAdjuster.h:136-155, Types.h:41-321).  None of those
+// libraries is a dependency here: the host layer owns small plain value types and
+// accepts the third-party ones through converting constructors (anything exposing
+// .translation() / .unit_quaternion(), operator[] / operator(), .data()), so existing
+// application code that passes Sophus::SE3d / Eigen vectors keeps compiling when those
+// headers are present.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <type_traits>
+#include <vector>
+
+namespace ba {
+
+static const double Gravity = 9.8007;  // reference Types.h:39
+#ifndef IMU_GYRO_SIGMA                 // reference Types.h:33-36
+#define IMU_GYRO_SIGMA 5.3088444e-5
+#define IMU_GYRO_BIAS_SIGMA 1.4125375e-4
+#define IMU_ACCEL_SIGMA 0.001883649
+#define IMU_ACCEL_BIAS_SIGMA 1.2589254e-2
+#endif
+
+// Fixed-size column vector / row-major matrix of doubles.
+template <int R, int C = 1>
+struct Mat {
+  double m[R * C];
+  Mat() { for (int i = 0; i < R * C; ++i) m[i] = 0.0; }
+  // from any indexable container of at least R*C scalars (vectors) ...
+  template <typename V, typename = decltype(std::declval<const V&>()[0]),
+            typename = typename std::enable_if<!std::is_arithmetic<V>::value>::type>
+  Mat(const V& v) { for (int i = 0; i < R * C; ++i) m[i] = (double)v[i]; }
+  Mat(std::initializer_list<double> l) {
+    int i = 0;
+    for (double x : l) { if (i < R * C) m[i++] = x; }
+    for (; i < R * C; ++i) m[i] = 0.0;
+  }
+  double& operator[](int i) { return m[i]; }
+  double operator[](int i) const { return m[i]; }
+  double& operator()(int r, int c = 0) { return m[r * C + c]; }
+  double operator()(int r, int c = 0) const { return m[r * C + c]; }
+  double* data() { return m; }
+  const double* data() const { return m; }
+  static Mat Zero() { return Mat(); }
+  static Mat Identity() { Mat a; for (int i = 0; i < (R < C ? R : C); ++i) a.m[i * C + i] = 1.0; return a; }
+  double norm() const { double s = 0; for (int i = 0; i < R * C; ++i) s += m[i] * m[i]; return std::sqrt(s); }
+};
+typedef Mat<2> Vector2t;
+typedef Mat<3> Vector3t;
+typedef Mat<4> Vector4t;
+typedef Mat<6> Vector6t;
+typedef Mat<3, 3> Matrix3t;
+typedef Mat<6, 6> Matrix6t;
+
+// Rigid transform: translation + unit quaternion (x,y,z,w), Sophus storage order.
+struct SE3 {
+  double t[3];
+  double q[4];
+  SE3() { t[0] = t[1] = t[2] = 0; q[0] = q[1] = q[2] = 0; q[3] = 1; }
+  SE3(const double* t3, const double* q4) { for (int i = 0; i < 3; ++i) t[i] = t3[i]; for (int i = 0; i < 4; ++i) q[i] = q4[i]; }
+  static SE3 from7(const double* p) { return SE3(p, p + 3); }
+  // from Sophus::SE3Group<double> or anything alike
+  template <typename S, typename = decltype(std::declval<const S&>().unit_quaternion()),
+            typename = decltype(std::declval<const S&>().translation())>
+  SE3(const S& s) {
+    const auto tr = s.translation();
+    const auto qq = s.unit_quaternion();
+    for (int i = 0; i < 3; ++i) t[i] = tr[i];
+    q[0] = qq.x(); q[1] = qq.y(); q[2] = qq.z(); q[3] = qq.w();
+  }
+  void to7(double* p) const { for (int i = 0; i < 3; ++i) p[i] = t[i]; for (int i = 0; i < 4; ++i) p[3 + i] = q[i]; }
+  Vector3t translation() const { Vector3t v; for (int i = 0; i < 3; ++i) v[i] = t[i]; return v; }
+  Matrix3t rotationMatrix() const {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    Matrix3t R;
+    R(0, 0) = 1 - 2 * (y * y + z * z); R(0, 1) = 2 * (x * y - w * z); R(0, 2) = 2 * (x * z + w * y);
+    R(1, 0) = 2 * (x * y + w * z); R(1, 1) = 1 - 2 * (x * x + z * z); R(1, 2) = 2 * (y * z - w * x);
+    R(2, 0) = 2 * (x * z - w * y); R(2, 1) = 2 * (y * z + w * x); R(2, 2) = 1 - 2 * (x * x + y * y);
+    return R;
+  }
+};
+
+// What the hot path needs of calibu::CameraInterface: pinhole parameters and the
+// vehicle-to-sensor pose (reference call sites parallel_algos.h:44-62).
+template <typename Scalar = double>
+class CameraInterface {
+ public:
+  CameraInterface() { p_[0] = p_[1] = 1; p_[2] = p_[3] = 0; }
+  CameraInterface(double fx, double fy, double u0, double v0, const SE3& t_vs = SE3()) : t_vs_(t_vs) {
+    p_[0] = fx; p_[1] = fy; p_[2] = u0; p_[3] = v0;
+  }
+  Vector4t GetParams() const { Vector4t v; for (int i = 0; i < 4; ++i) v[i] = p_[i]; return v; }
+  template <typename V> void SetParams(const V& v) { for (int i = 0; i < 4; ++i) p_[i] = v[i]; }
+  const SE3& Pose() const { return t_vs_; }
+  void SetPose(const SE3& t) { t_vs_ = t; }
+ private:
+  double p_[4];
+  SE3 t_vs_;
+};
+template <typename Scalar = double>
+using LinearCamera = CameraInterface<Scalar>;
+
+// calibu::Rig stand-in
+template <typename Scalar = double>
+struct Rig {
+  std::vector<std::shared_ptr<CameraInterface<Scalar>>> cameras_;
+  void AddCamera(std::shared_ptr<CameraInterface<Scalar>> c) { cameras_.push_back(c); }
+  uint32_t NumCams() const { return (uint32_t)cameras_.size(); }
+};
+
+// reference Types.h:222-244
+template <typename Scalar = double>
+struct ImuMeasurementT {
+  Vector3t w, a;
+  double time;
+  ImuMeasurementT() : time(0) {}
+  template <typename V>
+  ImuMeasurementT(const V& w_, const V& a_, double t) : w(w_), a(a_), time(t) {}
+  ImuMeasurementT operator*(const Scalar& rhs) const {
+    ImuMeasurementT r = *this;
+    for (int i = 0; i < 3; ++i) { r.w[i] *= rhs; r.a[i] *= rhs; }
+    return r;
+  }
+  ImuMeasurementT operator+(const ImuMeasurementT& rhs) const {
+    ImuMeasurementT r = *this;
+    for (int i = 0; i < 3; ++i) { r.w[i] += rhs.w[i]; r.a[i] += rhs.a[i]; }
+    return r;
+  }
+};
+
+// The fields of the reference's PoseT / LandmarkT that callers read back
+// (Types.h:41-89); adjacency lists and caches live in the engine instead.
+template <typename Scalar = double>
+struct PoseT {
+  SE3 t_wp;
+  Vector3t v_w;
+  Vector6t b;
+  std::vector<bool> param_mask;
+  bool is_param_mask_used = false;
+  bool is_active = true;
+  int external_id = -1;
+  uint32_t id = 0, opt_id = 0;
+  double time = -1;
+  // constraint counts (the reference keeps id lists; only emptiness is ever tested
+  // outside the solver, BundleAdjuster.cpp:1252-1265)
+  uint32_t num_proj_residuals = 0, num_inertial_residuals = 0, num_binary_residuals = 0,
+           num_unary_residuals = 0;
+};
+
+template <typename Scalar = double, int LmSize = 1>
+struct LandmarkT {
+  Vector2t z_ref;
+  Vector4t x_w;
+  int external_id = -1;
+  uint32_t num_outlier_residuals = 0, num_proj_residuals = 0;
+  uint32_t id = 0, opt_id = 0, ref_pose_id = 0, ref_cam_id = 0;
+  bool is_active = true, is_reliable = true;
+};
+
+// reference Types.h:112-159 (fields used on the hot path)
+template <typename Scalar = double>
+struct ImuCalibrationT {
+  SE3 t_vs;
+  Vector3t b_g, b_a;
+  Vector2t g;
+  Vector3t g_vec;
+  Vector6t r;    // diagonal of the measurement noise
+  Vector6t r_b;  // bias random walk
+  ImuCalibrationT() {
+    g_vec[0] = 0; g_vec[1] = 0; g_vec[2] = -Gravity;  // GetGravityVector((0,0))
+    for (int i = 0; i < 3; ++i) {
+      r[i] = IMU_GYRO_SIGMA * IMU_GYRO_SIGMA; r[3 + i] = IMU_ACCEL_SIGMA * IMU_ACCEL_SIGMA;
+      r_b[i] = IMU_GYRO_BIAS_SIGMA * IMU_GYRO_BIAS_SIGMA;
+      r_b[3 + i] = IMU_ACCEL_BIAS_SIGMA * IMU_ACCEL_BIAS_SIGMA;
+    }
+  }
+};
+
+}  // namespace ba

@@ -1,0 +1,91 @@
+/*
+ * ba_capi.h — flat C view of the C++ host class ba::BundleAdjuster<> (include/ba/
+ * BundleAdjuster.h) for callers without a C++ toolchain: Python/ctypes in this repo's
+ * tests and bench.py.  One handle = one ba::BundleAdjuster<double, lm_dim, pose_dim, 0>.
+ * Every call forwards to the member of the same name, whose semantics follow the
+ * reference API (/root/reference/include/ba/BundleAdjuster.h:177-631).  7-vectors are
+ * [tx,ty,tz,qx,qy,qz,qw].
+ */
+#ifndef BA_CAPI_H
+#define BA_CAPI_H
+#include <stdint.h>
+#include "ba_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ba_adjuster ba_adjuster;
+
+typedef struct { /* ba::Options<double>, reference BundleAdjuster.h:72-107 */
+  double trust_region_size;
+  double gyro_sigma, accel_sigma, gyro_bias_sigma, accel_bias_sigma;
+  double projection_outlier_threshold;
+  double error_change_threshold, param_change_threshold;
+  uint32_t dogleg_max_inner_iterations;
+  int32_t apply_results, use_dogleg, use_triangular_matrices, use_sparse_solver;
+  int32_t regularize_biases_in_batch, enable_auto_regularization;
+  int32_t use_robust_norm_for_proj_residuals, use_robust_norm_for_inertial_residuals;
+  int32_t write_reduced_camera_matrix; /* keeps S readable through ba_hip_get_S */
+  int32_t device;
+} ba_options;
+
+typedef struct { /* ba::SolutionSummary<double> + GetErrors, reference :48-70,593-602 */
+  uint32_t num_proj_residuals, num_inertial_residuals;
+  uint32_t num_cond_proj_residuals, num_cond_inertial_residuals;
+  double proj_error, inertial_error, unary_error, binary_error;
+  double delta_norm, pre_solve_norm, post_solve_norm;
+  int32_t result; /* ba::OptimizationResult */
+  uint32_t iterations_run;
+  double trust_region_size;
+} ba_summary;
+
+void ba_default_options(ba_options* o);
+ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim);
+void ba_adjuster_destroy(ba_adjuster* a);
+void ba_adjuster_init(ba_adjuster* a, const ba_options* o);
+void ba_adjuster_set_gravity(ba_adjuster* a, const double g[3]);
+uint32_t ba_adjuster_add_camera(ba_adjuster* a, const double params[4], const double t_vs[7]);
+uint32_t ba_adjuster_add_pose(ba_adjuster* a, const double t_wp[7], const double v_w[3],
+                              const double b[6], int is_active, double time);
+uint32_t ba_adjuster_add_landmark(ba_adjuster* a, const double x_w[4], uint32_t ref_pose_id,
+                                  uint32_t ref_cam_id, int is_active);
+uint32_t ba_adjuster_add_projection_residual(ba_adjuster* a, const double z[2], uint32_t meas_pose_id,
+                                             uint32_t landmark_id, uint32_t cam_id, double weight);
+uint32_t ba_adjuster_add_unary_constraint(ba_adjuster* a, uint32_t pose_id, const double t_wv[7],
+                                          const double cov[36], int use_rotation);
+uint32_t ba_adjuster_add_binary_constraint(ba_adjuster* a, uint32_t pose1_id, uint32_t pose2_id,
+                                           const double t_12[7], const double cov[36], double weight,
+                                           int use_rotation);
+uint32_t ba_adjuster_add_imu_residual(ba_adjuster* a, uint32_t pose1_id, uint32_t pose2_id,
+                                      const double* meas7, uint32_t n, double weight);
+void ba_adjuster_regularize_pose(ba_adjuster* a, uint32_t pose_id, int translation, int gravity,
+                                 int bias, int rotation);
+void ba_adjuster_set_root_pose_id(ba_adjuster* a, uint32_t id);
+/* bulk adders = n single calls */
+void ba_adjuster_add_poses(ba_adjuster* a, uint32_t n, const double* t_wp, const double* v_w,
+                           const double* b, const uint8_t* is_active, const double* time);
+void ba_adjuster_add_landmarks(ba_adjuster* a, uint32_t n, const double* x_w,
+                               const uint32_t* ref_pose_id, const uint32_t* ref_cam_id,
+                               const uint8_t* is_active);
+void ba_adjuster_add_projection_residuals(ba_adjuster* a, uint32_t n, const double* z,
+                                          const uint32_t* meas_pose_id, const uint32_t* landmark_id,
+                                          const uint32_t* cam_id, const double* weight,
+                                          uint32_t* out_ids);
+void ba_adjuster_solve(ba_adjuster* a, uint32_t max_iter, double gn_damping, int error_increase_allowed);
+uint32_t ba_adjuster_num_poses(const ba_adjuster* a);
+uint32_t ba_adjuster_num_landmarks(const ba_adjuster* a);
+uint32_t ba_adjuster_num_proj_residuals(const ba_adjuster* a);
+void ba_adjuster_get_poses(const ba_adjuster* a, double* t_wp, double* v_w, double* b);
+void ba_adjuster_get_landmarks(const ba_adjuster* a, double* x_w);
+int ba_adjuster_is_landmark_reliable(const ba_adjuster* a, uint32_t id);
+double ba_adjuster_landmark_outlier_ratio(const ba_adjuster* a, uint32_t id);
+void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s);
+void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
+/* the engine behind the adjuster (valid after the first Solve) for the debug taps of ba_hip.h */
+ba_hip_engine* ba_adjuster_engine(ba_adjuster* a);
+void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -44,7 +44,9 @@ typedef struct {
   int32_t use_robust_norm_for_proj_residuals;     /* BundleAdjuster.cpp:1377 */
   int32_t use_robust_norm_for_inertial_residuals; /* BundleAdjuster.cpp:1513 */
   int32_t use_triangular_matrices;                /* only affects debug downloads of S */
-  int32_t reserved;
+  int32_t keep_reduced_system;                    /* keep a copy of S for ba_hip_get_S after the
+                                                     in-place factorisation (the reference's
+                                                     write_reduced_camera_matrix, BundleAdjuster.cpp:600-627) */
   double gyro_sigma, accel_sigma, gyro_bias_sigma, accel_bias_sigma; /* BundleAdjuster.h:204-218 */
 } ba_hip_options;
 

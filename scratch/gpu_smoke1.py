@@ -29,7 +29,7 @@ for lm_dim in (1, 3):
         sc = scene.make_scene(30, 60, 5, lm_dim=lm_dim, seed=7)
         P = sc.num_poses
         pa = np.ones(P, dtype=np.uint8); la = np.ones(sc.num_landmarks, dtype=np.uint8)
-        if variant == 'two_fixed': pa[:2] = 0
+        if variant == 'two_fixed': pa[sc.anchor_poses] = 0
         if variant == 'inactive_mix': pa[[0, 3, 4, 17]] = 0; la[[5, 6, 40]] = 0
         ba = po.OracleBundleAdjuster(lm_dim, 6)
         ba.Init(gn_options(po))
