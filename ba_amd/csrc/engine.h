@@ -136,6 +136,23 @@ struct Engine {
   DBuf<unsigned long long> hist;         // selection histograms
   DBuf<int32_t> flags;                   // factorisation status etc.
 
+  // optional per-kernel timing (ba_hip_set_profiling)
+  bool profiling = false;
+  ba_hip_kernel_stats kstats = {};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_syrk, ev_gather, ev_landmarks;
+  void prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+    if (!profiling) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, stream);
+    v.push_back({a, b});
+  }
+  void prof_end(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+    if (!profiling) return;
+    (void)hipEventRecord(v.back().second, stream);
+  }
+  void prof_collect();
+
   int fail(hipError_t e, const char* what);
   int fail_msg(const char* what);
 };

@@ -16,6 +16,21 @@ int Engine::fail(hipError_t e, const char* what) {
   err = std::string(what) + ": " + hipGetErrorString(e);
   return -(int)(e == hipSuccess ? 1 : e);
 }
+void Engine::prof_collect() {
+  auto drain = [](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, double& ms, uint32_t& n) {
+    for (auto& p : v) {
+      (void)hipEventSynchronize(p.second);
+      float t = 0;
+      (void)hipEventElapsedTime(&t, p.first, p.second);
+      ms += t; n += 1;
+      (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+    }
+    v.clear();
+  };
+  drain(ev_syrk, kstats.syrk_ms, kstats.syrk_launches);
+  drain(ev_gather, kstats.gather_ms, kstats.gather_launches);
+  drain(ev_landmarks, kstats.landmarks_ms, kstats.landmarks_launches);
+}
 int Engine::fail_msg(const char* what) {
   err = what;
   return -1;
@@ -653,16 +668,20 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   EventTimer t_s(e->stream);
   e->factored = false;
   if ((rc = launch_gather_S(e))) return rc;
-  if (e->allreduce && e->nranks > 1) {
-    // S (lower storage) and the reduced rhs row are sums over landmark shards
-    // (SURVEY.md §8e item 1); the masked 1e6 diagonals and the padding identity are
-    // written by every shard, so they are rescaled after the sum.
-    BAE_HIP(hipStreamSynchronize(e->stream));
-    return e->fail_msg("multi-shard reduction of S is wired in ba_hip_linearize_sharded");
-  }
   // copy the reduced rhs into the rhs row of A
   BAE_HIP(hipMemcpyAsync(e->A.p + (size_t)st.ld * st.ld, e->rhs_sc.p, (size_t)st.n * sizeof(double),
                          hipMemcpyDeviceToDevice, e->stream));
+  if (e->allreduce && e->nranks > 1) {
+    // S (lower storage) with its rhs row, and the unreduced rhs_p, are sums over the
+    // landmark shards: one all-reduce each over xGMI.
+    BAE_HIP(hipStreamSynchronize(e->stream));
+    if (e->allreduce(e->allreduce_ctx, e->A.p, (size_t)(st.ld + 1) * st.ld, 0) != 0)
+      return e->fail_msg("allreduce hook failed");
+    if (e->allreduce(e->allreduce_ctx, e->rhs_p.p, st.ld, 0) != 0)
+      return e->fail_msg("allreduce hook failed");
+    BAE_HIP(hipMemcpyAsync(e->rhs_sc.p, e->A.p + (size_t)st.ld * st.ld, (size_t)st.n * sizeof(double),
+                           hipMemcpyDeviceToDevice, e->stream));
+  }
   e->timers.jtj_schur = t_s.stop_ms();
   // proj_error_ of BuildProblem (BundleAdjuster.cpp:1386) = EvaluateResiduals at the same
   // state with the new weights
@@ -891,6 +910,21 @@ int ba_hip_get_proj_weights(ba_hip_engine* h, double* weight) {
 int ba_hip_get_timers(ba_hip_engine* h, ba_hip_timers* t) {
   ENG(h);
   *t = e->timers;
+  return 0;
+}
+
+int ba_hip_set_profiling(ba_hip_engine* h, int enable) {
+  ENG(h);
+  e->prof_collect();
+  e->profiling = enable != 0;
+  memset(&e->kstats, 0, sizeof(e->kstats));
+  return 0;
+}
+int ba_hip_get_kernel_stats(ba_hip_engine* h, ba_hip_kernel_stats* out) {
+  ENG(h);
+  (void)hipStreamSynchronize(e->stream);
+  e->prof_collect();
+  *out = e->kstats;
   return 0;
 }
 

@@ -2,97 +2,163 @@
 //
 // Replaces CalculateGn (BundleAdjuster.cpp:748-833): the reference converts the dense
 // s_ to a sparse view and runs Eigen::SimplicialLDLT<Upper> (or dense LDLT<Upper>).
-// Here: blocked right-looking Cholesky on the LOWER storage (row-major, leading
-// dimension ld, multiple of 64) with
-//   * k_potrf_inv   — 64x64 diagonal tile factorised in LDS, plus its inverse, so that
-//   * k_panel       — the panel solve A_ik L_kk^-T becomes a matrix product,
-//   * k_syrk        — trailing update A_ij -= A_ik A_jk^T,
-// both products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64: the one true dense
-// contraction of the path).  The right-hand side rides along as one extra row below
-// the matrix, so the forward substitution L y = b is a by-product of the panel steps;
-// k_backward then solves L^T x = y block row by block row using the stored inverse
-// diagonal tiles.
-// The system is SPD for well-posed problems (masked parameters carry 1e6 on the
-// diagonal); a non-positive pivot raises the status flag (-> FactorizationError,
+// Here: two-level blocked right-looking Cholesky on the LOWER storage (row-major,
+// leading dimension ld, multiple of 64):
+//
+//   for every outer panel J of KOUT = 4 tile columns (256 columns)
+//     for every 64-column tile jj of the panel
+//       k_potrf64   one wavefront factorises the 64x64 diagonal tile in registers
+//                   (row per lane, pivots broadcast with v_readlane: no barriers)
+//       k_trsm64    rows below: X L_jj^T = A, one thread per row (forward substitution,
+//                   L_jj broadcast from LDS)
+//       k_update    in-panel update of the remaining tile columns of the panel (K = 64)
+//     k_update      trailing update of everything right of the panel with K = 256
+//
+// The products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64 — the one true dense
+// contraction of the path); accumulating 256 columns per pass over the trailing matrix
+// quarters the HBM read-modify-write traffic of the C tiles compared with K = 64.
+// The right-hand side rides along as one extra row below the matrix, so the forward
+// substitution L y = b is a by-product; k_backward then solves L^T x = y block row by
+// block row.  The system is SPD for well-posed problems (masked parameters carry 1e6 on
+// the diagonal); a non-positive pivot raises the status flag (-> FactorizationError,
 // BundleAdjuster.cpp:756-759).
 #include "engine.h"
 
 namespace bae {
 
 static const int NB = 64;        // tile size
-static const int LDT = NB + 2;   // LDS row stride in doubles: conflict-free MFMA operand reads
+static const int KOUT = 4;       // tiles per outer panel
+static const int LDT = NB + 2;   // LDS row stride (doubles): conflict-free MFMA operand reads
+static const int LDP = NB + 1;   // LDS row stride for row-per-lane access
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// ---------------------------------------------------------------------------------
-// Factorise the diagonal tile k in place (lower), compute inv(L_kk) (lower) into
-// invd[k], one workgroup of 256 threads.  status != 0 on a non-positive pivot.
-__global__ void __launch_bounds__(256)
-k_potrf_inv(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ invd,
-            int* __restrict__ status) {
-  // lower triangle + diagonal: L; strict upper triangle: inv(L)^T; dinv: diagonal of inv(L)
-  __shared__ double T[NB][LDT];
-  __shared__ double dinv[NB];
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  double* Akk = A + ((size_t)k * NB) * ld + (size_t)k * NB;
-  if (tid == 0) bad = 0;
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx % NB;
-    T[r][c] = (c <= r) ? Akk[(size_t)r * ld + c] : 0.0;
-  }
-  __syncthreads();
-  // right-looking unblocked Cholesky on the lower triangle
-  for (int j = 0; j < NB; ++j) {
-    if (tid == 0) {
-      const double d = T[j][j];
-      if (!(d > 0.0)) bad = 1;
-      T[j][j] = sqrt(d > 0.0 ? d : 1.0);
-    }
-    __syncthreads();
-    const double dj = T[j][j];
-    if (tid > j && tid < NB) T[tid][j] = T[tid][j] / dj;
-    __syncthreads();
-    const int m = NB - 1 - j;  // trailing size
-    for (int idx = tid; idx < m * m; idx += 256) {
-      const int rr = idx / m, cc = idx % m;
-      if (cc <= rr) {
-        const int r = j + 1 + rr, c = j + 1 + cc;
-        T[r][c] -= T[r][j] * T[c][j];
-      }
-    }
-    __syncthreads();
-  }
-  // inverse of the lower-triangular tile, column c solves L x = e_c by forward
-  // substitution; 4 threads per column split each dot product.  x_r for r > c is kept
-  // at T[c][r] (the unused upper triangle), x_c in dinv[c].
-  {
-    const int c = tid >> 2, part = tid & 3;
-    for (int r = 0; r < NB; ++r) {
-      double s = 0.0;
-      if (r > c) {
-        for (int p = c + 1 + part; p < r; p += 4) s += T[r][p] * T[c][p];
-        if (part == 0) s += T[r][c] * dinv[c];
-      }
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      if (part == 0) {
-        if (r == c) dinv[c] = 1.0 / T[r][r];
-        else if (r > c) T[c][r] = -s / T[r][r];
-      }
-      __syncthreads();
-    }
-  }
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx / NB, c = idx % NB;
-    if (c <= r) Akk[(size_t)r * ld + c] = T[r][c];
-    invd[(size_t)k * NB * NB + idx] = (r < c) ? 0.0 : (r == c ? dinv[r] : T[c][r]);
-  }
-  if (tid == 0 && bad) atomicExch(status, 1);
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
 }
 
 // ---------------------------------------------------------------------------------
-// C(64x64) = X(64xNB) * Y(64xNB)^T on the FP64 matrix cores; X, Y in LDS (stride LDT).
+// 64x64 Cholesky of the diagonal tile k by ONE wavefront.  Lane r keeps row r in
+// registers.  Step j: the pivot is broadcast by v_readlane, 1/sqrt(pivot) comes from
+// v_rsq_f64 refined by two Newton steps (no division on the serial chain), every lane
+// scales its column-j entry and publishes it to an LDS column buffer, then updates its
+// columns right of j with the column entries read back as wave-uniform (broadcast) LDS
+// reads.  Fully unrolled: every register index is static; no barriers (single wave, LDS
+// operations of one wave execute in order).
+// Also stores 1/L[j][j] for the triangular solves.
+__global__ void __launch_bounds__(64)
+k_potrf64(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ dinv_out,
+          int* __restrict__ status) {
+  __shared__ double T[NB][LDP];
+  __shared__ double colbuf[2][NB];
+  const int lane = threadIdx.x;
+  double* Akk = A + ((size_t)k * NB) * ld + (size_t)k * NB;
+  {
+    double tmp[NB];  // all 64 row loads in flight before the first use
+#pragma unroll
+    for (int r = 0; r < NB; ++r) tmp[r] = Akk[(size_t)r * ld + lane];  // coalesced rows
+#pragma unroll
+    for (int r = 0; r < NB; ++r) T[r][lane] = tmp[r];
+  }
+  __syncthreads();
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) a[c] = (c <= lane) ? T[lane][c] : 0.0;
+  int bad = 0;
+  double my_dinv = 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double d = readlane_f64(a[j], j);
+    if (!(d > 0.0)) bad = 1;
+    const double dd = d > 0.0 ? d : 1.0;
+    // y ~ 1/sqrt(dd): hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 dd y^2)
+    double y = __builtin_amdgcn_rsq(dd);
+    y = y * fma(-0.5 * dd * y, y, 1.5);
+    y = y * fma(-0.5 * dd * y, y, 1.5);
+    if (lane == j) my_dinv = y;
+    a[j] *= y;  // lane j: sqrt(d); lanes below: L[r][j]
+    colbuf[j & 1][lane] = a[j];
+#pragma unroll
+    for (int c = j + 1; c < NB; ++c) a[c] -= a[j] * colbuf[j & 1][c];  // L[r][j] L[c][j]
+  }
+#pragma unroll
+  for (int c = 0; c < NB; ++c) T[lane][c] = a[c];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+    if (lane <= r) Akk[(size_t)r * ld + lane] = T[r][lane];
+  dinv_out[(size_t)k * NB + lane] = my_dinv;
+  if (lane == 0 && bad) atomicExch(status, 1);
+}
+
+// ---------------------------------------------------------------------------------
+// Rows below the diagonal tile: X L_kk^T = A_ik, one thread per row, column-oriented
+// (right-looking) forward substitution: once x_p is known every remaining entry of the
+// row is updated independently, s_j -= x_p L[j][p], so the 2016 FMAs per row have no
+// serial dependence beyond one FMA per step.  L_kk is staged TRANSPOSED in LDS so that
+// the entries needed at step p (L[p+1..63][p]) are contiguous: wave-uniform 16-byte LDS
+// reads (broadcast).  One wavefront per 64-row block; the last block is the rhs row.
+__global__ void __launch_bounds__(64)
+k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
+         double* __restrict__ Apanel, uint32_t ld, uint32_t nrowblk) {
+  __shared__ double Xs[NB][LDP];
+  __shared__ __attribute__((aligned(16))) double LsT[NB][LDT];  // LsT[p][j] = L[j][p] / L[j][j]
+  __shared__ double dv[NB];
+  const int lane = threadIdx.x;
+  const int rows = (blockIdx.x + 1 == nrowblk) ? 1 : NB;  // the last block is the rhs row
+  double* Aik = Apanel + ((size_t)blockIdx.x * NB) * ld;
+  {
+    double ta[NB], tl[NB];  // all loads in flight before the first use
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      ta[r] = (r < rows) ? Aik[(size_t)r * ld + lane] : 0.0;
+      tl[r] = Lkk[(size_t)r * ld + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      Xs[r][lane] = ta[r];
+      // row r of L, element (r, lane), pre-scaled by 1/L[r][r]: with t_j = s_j / L[j][j]
+      // the substitution needs no multiply on its serial chain (x_p = t_p)
+      LsT[lane][r] = tl[r] * dinv[r];
+    }
+  }
+  dv[lane] = dinv[lane];
+  __syncthreads();
+  double s[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) s[j] = Xs[lane][j] * dv[j];
+  // software pipeline: the L entries of step p+1 are fetched (wave-uniform LDS reads)
+  // while step p computes; sched_barrier keeps the compiler from sinking the loads
+  double cur[NB], nxt[NB];
+#pragma unroll
+  for (int j = 1; j < NB; ++j) cur[j] = LsT[0][j];
+#pragma unroll
+  for (int p = 0; p < NB; ++p) {
+    if (p + 1 < NB) {
+#pragma unroll
+      for (int j = p + 2; j < NB; ++j) nxt[j] = LsT[p + 1][j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double x = s[p];
+#pragma unroll
+    for (int j = p + 1; j < NB; ++j) s[j] -= x * cur[j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = p + 2; j < NB; ++j) cur[j] = nxt[j];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) Xs[lane][j] = s[j];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+    if (r < rows) Aik[(size_t)r * ld + lane] = Xs[r][lane];
+}
+
+// ---------------------------------------------------------------------------------
+// C(64x64) += X(64x64) * Y(64x64)^T on the FP64 matrix cores; X, Y in LDS (stride LDT).
 // 4 waves: wave w owns rows [32*(w>>1), +32) x cols [32*(w&1), +32) as 2x2 MFMA tiles.
 // Fragment maps of v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4],
 // B[k = lane>>4][j = lane&15]; C/D: col = lane&15, row = (lane>>4) + 4*reg.
@@ -125,78 +191,37 @@ __device__ __forceinline__ void load_tile(double (*T)[LDT], const double* __rest
   }
 }
 
-// Panel: for every row block i > k (the last one is the single rhs row):
-// A_ik <- A_ik * inv(L_kk)^T.
+// Update of the tiles (i, c), c in [c0, c0 + gridDim.y), i in [c, nblk] (i == nblk: the
+// rhs row) with the tile columns [kb0, kb1):
+//     A_ic -= sum_kb A_i,kb * A_c,kb^T
+// grid = (nblk - c0 + 1, number of tile columns); blockIdx.x counts rows from c.
 __global__ void __launch_bounds__(256)
-k_panel(double* __restrict__ A, uint32_t ld, uint32_t k, uint32_t nblk /* matrix row blocks */,
-        const double* __restrict__ invd) {
+k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
+         uint32_t kb1) {
   __shared__ double X[NB][LDT];
   __shared__ double Y[NB][LDT];
-  const uint32_t i = k + 1 + blockIdx.x;       // row block; i == nblk is the rhs row
+  const uint32_t c = c0 + blockIdx.y;
+  const uint32_t i = c + blockIdx.x;
+  if (i > nblk) return;
   const int rows = (i == nblk) ? 1 : NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* Aik = A + ((size_t)i * NB) * ld + (size_t)k * NB;
-  load_tile(X, Aik, ld, rows, tid);
-  load_tile(Y, invd + (size_t)k * NB * NB, NB, NB, tid);
-  __syncthreads();
   double4_t acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mma(X, Y, wave, lane, acc);
-  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
-#pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = rb + 16 * ti + (lane >> 4) + 4 * reg;
-        const int c = cb + 16 * tj + (lane & 15);
-        if (r < rows) Aik[(size_t)r * ld + c] = acc[ti][tj][reg];
-      }
-}
-
-// Trailing update: for k < j <= i: A_ij -= A_ik A_jk^T (lower tiles; i may be the rhs row,
-// for which j < nblk).  Linear block index -> (i,j) over the trailing triangle.
-__global__ void __launch_bounds__(256)
-k_syrk(double* __restrict__ A, uint32_t ld, uint32_t k, uint32_t nblk) {
-  __shared__ double X[NB][LDT];
-  __shared__ double Y[NB][LDT];
-  const uint32_t m = nblk - k - 1;  // trailing matrix row blocks
-  // tiles: triangle of m rows (t*(t+1)/2 indexing) followed by the rhs row (m tiles)
-  const uint32_t tri = m * (m + 1) / 2;
-  uint32_t bi, bj;
-  const uint32_t b = blockIdx.x;
-  if (b < tri) {
-    // bi = largest t with t(t+1)/2 <= b
-    uint32_t t = (uint32_t)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-    while ((t + 1) * (t + 2) / 2 <= b) ++t;
-    while (t * (t + 1) / 2 > b) --t;
-    bi = t;
-    bj = b - t * (t + 1) / 2;
-  } else {
-    bi = m;  // rhs row
-    bj = b - tri;
+  for (uint32_t kb = kb0; kb < kb1; ++kb) {
+    const double* Aik = A + ((size_t)i * NB) * ld + (size_t)kb * NB;
+    const double* Ack = A + ((size_t)c * NB) * ld + (size_t)kb * NB;
+    if (kb != kb0) __syncthreads();
+    load_tile(X, Aik, ld, rows, tid);
+    load_tile(Y, Ack, ld, NB, tid);
+    __syncthreads();
+    tile_mma(X, Y, wave, lane, acc);
   }
-  const uint32_t i = k + 1 + bi, j = k + 1 + bj;
-  const int rows = (i == nblk) ? 1 : NB;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double* Aik = A + ((size_t)i * NB) * ld + (size_t)k * NB;
-  const double* Ajk = A + ((size_t)j * NB) * ld + (size_t)k * NB;
-  double* Aij = A + ((size_t)i * NB) * ld + (size_t)j * NB;
-  load_tile(X, Aik, ld, rows, tid);
-  load_tile(Y, Ajk, ld, NB, tid);
-  __syncthreads();
-  double4_t acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int bb = 0; bb < 2; ++bb) acc[a][bb] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  tile_mma(X, Y, wave, lane, acc);
+  double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
   const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
-  const bool diag = (i == j);
+  const bool diag = (i == c);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -204,35 +229,41 @@ k_syrk(double* __restrict__ A, uint32_t ld, uint32_t k, uint32_t nblk) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = rb + 16 * ti + (lane >> 4) + 4 * reg;
-        const int c = cb + 16 * tj + (lane & 15);
-        if (r < rows && (!diag || c <= r)) Aij[(size_t)r * ld + c] -= acc[ti][tj][reg];
+        const int cc = cb + 16 * tj + (lane & 15);
+        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] -= acc[ti][tj][reg];
       }
 }
 
 // Backward substitution, block row i (from the last to the first):
-//   x_i = inv(L_ii)^T y_i ;  y[0 : i*NB] -= L[i-block, 0:i*NB]^T x_i
-// y lives in the rhs row of A.  Every workgroup recomputes x_i (64x64 mat-vec) and
-// updates its own 256 columns; workgroup 0 also stores x_i.
+//   L_ii^T x_i = y_i ;  y[0 : i*NB] -= L[i-block, 0:i*NB]^T x_i
+// y lives in the rhs row of A.  Wave 0 of every workgroup solves the 64x64 triangular
+// system (column sweep, pivots broadcast by readlane); then each thread updates one
+// column.  Workgroup 0 also stores x_i.
 __global__ void __launch_bounds__(256)
 k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
-           const double* __restrict__ invd, double* __restrict__ x) {
+           const double* __restrict__ dinv, double* __restrict__ x) {
+  __shared__ double Ls[NB][LDP];
   __shared__ double xi[NB];
-  __shared__ double part[4][NB];
   const int tid = threadIdx.x;
-  const double* y = A + ((size_t)nblk * NB) * ld;
+  const double* Aii = A + ((size_t)i * NB) * ld + (size_t)i * NB;
   {
-    // x_i[c] = sum_r Linv[r][c] * y_i[r]; 4 partial sums per column
-    const int c = tid & 63, q = tid >> 6;
-    const double* Li = invd + (size_t)i * NB * NB;
-    double s = 0.0;
-    for (int r = q * 16; r < q * 16 + 16; ++r) s += Li[r * NB + c] * y[(size_t)i * NB + r];
-    part[q][c] = s;
+    double tmp[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tmp[u] = Aii[(size_t)(4 * u + (tid >> 6)) * ld + (tid & 63)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) Ls[4 * u + (tid >> 6)][tid & 63] = tmp[u];
   }
   __syncthreads();
   if (tid < NB) {
-    const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-    xi[tid] = v;
-    if (blockIdx.x == 0) x[(size_t)i * NB + tid] = v;
+    double yv = A[((size_t)nblk * NB) * ld + (size_t)i * NB + tid];
+    // for j = 63..0: x_j = y_j / L[j][j]; y_r -= L[j][r] x_j for r < j
+    for (int j = NB - 1; j >= 0; --j) {
+      const double xj = readlane_f64(yv, j) * dinv[(size_t)i * NB + j];
+      if (tid == j) yv = xj;
+      else if (tid < j) yv -= Ls[j][tid] * xj;
+    }
+    xi[tid] = yv;
+    if (blockIdx.x == 0) x[(size_t)i * NB + tid] = yv;
   }
   __syncthreads();
   const uint32_t col = blockIdx.x * 256 + tid;
@@ -241,8 +272,7 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
     double s = 0.0;
 #pragma unroll 8
     for (int r = 0; r < NB; ++r) s += Li[(size_t)r * ld] * xi[r];
-    double* yy = A + ((size_t)nblk * NB) * ld + col;
-    *yy -= s;
+    A[((size_t)nblk * NB) * ld + col] -= s;
   }
 }
 
@@ -251,25 +281,41 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status) {
   (void)n;
   const uint32_t nblk = ld / NB;
-  BAE_HIP(e->invdiag.alloc((size_t)nblk * NB * NB));
+  BAE_HIP(e->invdiag.alloc((size_t)nblk * NB));  // 1 / diag(L)
   BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), e->stream));
-  for (uint32_t k = 0; k < nblk; ++k) {
-    hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(256), 0, e->stream, dA, ld, k, e->invdiag.p,
-                       e->flags.p);
-    const uint32_t below = nblk - k;  // row blocks k+1..nblk (incl. the rhs row)
-    hipLaunchKernelGGL(k_panel, dim3(below), dim3(256), 0, e->stream, dA, ld, k, nblk,
-                       e->invdiag.p);
-    const uint32_t m = nblk - k - 1;
-    const uint32_t tiles = m * (m + 1) / 2 + m;
-    if (tiles > 0)
-      hipLaunchKernelGGL(k_syrk, dim3(tiles), dim3(256), 0, e->stream, dA, ld, k, nblk);
+  for (uint32_t J = 0; J < nblk; J += KOUT) {
+    const uint32_t Jend = J + KOUT < nblk ? J + KOUT : nblk;
+    for (uint32_t jj = J; jj < Jend; ++jj) {
+      hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, e->stream, dA, ld, jj, e->invdiag.p,
+                         e->flags.p);
+      hipLaunchKernelGGL(k_trsm64, dim3(nblk - jj), dim3(64), 0, e->stream,
+                         (const double*)(dA + ((size_t)jj * NB) * ld + (size_t)jj * NB),
+                         (const double*)(e->invdiag.p + (size_t)jj * NB),
+                         dA + ((size_t)(jj + 1) * NB) * ld + (size_t)jj * NB, ld, nblk - jj);
+      if (jj + 1 < Jend) {
+        // in-panel update of the panel's remaining tile columns with tile column jj
+        hipLaunchKernelGGL(k_update, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0,
+                           e->stream, dA, ld, nblk, jj + 1, jj, jj + 1);
+      }
+    }
+    if (Jend < nblk) {
+      // trailing update right of the panel, K = 64 * (Jend - J)
+      e->prof_begin(e->ev_syrk);
+      hipLaunchKernelGGL(k_update, dim3(nblk - Jend + 1, nblk - Jend), dim3(256), 0, e->stream, dA,
+                         ld, nblk, Jend, J, Jend);
+      e->prof_end(e->ev_syrk);
+      if (e->profiling) {
+        const double m = (double)(nblk - Jend);
+        e->kstats.syrk_flops += (m * (m + 1) / 2 + m) * 2.0 * NB * NB * NB * (Jend - J);
+      }
+    }
   }
   BAE_HIP(hipGetLastError());
   for (uint32_t ii = nblk; ii-- > 0;) {
     const uint32_t cols = ii * NB;
     const uint32_t grid = cols == 0 ? 1 : (cols + 255) / 256;
     hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, e->stream, dA, ld, ii, nblk,
-                       e->invdiag.p, dx);
+                       (const double*)e->invdiag.p, dx);
   }
   BAE_HIP(hipGetLastError());
   int st = 0;

@@ -377,8 +377,10 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
       e->pose_mask.p, e->lm_x[e->cur].p, e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p,         \
       e->tsw.p, e->tws.p, e->twp.p, e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p,   \
       e->obs_jl.p
+  e->prof_begin(e->ev_landmarks);
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_landmarks<1>, grid, block, 0, e->stream, BAE_ARGS);
   else hipLaunchKernelGGL(k_landmarks<3>, grid, block, 0, e->stream, BAE_ARGS);
+  e->prof_end(e->ev_landmarks);
 #undef BAE_ARGS
   BAE_HIP(hipGetLastError());
   return 0;

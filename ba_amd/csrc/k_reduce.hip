@@ -27,42 +27,62 @@ __global__ void __launch_bounds__(256)
 k_gather_S(uint32_t npairs, const uint32_t* __restrict__ pair_ptr,
            const uint2* __restrict__ pair_ij, const uint2* __restrict__ pair_ent,
            const double* __restrict__ frow, int D, uint32_t ld,
-           const uint16_t* __restrict__ mask_opt, double* __restrict__ A) {
-  const uint32_t pair = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pair >= npairs) return;
-  const int lane = threadIdx.x & 63;
-  const uint32_t e0 = pair_ptr[pair], e1 = pair_ptr[pair + 1];
-  const uint2 ij = pair_ij[pair];
-  const int r = lane / 6, c = lane - 6 * r;
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-  if (lane < 36) {
-    uint32_t e = e0;
-    for (; e + 4 <= e1; e += 4) {
-      const uint2 p0 = pair_ent[e], p1 = pair_ent[e + 1], p2 = pair_ent[e + 2], p3 = pair_ent[e + 3];
-      const double a0 = frow[(size_t)p0.x * kRow + r], b0 = frow[(size_t)p0.y * kRow + c];
-      const double a1 = frow[(size_t)p1.x * kRow + r], b1 = frow[(size_t)p1.y * kRow + c];
-      const double a2 = frow[(size_t)p2.x * kRow + r], b2 = frow[(size_t)p2.y * kRow + c];
-      const double a3 = frow[(size_t)p3.x * kRow + r], b3 = frow[(size_t)p3.y * kRow + c];
-      acc0 += a0 * b0; acc1 += a1 * b1; acc2 += a2 * b2; acc3 += a3 * b3;
+           const uint16_t* __restrict__ mask_opt, int write_fixed, double* __restrict__ A) {
+  // 60 lanes work: 5 entry slots x 12 lanes; a lane owns 3 elements (r, c0..c0+2) of the
+  // 6x6 block for the entries of its slot (entry index = slot mod 5); the 5 partial
+  // blocks are added in a fixed order through LDS.
+  __shared__ double red[4][5][36];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t pair = blockIdx.x * 4 + w;
+  const bool valid = pair < npairs;
+  const int slot = lane / 12, t = lane - 12 * slot;
+  const int r = t >> 1, c0 = (t & 1) * 3;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  if (valid && lane < 60) {
+    const uint32_t e0 = pair_ptr[pair], e1 = pair_ptr[pair + 1];
+    uint32_t e = e0 + slot;
+    for (; e + 5 < e1; e += 10) {
+      const uint2 p0 = pair_ent[e], p1 = pair_ent[e + 5];
+      const double* ra0 = frow + (size_t)p0.x * kRow;
+      const double* rb0 = frow + (size_t)p0.y * kRow + c0;
+      const double* ra1 = frow + (size_t)p1.x * kRow;
+      const double* rb1 = frow + (size_t)p1.y * kRow + c0;
+      const double a0 = ra0[r], b00 = rb0[0], b01 = rb0[1], b02 = rb0[2];
+      const double a1 = ra1[r], b10 = rb1[0], b11 = rb1[1], b12 = rb1[2];
+      acc0 += a0 * b00; acc1 += a0 * b01; acc2 += a0 * b02;
+      acc0 += a1 * b10; acc1 += a1 * b11; acc2 += a1 * b12;
     }
-    for (; e < e1; ++e) {
+    for (; e < e1; e += 5) {
       const uint2 p0 = pair_ent[e];
-      acc0 += frow[(size_t)p0.x * kRow + r] * frow[(size_t)p0.y * kRow + c];
+      const double a0 = frow[(size_t)p0.x * kRow + r];
+      const double* rb0 = frow + (size_t)p0.y * kRow + c0;
+      acc0 += a0 * rb0[0]; acc1 += a0 * rb0[1]; acc2 += a0 * rb0[2];
     }
   }
-  double acc = (acc0 + acc1) + (acc2 + acc3);
+  if (lane < 60) {
+    red[w][slot][r * 6 + c0] = acc0;
+    red[w][slot][r * 6 + c0 + 1] = acc1;
+    red[w][slot][r * 6 + c0 + 2] = acc2;
+  }
+  __syncthreads();
+  if (!valid) return;
+  const uint2 ij = pair_ij[pair];
   const uint32_t i = ij.x, j = ij.y;
-  if (i == j) {
-    const uint16_t m = mask_opt[i];
-    if (lane < 36) {
-      if (r == c && (m & (1u << r))) acc = 1e6;
-      A[((size_t)i * D + r) * ld + (size_t)i * D + c] = acc;
-    } else if (lane - 36 < D - 6) {
-      const int k = 6 + (lane - 36);
-      if (m & (1u << k)) A[((size_t)i * D + k) * ld + (size_t)i * D + k] = 1e6;
+  if (lane < 36) {
+    const int rr = lane / 6, cc = lane - 6 * rr;
+    double acc = ((red[w][0][lane] + red[w][1][lane]) + (red[w][2][lane] + red[w][3][lane])) +
+                 red[w][4][lane];
+    if (i == j) {
+      const uint16_t m = mask_opt[i];
+      if (rr == cc && (m & (1u << rr))) acc = write_fixed ? 1e6 : 0.0;
+      A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] = acc;
+    } else {
+      A[((size_t)j * D + cc) * ld + (size_t)i * D + rr] = acc;
     }
-  } else if (lane < 36) {
-    A[((size_t)j * D + c) * ld + (size_t)i * D + r] = acc;
+  } else if (i == j && lane - 36 < D - 6) {
+    const uint16_t m = mask_opt[i];
+    const int k = 6 + (lane - 36);
+    if ((m & (1u << k)) && write_fixed) A[((size_t)i * D + k) * ld + (size_t)i * D + k] = 1e6;
   }
 }
 
@@ -114,7 +134,10 @@ int launch_gather_S(Engine* e) {
   const uint32_t n = st.n, ld = st.ld, n_pad = ld;
   // zero the whole lower storage + rhs row, then identity on the padding
   BAE_HIP(hipMemsetAsync(e->A.p, 0, (size_t)(n_pad + 1) * ld * sizeof(double), e->stream));
-  if (n_pad > n) {
+  // fixed entries (padding identity, 1e6 on masked parameters) are written by shard 0
+  // only, so that the cross-shard sum of S leaves them exact
+  const int write_fixed = (e->rank == 0) ? 1 : 0;
+  if (n_pad > n && write_fixed) {
     hipLaunchKernelGGL(k_pad_diag, dim3((n_pad - n + 255) / 256), dim3(256), 0, e->stream, n, n_pad,
                        ld, e->A.p);
     BAE_HIP(hipGetLastError());
@@ -122,10 +145,12 @@ int launch_gather_S(Engine* e) {
   BAE_HIP(hipMemsetAsync(e->rhs_p.p, 0, e->rhs_p.bytes(), e->stream));
   BAE_HIP(hipMemsetAsync(e->rhs_sc.p, 0, e->rhs_sc.bytes(), e->stream));
   if (st.n_pairs > 0) {
+    e->prof_begin(e->ev_gather);
     hipLaunchKernelGGL(k_gather_S, dim3((st.n_pairs + 3) / 4), dim3(256), 0, e->stream, st.n_pairs,
                        e->pair_ptr.p, e->pair_ij.p, e->pair_ent.p, e->frow.p, e->pose_dim, ld,
                        e->pose_mask.p + st.P /* masks by opt id live after the by-id masks */,
-                       e->A.p);
+                       write_fixed, e->A.p);
+    e->prof_end(e->ev_gather);
     BAE_HIP(hipGetLastError());
   }
   if (st.Pact > 0 && st.O > 0) {

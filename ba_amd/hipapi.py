@@ -50,6 +50,13 @@ class Timers(C.Structure):
                                           "apply_update")]
 
 
+class KernelStats(C.Structure):
+    _fields_ = [("syrk_launches", C.c_uint32), ("gather_launches", C.c_uint32),
+                ("landmarks_launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("syrk_ms", C.c_double), ("gather_ms", C.c_double), ("landmarks_ms", C.c_double),
+                ("syrk_flops", C.c_double)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 
 # every entry point include/ba_hip.h declares (checked by tests/test_abi.py)
@@ -64,7 +71,8 @@ SYMBOLS = [
     "ba_hip_get_landmarks", "ba_hip_get_landmark_flags", "ba_hip_num_pose_params",
     "ba_hip_num_lm_params", "ba_hip_get_S", "ba_hip_get_rhs", "ba_hip_get_delta_gn",
     "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_timers", "ba_hip_device_buffer",
-    "ba_hip_set_allreduce", "ba_hip_dense_solve", "ba_hip_select_kth",
+    "ba_hip_set_allreduce", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
+    "ba_hip_get_kernel_stats",
 ]
 
 
@@ -270,6 +278,23 @@ class Engine:
         t = Timers()
         self._chk(self.L.ba_hip_get_timers(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in Timers._fields_}
+
+    def set_profiling(self, on):
+        self._chk(self.L.ba_hip_set_profiling(self.h, int(on)))
+
+    def kernel_stats(self):
+        k = KernelStats()
+        self._chk(self.L.ba_hip_get_kernel_stats(self.h, C.byref(k)))
+        return k
+
+    def set_allreduce(self, fn, rank, nranks):
+        """fn(dev_ptr:int, count:int, dtype:int) -> int (0 = ok); kept alive by this object."""
+        if fn is None:
+            self._cb = None
+            self._chk(self.L.ba_hip_set_allreduce(self.h, None, None, 0, 1))
+            return
+        self._cb = ALLREDUCE_FN(lambda ctx, ptr, count, dtype: int(fn(ptr, count, dtype)))
+        self._chk(self.L.ba_hip_set_allreduce(self.h, self._cb, None, int(rank), int(nranks)))
 
     def dense_solve(self, a_lower, b):
         a, b = _d(a_lower), _d(b)

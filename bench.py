@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Gauss-Newton iterations/sec of the MI355X BundleAdjuster path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full Gauss-Newton iteration of ba::BundleAdjuster::Solve
+(/root/reference/src/BundleAdjuster.cpp:298-663) on a synthetic scene already resident in
+HBM: linearise (residuals, Huber median, Jacobians, V/W, gather S and rhs) -> dense
+Cholesky solve -> landmark back-substitution -> EvaluateResiduals -> ApplyUpdate ->
+EvaluateResiduals -> accept / roll back.  Exit tests are disabled (fixed step count).
+
+Workload at N = 1: BASELINE.json configs[1] — 1k poses / 100k landmarks / 1M reprojection
+residuals, pinhole camera, inverse-depth landmarks (LmSize = 1).  For N > 1 the SAME scene
+is sharded by landmark across the ranks (every rank holds all poses); the reduced pose
+system S, its right-hand side and a few scalars/histograms are summed with RCCL
+all-reduces over xGMI through the engine's all-reduce hook ("scaling": "strong").
+
+Rank 0 prints one JSON line with the driver's contract keys plus `roofline` (dominant
+kernel, measured live with HIP events on the engine's stream) and `cpu_baseline` (the
+oracle — a CPU restatement of the reference — timed on the host cores for ONE iteration
+of the same scene).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ba_amd import hipapi, scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet FP64 matrix peak (not listed in the local guide)
+
+
+class _CudaArray:
+    """Minimal __cuda_array_interface__ holder so torch can view an engine buffer."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr,
+                                         "data": (ptr, False), "version": 2}
+
+
+def make_allreduce(torch, dist):
+    def fn(ptr, count, dtype):
+        try:
+            t = torch.as_tensor(_CudaArray(ptr, count, "<f8" if dtype == 0 else "<i8"), device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            return 0
+        except Exception as exc:  # surfaced by the engine as "allreduce hook failed"
+            print("allreduce hook:", exc, file=sys.stderr)
+            return 1
+    return fn
+
+
+def build_engine(sc, lm_dim, lo, hi, device, stream=None):
+    """Upload poses (all) and the landmark shard [lo, hi) with its accepted residuals."""
+    nsel = sc.obs_per_landmark + (1 if lm_dim == 1 else 0)
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    if lm_dim == 1:
+        keep[::nsel] = False  # the reference-frame observation is rejected (BundleAdjuster.h:489-501)
+    sel = keep & (sc.obs_lm >= lo) & (sc.obs_lm < hi)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    eng = hipapi.Engine(lm_dim, 6, device=device, stream=stream)
+    eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+    eng.set_poses(sc.poses, is_active=pa)
+    eng.set_landmarks(sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi])
+    eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], sc.obs_lm[sel] - lo)
+    eng.finalize()
+    eng.begin_solve()
+    eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+    return eng, int(sel.sum())
+
+
+def gn_step(eng):
+    """One Gauss-Newton iteration (BundleAdjuster.cpp:298-663, GN branch :1084-1159)."""
+    eng.linearize()
+    rc = eng.solve_gn()
+    if rc != 0:
+        raise RuntimeError("reduced system not SPD (rc=%d)" % rc)
+    eng.compose_step(0.0, 1.0)
+    pre = eng.eval_residuals()
+    eng.apply_step()
+    post = eng.eval_residuals()
+    if post.total() > pre.total():
+        eng.rollback()
+        return pre.total(), False
+    return post.total(), True
+
+
+def cpu_baseline(sc, lm_dim):
+    """The oracle (CPU restatement of the reference, 1 thread as the reference runs its
+    projection loop serially, BundleAdjuster.cpp:1345-1347) on ONE iteration of the scene."""
+    from oracle import pyoracle as po
+    po.build()
+    ba = po.OracleBundleAdjuster(lm_dim, 6)
+    o = po.default_options()
+    o.use_dogleg = 0
+    o.error_change_threshold = 0
+    o.param_change_threshold = 0
+    ba.Init(o)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    ba.AddCamera(sc.cam_params)
+    ba.add_poses(sc.poses, is_active=pa)
+    ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    t0 = time.time()
+    ba.Solve(1)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "iterations/sec", "cores": 1, "kind": "port",
+            "sample": "1 Gauss-Newton iteration of the same scene (%.1f s)" % dt,
+            "phases_s": {k: round(v, 3) for k, v in ba.timers().items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--poses", type=int, default=1000)
+    ap.add_argument("--landmarks", type=int, default=100000)
+    ap.add_argument("--obs-per-landmark", type=int, default=10)
+    ap.add_argument("--lm-dim", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+
+    P, L, K, lm_dim = args.poses, args.landmarks, args.obs_per_landmark, args.lm_dim
+    sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=2)
+    # landmark shards: contiguous, equal counts (every landmark has K residuals, so the
+    # Schur work  sum k(k+1)/2  is balanced too)
+    lo, hi = (L * rank) // world, (L * (rank + 1)) // world
+    eng, n_obs_local = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
+    if world > 1:
+        eng.set_allreduce(make_allreduce(torch, dist), rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        gn_step(eng)
+    eng.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    accepted = 0
+    err = 0.0
+    for _ in range(args.steps):
+        err, ok = gn_step(eng)
+        accepted += int(ok)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ks = eng.kernel_stats()
+    timers = eng.get_timers()
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.end_solve()
+
+    if rank == 0:
+        n = eng.num_pose_params()
+        O = L * K
+        ms = 1e3 * elapsed / args.steps
+        # dominant kernel: the trailing update of the dense Cholesky (FP64 MFMA)
+        syrk_tf = ks.syrk_flops / (ks.syrk_ms * 1e-3) / 1e12 if ks.syrk_ms > 0 else 0.0
+        # HBM-bound kernels, algorithmic bytes per launch (DESIGN.md §Roofline accounting)
+        ell = lm_dim
+        b_landmarks = O / world * 32 + (L / world) * 36 + P * 56 + (L / world) * 8 * (ell * ell + ell)
+        b_gather = 8.0 * n * (n + 1) / 2 + 8 * n
+        lm_gbs = b_landmarks * ks.landmarks_launches / (ks.landmarks_ms * 1e-3) / 1e9 if ks.landmarks_ms > 0 else 0.0
+        ga_gbs = b_gather * ks.gather_launches / (ks.gather_ms * 1e-3) / 1e9 if ks.gather_ms > 0 else 0.0
+        out = {
+            "metric": "Gauss-Newton iterations/sec",
+            "value": args.steps / elapsed,
+            "unit": "iterations/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: %d poses / %d landmarks / %d reprojection "
+                                   "residuals, pinhole, LmSize=%d, PoseSize=6, Gauss-Newton (no dogleg), "
+                                   "2 anchor poses inactive" % (P, L, O, lm_dim),
+                       "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
+                       "parallelism": "landmark-sharded x%d, all-reduce of S" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "k_syrk (dense Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
+                         "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                         "launches": ks.syrk_launches,
+                         "avg_launch_us": 1e3 * ks.syrk_ms / max(ks.syrk_launches, 1)},
+            "hbm_kernels": {
+                "k_landmarks": {"achieved_GBs": lm_gbs, "frac_of_8TBs": lm_gbs / HBM_PEAK_GBS,
+                                "avg_launch_us": 1e3 * ks.landmarks_ms / max(ks.landmarks_launches, 1),
+                                "algorithmic_bytes": b_landmarks},
+                "k_gather_S": {"achieved_GBs": ga_gbs, "frac_of_8TBs": ga_gbs / HBM_PEAK_GBS,
+                               "avg_launch_us": 1e3 * ks.gather_ms / max(ks.gather_launches, 1),
+                               "algorithmic_bytes": b_gather}},
+            "phase_ms_last_step": {k: round(v, 4) for k, v in timers.items()},
+            "accepted_steps": accepted,
+            "final_error": err,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sc, lm_dim)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,17 @@ int ba_hip_get_step(ba_hip_engine* e, double* delta_p, double* delta_l);
 int ba_hip_get_proj_weights(ba_hip_engine* e, double* weight); /* per residual id */
 int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
 
+/* Per-kernel device time, accumulated since ba_hip_set_profiling(e, 1): HIP events on
+ * the engine's stream around every launch of the three hot kernels (used by bench.py's
+ * roofline; costs two events per launch, so it is off by default). */
+typedef struct {
+  uint32_t syrk_launches, gather_launches, landmarks_launches, reserved;
+  double syrk_ms, gather_ms, landmarks_ms;
+  double syrk_flops;       /* algorithmic flops of those k_syrk launches */
+} ba_hip_kernel_stats;
+int ba_hip_set_profiling(ba_hip_engine* e, int enable);
+int ba_hip_get_kernel_stats(ba_hip_engine* e, ba_hip_kernel_stats* out);
+
 /* ---- raw device access for drivers that own streams/collectives ---------------------- */
 /* Device pointer + element count of the buffers whose cross-shard SUM defines the
  * iteration: 0 = S (lower storage incl. rhs row), 1 = scalar block. */
