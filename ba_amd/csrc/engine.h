@@ -67,7 +67,7 @@ struct Structure {
   uint32_t n_pairs = 0;   // pose pairs (i <= j) with a block in S
   uint64_t n_pair_entries = 0;
   uint64_t n_rhs_entries = 0;
-  uint32_t n_ppair = 0;   // pose pairs receiving pose-pose residual blocks
+  uint32_t n_pp_entries = 0;  // (pose, residual side) entries of the pose-pose scatter
   std::vector<int32_t> pose_opt, lm_opt;
   std::vector<uint32_t> obs_perm;  // sorted position -> residual id
 };
@@ -111,6 +111,16 @@ struct Engine {
   DBuf<uint2> pair_ent;                  // (rowA, rowB)
   DBuf<uint32_t> prhs_ptr;               // [Pact+1]
   DBuf<uint2> prhs_ent;                  // (row, scalar index)
+
+  // pose-pose residuals (unary | binary | imu slots)
+  DBuf<uint8_t> pose_active;
+  DBuf<uint32_t> un_pose; DBuf<double> un_t, un_cov_inv, un_scale; DBuf<uint8_t> un_rot;
+  DBuf<uint32_t> bin_p1, bin_p2; DBuf<double> bin_t, bin_cov_inv, bin_cov_inv_sqrt, bin_w;
+  DBuf<uint8_t> bin_rot;
+  DBuf<uint32_t> imu_p1, imu_p2, imu_ptr; DBuf<double> imu_meas, imu_consts, imu_cov_inv;
+  DBuf<double> pp_h, pp_g, pp_dz, pp_info, pp_err;
+  DBuf<uint32_t> pp_ptr, pp_res_p1, pp_res_p2;
+  DBuf<uint4> pp_ent;
 
   // ---- device: state (double buffered)
   DBuf<double> pose_state[2];            // [P][16]
@@ -175,7 +185,10 @@ int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norm
 int launch_apply_step(Engine* e);                      // state[cur] -> state[1-cur]
 int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out);
 int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out);
-int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out);
+int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard = true);
+int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs);
+int launch_posepose_eval(Engine* e, ba_hip_errors* errs);
+int launch_posepose_jrhs(Engine* e, double* out);
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status);
 
 }  // namespace bae

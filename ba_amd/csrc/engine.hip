@@ -311,6 +311,36 @@ static int build_structure(Engine* e) {
           prhs_ent[curB[linc_pose_lm[q]]++] = make_uint2(linc_row[q] + LM + k, 2 * st.O + l * LM + k);
   }
 
+  // ---- pose-pose residuals: slots [unary | binary | imu], scatter lists per active pose ------
+  const uint32_t nu = pb.num_unary, nbn = pb.num_binary, ni = pb.num_imu, nres = nu + nbn + ni;
+  std::vector<uint32_t> res_p1(nres), res_p2(nres, 0xffffffffu);
+  for (uint32_t i = 0; i < nu; ++i) res_p1[i] = pb.un_pose[i];
+  for (uint32_t i = 0; i < nbn; ++i) { res_p1[nu + i] = pb.bin_p1[i]; res_p2[nu + i] = pb.bin_p2[i]; }
+  for (uint32_t i = 0; i < ni; ++i) { res_p1[nu + nbn + i] = pb.imu_p1[i]; res_p2[nu + nbn + i] = pb.imu_p2[i]; }
+  for (uint32_t s = 0; s < nres; ++s)
+    if (res_p1[s] >= st.P || (res_p2[s] != 0xffffffffu && res_p2[s] >= st.P))
+      return e->fail_msg("pose-pose residual references an unknown pose");
+  std::vector<uint32_t> pp_ptr(st.Pact + 1, 0);
+  for (uint32_t s = 0; s < nres; ++s) {
+    const int32_t o1 = st.pose_opt[res_p1[s]];
+    const int32_t o2 = res_p2[s] != 0xffffffffu ? st.pose_opt[res_p2[s]] : -1;
+    if (o1 >= 0) pp_ptr[o1 + 1]++;
+    if (o2 >= 0 && res_p2[s] != res_p1[s]) pp_ptr[o2 + 1]++;
+  }
+  for (uint32_t p = 0; p < st.Pact; ++p) pp_ptr[p + 1] += pp_ptr[p];
+  st.n_pp_entries = st.Pact ? pp_ptr[st.Pact] : 0;
+  std::vector<uint4> pp_ent(st.n_pp_entries);
+  {
+    std::vector<uint32_t> cur(pp_ptr.begin(), pp_ptr.end() - 1);
+    for (uint32_t s = 0; s < nres; ++s) {
+      const int32_t o1 = st.pose_opt[res_p1[s]];
+      const bool two = res_p2[s] != 0xffffffffu && res_p2[s] != res_p1[s];
+      const int32_t o2 = two ? st.pose_opt[res_p2[s]] : -1;
+      if (o1 >= 0) pp_ent[cur[o1]++] = make_uint4(s, 0, o2 >= 0 ? (uint32_t)o2 : 0xffffffffu, 0);
+      if (o2 >= 0) pp_ent[cur[o2]++] = make_uint4(s, 1, o1 >= 0 ? (uint32_t)o1 : 0xffffffffu, 0);
+    }
+  }
+
   // ---- upload ------------------------------------------------------------------------------
   int rc;
 #define UP(buf, vec) if ((rc = upload(e, e->buf, vec))) return rc
@@ -323,7 +353,33 @@ static int build_structure(Engine* e) {
   UP(linc_ptr, linc_ptr); UP(linc_row, linc_row); UP(linc_pose, linc_pose_lm);
   UP(pair_ptr, pair_ptr); UP(pair_ij, pair_ij); UP(pair_ent, pair_ent);
   UP(prhs_ptr, prhs); UP(prhs_ent, prhs_ent);
+  UP(pose_active, pb.pose_active);
+  UP(un_pose, pb.un_pose); UP(un_t, pb.un_t); UP(un_cov_inv, pb.un_cov_inv); UP(un_rot, pb.un_rot);
+  UP(bin_p1, pb.bin_p1); UP(bin_p2, pb.bin_p2); UP(bin_t, pb.bin_t); UP(bin_cov_inv, pb.bin_cov_inv);
+  UP(bin_cov_inv_sqrt, pb.bin_cov_inv_sqrt); UP(bin_w, pb.bin_w); UP(bin_rot, pb.bin_rot);
+  UP(imu_p1, pb.imu_p1); UP(imu_p2, pb.imu_p2); UP(imu_ptr, pb.imu_ptr); UP(imu_meas, pb.imu_meas);
+  UP(pp_ptr, pp_ptr); UP(pp_ent, pp_ent); UP(pp_res_p1, res_p1); UP(pp_res_p2, res_p2);
 #undef UP
+  {
+    std::vector<double> ones(std::max<uint32_t>(nu, 1), 1.0);
+    if ((rc = upload(e, e->un_scale, ones))) return rc;
+    // gravity | measurement noise diag (gyro^2 x3, accel^2 x3) | bias random walk
+    std::vector<double> c(15);
+    for (int i = 0; i < 3; ++i) {
+      c[i] = pb.gravity[i];
+      c[3 + i] = e->opt.gyro_sigma * e->opt.gyro_sigma;
+      c[6 + i] = e->opt.accel_sigma * e->opt.accel_sigma;
+      c[9 + i] = e->opt.gyro_bias_sigma * e->opt.gyro_bias_sigma;
+      c[12 + i] = e->opt.accel_bias_sigma * e->opt.accel_bias_sigma;
+    }
+    if ((rc = upload(e, e->imu_consts, c))) return rc;
+    const size_t nr1 = std::max<size_t>(nres, 1);
+    BAE_HIP(e->pp_h.alloc(nr1 * 3 * 225)); BAE_HIP(e->pp_g.alloc(nr1 * 30));
+    BAE_HIP(e->pp_dz.alloc(nr1 * 2 * 225)); BAE_HIP(e->pp_info.alloc(nr1 * 225));
+    BAE_HIP(e->pp_err.alloc(nr1));
+    BAE_HIP(e->imu_cov_inv.alloc(std::max<size_t>(ni, 1) * 225));
+    BAE_HIP(hipMemsetAsync(e->imu_cov_inv.p, 0, e->imu_cov_inv.bytes(), e->stream));
+  }
   // cameras: params(4) | T_vs Rt(12) | T_sv Rt(12) | T_vs as t,q (7)
   {
     std::vector<double> cam((size_t)st.C * 35, 0.0);
@@ -466,6 +522,11 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
   REL(gn_l); REL(step_p); REL(step_l); REL(invdiag); REL(partials); REL(scalars_out); REL(hist);
   REL(flags);
+  REL(pose_active); REL(un_pose); REL(un_t); REL(un_cov_inv); REL(un_scale); REL(un_rot);
+  REL(bin_p1); REL(bin_p2); REL(bin_t); REL(bin_cov_inv); REL(bin_cov_inv_sqrt); REL(bin_w); REL(bin_rot);
+  REL(imu_p1); REL(imu_p2); REL(imu_ptr); REL(imu_meas); REL(imu_consts); REL(imu_cov_inv);
+  REL(pp_h); REL(pp_g); REL(pp_dz); REL(pp_info); REL(pp_err); REL(pp_ptr); REL(pp_res_p1);
+  REL(pp_res_p2); REL(pp_ent);
 #undef REL
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -603,8 +664,6 @@ int ba_hip_finalize(ba_hip_engine* h) {
   Problem& pb = e->prob;
   if (pb.pose_active.size() != pb.num_poses) pb.pose_active.assign(pb.num_poses, 1);
   if (pb.lm_active.size() != pb.num_lms) pb.lm_active.assign(pb.num_lms, 1);
-  if (pb.num_unary || pb.num_binary || pb.num_imu)
-    return e->fail_msg("pose-pose residuals (unary/binary/IMU) are not enabled in this build yet");
   int rc = build_structure(e);
   if (rc) return rc;
   e->finalized = true;
@@ -668,6 +727,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   EventTimer t_s(e->stream);
   e->factored = false;
   if ((rc = launch_gather_S(e))) return rc;
+  if ((rc = launch_posepose_build(e, c_huber, &errs))) return rc;
   // copy the reduced rhs into the rhs row of A
   BAE_HIP(hipMemcpyAsync(e->A.p + (size_t)st.ld * st.ld, e->rhs_sc.p, (size_t)st.n * sizeof(double),
                          hipMemcpyDeviceToDevice, e->stream));
@@ -719,8 +779,13 @@ int ba_hip_solve_gn(ba_hip_engine* h) {
 int ba_hip_dogleg_terms(ba_hip_engine* h, int gn_available, ba_hip_dogleg_scalars* out) {
   ENG(h);
   NEED_FINAL();
-  (void)gn_available; (void)out;
-  return e->fail_msg("dogleg is not enabled in this build yet");
+  BAE_HIP(hipSetDevice(e->device));
+  int rc = launch_dogleg(e, gn_available, out);
+  if (rc) return rc;
+  double pp = 0.0;
+  if ((rc = launch_posepose_jrhs(e, &pp))) return rc;
+  out->j_rhs_sq += pp;
+  return 0;
 }
 
 int ba_hip_compose_step(ba_hip_engine* h, double coef_rhs, double coef_gn, ba_hip_step_norms* out) {
@@ -772,8 +837,9 @@ int ba_hip_eval_residuals(ba_hip_engine* h, ba_hip_errors* out) {
   if (rc) return rc;
   double s = 0.0;
   if ((rc = sum_partials(e, (e->st.O + 255) / 256, 1, &s))) return rc;
-  e->timers.evaluate_residuals = t.stop_ms();
   errs.proj_error = s;
+  if ((rc = launch_posepose_eval(e, &errs))) return rc;
+  e->timers.evaluate_residuals = t.stop_ms();
   if (out) *out = errs;
   return 0;
 }
@@ -904,6 +970,15 @@ int ba_hip_get_proj_weights(ba_hip_engine* h, double* weight) {
   BAE_HIP(hipStreamSynchronize(e->stream));
   if (st.O) BAE_HIP(hipMemcpy(w.data(), e->obs_w.p, (size_t)st.O * 8, hipMemcpyDeviceToHost));
   for (uint32_t s = 0; s < st.O; ++s) weight[st.obs_perm[s]] = w[s];
+  return 0;
+}
+
+int ba_hip_get_unary_scales(ba_hip_engine* h, double* scale) {
+  ENG(h);
+  NEED_FINAL();
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  if (e->prob.num_unary)
+    BAE_HIP(hipMemcpy(scale, e->un_scale.p, (size_t)e->prob.num_unary * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -17,6 +17,10 @@
 // The products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64 — the one true dense
 // contraction of the path); accumulating 256 columns per pass over the trailing matrix
 // quarters the HBM read-modify-write traffic of the C tiles compared with K = 64.
+// The factorisation is L D L^T with D = diag(+-1) (L carries sqrt|pivot|): for SPD
+// systems it IS the Cholesky factor, and like the reference's un-pivoted LDL^T it does
+// not break down on the indefinite / nearly singular systems that ill-posed gauges
+// produce (BundleAdjuster.cpp:752-761).
 // The right-hand side rides along as one extra row below the matrix, so the forward
 // substitution L y = b is a by-product; k_backward then solves L^T x = y block row by
 // block row.  The system is SPD for well-posed problems (masked parameters carry 1e6 on
@@ -51,7 +55,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // Also stores 1/L[j][j] for the triangular solves.
 __global__ void __launch_bounds__(64)
 k_potrf64(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ dinv_out,
-          int* __restrict__ status) {
+          double* __restrict__ dsgn_out, int* __restrict__ status) {
   __shared__ double T[NB][LDP];
   __shared__ double colbuf[2][NB];
   const int lane = threadIdx.x;
@@ -68,21 +72,25 @@ k_potrf64(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ 
 #pragma unroll
   for (int c = 0; c < NB; ++c) a[c] = (c <= lane) ? T[lane][c] : 0.0;
   int bad = 0;
-  double my_dinv = 0.0;
+  double my_dinv = 0.0, my_sgn = 1.0;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const double d = readlane_f64(a[j], j);
-    if (!(d > 0.0)) bad = 1;
-    const double dd = d > 0.0 ? d : 1.0;
+    const double ad = fabs(d);
+    if (!(ad > 0.0) || !(ad < 1e300)) bad = 1;  // zero / NaN / Inf pivot
+    const double sgn = d < 0.0 ? -1.0 : 1.0;
+    const double dd = (ad > 0.0 && ad < 1e300) ? ad : 1.0;
     // y ~ 1/sqrt(dd): hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 dd y^2)
     double y = __builtin_amdgcn_rsq(dd);
     y = y * fma(-0.5 * dd * y, y, 1.5);
     y = y * fma(-0.5 * dd * y, y, 1.5);
-    if (lane == j) my_dinv = y;
-    a[j] *= y;  // lane j: sqrt(d); lanes below: L[r][j]
+    if (lane == j) { my_dinv = y; my_sgn = sgn; }
+    a[j] *= y * sgn;  // lanes below: L[r][j] = d_j A[r][j] / sqrt|d|
+    if (lane == j) a[j] = fabs(a[j]);  // L[j][j] = sqrt|d|
     colbuf[j & 1][lane] = a[j];
+    const double sa = sgn * a[j];
 #pragma unroll
-    for (int c = j + 1; c < NB; ++c) a[c] -= a[j] * colbuf[j & 1][c];  // L[r][j] L[c][j]
+    for (int c = j + 1; c < NB; ++c) a[c] -= sa * colbuf[j & 1][c];  // d_j L[r][j] L[c][j]
   }
 #pragma unroll
   for (int c = 0; c < NB; ++c) T[lane][c] = a[c];
@@ -91,6 +99,7 @@ k_potrf64(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ 
   for (int r = 0; r < NB; ++r)
     if (lane <= r) Akk[(size_t)r * ld + lane] = T[r][lane];
   dinv_out[(size_t)k * NB + lane] = my_dinv;
+  dsgn_out[(size_t)k * NB + lane] = my_sgn;
   if (lane == 0 && bad) atomicExch(status, 1);
 }
 
@@ -103,7 +112,8 @@ k_potrf64(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ 
 // reads (broadcast).  One wavefront per 64-row block; the last block is the rhs row.
 __global__ void __launch_bounds__(64)
 k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
-         double* __restrict__ Apanel, uint32_t ld, uint32_t nrowblk) {
+         const double* __restrict__ dsgn, double* __restrict__ Apanel, uint32_t ld,
+         uint32_t nrowblk) {
   __shared__ double Xs[NB][LDP];
   __shared__ __attribute__((aligned(16))) double LsT[NB][LDT];  // LsT[p][j] = L[j][p] / L[j][j]
   __shared__ double dv[NB];
@@ -122,10 +132,11 @@ k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
       Xs[r][lane] = ta[r];
       // row r of L, element (r, lane), pre-scaled by 1/L[r][r]: with t_j = s_j / L[j][j]
       // the substitution needs no multiply on its serial chain (x_p = t_p)
-      LsT[lane][r] = tl[r] * dinv[r];
+      // (column sign d_lane, row scale d_r / L[r][r]:  x_j = d_j (a_j - sum x_p d_p L[j][p]) / L[j][j])
+      LsT[lane][r] = tl[r] * dinv[r] * dsgn[r] * dsgn[lane];
     }
   }
-  dv[lane] = dinv[lane];
+  dv[lane] = dinv[lane] * dsgn[lane];
   __syncthreads();
   double s[NB];
 #pragma unroll
@@ -191,13 +202,24 @@ __device__ __forceinline__ void load_tile(double (*T)[LDT], const double* __rest
   }
 }
 
+// same, columns scaled by the pivot signs d_k = +-1 (C -= X D Y^T)
+__device__ __forceinline__ void load_tile_signed(double (*T)[LDT], const double* __restrict__ src,
+                                                 uint32_t ld, const double* __restrict__ sg, int tid) {
+  for (int idx = tid; idx < NB * (NB / 2); idx += 256) {
+    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
+    const double2 v = *reinterpret_cast<const double2*>(src + (size_t)r * ld + c2);
+    T[r][c2] = v.x * sg[c2];
+    T[r][c2 + 1] = v.y * sg[c2 + 1];
+  }
+}
+
 // Update of the tiles (i, c), c in [c0, c0 + gridDim.y), i in [c, nblk] (i == nblk: the
 // rhs row) with the tile columns [kb0, kb1):
 //     A_ic -= sum_kb A_i,kb * A_c,kb^T
 // grid = (nblk - c0 + 1, number of tile columns); blockIdx.x counts rows from c.
 __global__ void __launch_bounds__(256)
 k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
-         uint32_t kb1) {
+         uint32_t kb1, const double* __restrict__ dsgn) {
   __shared__ double X[NB][LDT];
   __shared__ double Y[NB][LDT];
   const uint32_t c = c0 + blockIdx.y;
@@ -215,7 +237,7 @@ k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32
     const double* Ack = A + ((size_t)c * NB) * ld + (size_t)kb * NB;
     if (kb != kb0) __syncthreads();
     load_tile(X, Aik, ld, rows, tid);
-    load_tile(Y, Ack, ld, NB, tid);
+    load_tile_signed(Y, Ack, ld, dsgn + (size_t)kb * NB, tid);
     __syncthreads();
     tile_mma(X, Y, wave, lane, acc);
   }
@@ -281,28 +303,30 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status) {
   (void)n;
   const uint32_t nblk = ld / NB;
-  BAE_HIP(e->invdiag.alloc((size_t)nblk * NB));  // 1 / diag(L)
+  BAE_HIP(e->invdiag.alloc((size_t)2 * nblk * NB));  // 1 / diag(L), then the pivot signs
+  double* dsgn = e->invdiag.p + (size_t)nblk * NB;
   BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), e->stream));
   for (uint32_t J = 0; J < nblk; J += KOUT) {
     const uint32_t Jend = J + KOUT < nblk ? J + KOUT : nblk;
     for (uint32_t jj = J; jj < Jend; ++jj) {
       hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, e->stream, dA, ld, jj, e->invdiag.p,
-                         e->flags.p);
+                         dsgn, e->flags.p);
       hipLaunchKernelGGL(k_trsm64, dim3(nblk - jj), dim3(64), 0, e->stream,
                          (const double*)(dA + ((size_t)jj * NB) * ld + (size_t)jj * NB),
                          (const double*)(e->invdiag.p + (size_t)jj * NB),
+                         (const double*)(dsgn + (size_t)jj * NB),
                          dA + ((size_t)(jj + 1) * NB) * ld + (size_t)jj * NB, ld, nblk - jj);
       if (jj + 1 < Jend) {
         // in-panel update of the panel's remaining tile columns with tile column jj
         hipLaunchKernelGGL(k_update, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0,
-                           e->stream, dA, ld, nblk, jj + 1, jj, jj + 1);
+                           e->stream, dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
       }
     }
     if (Jend < nblk) {
       // trailing update right of the panel, K = 64 * (Jend - J)
       e->prof_begin(e->ev_syrk);
       hipLaunchKernelGGL(k_update, dim3(nblk - Jend + 1, nblk - Jend), dim3(256), 0, e->stream, dA,
-                         ld, nblk, Jend, J, Jend);
+                         ld, nblk, Jend, J, Jend, (const double*)dsgn);
       e->prof_end(e->ev_syrk);
       if (e->profiling) {
         const double m = (double)(nblk - Jend);

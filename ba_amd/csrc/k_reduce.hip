@@ -181,7 +181,7 @@ __global__ void k_sum_partials(uint32_t nparts, uint32_t ncomp, const double* __
   }
 }
 
-int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out) {
+int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard) {
   if (nparts == 0) {
     for (uint32_t c = 0; c < ncomp; ++c) host_out[c] = 0.0;
   } else {
@@ -192,7 +192,7 @@ int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out) {
                            hipMemcpyDeviceToHost, e->stream));
     BAE_HIP(hipStreamSynchronize(e->stream));
   }
-  if (e->allreduce && e->nranks > 1) {
+  if (cross_shard && e->allreduce && e->nranks > 1) {
     // cross-shard sum of the scalars
     BAE_HIP(hipMemcpyAsync(e->scalars_out.p, host_out, ncomp * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
@@ -425,6 +425,44 @@ __global__ void k_jrhs(uint32_t O, int D, int LM, const int32_t* __restrict__ ob
     __syncthreads();
   }
   if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
+  const Structure& st = e->st;
+  memset(out, 0, sizeof(*out));
+  double h[3];
+  int rc;
+  if (st.n > 0) {  // pose parts: replicated on every shard
+    const uint32_t nb = (st.n + 255) / 256;
+    hipLaunchKernelGGL(k_dots_pose, dim3(nb), dim3(256), 0, e->stream, st.n, gn_available,
+                       e->rhs_p.p, e->gn_p.p, e->partials.p, nb);
+    BAE_HIP(hipGetLastError());
+    if ((rc = sum_partials(e, nb, 3, h, false))) return rc;
+    out->rhs_p_sq = h[0]; out->gn_p_sq = h[1]; out->rhs_gn_p = h[2];
+  }
+  {  // landmark parts: sharded
+    const uint32_t nb = (st.L > 0 && e->lm_dim > 0) ? (st.L + 255) / 256 : 0;
+    if (nb) {
+      hipLaunchKernelGGL(k_dots_lm, dim3(nb), dim3(256), 0, e->stream, st.L, e->lm_dim, gn_available,
+                         e->lm_opt.p, e->lm_bl.p, e->gn_l.p, e->partials.p, nb);
+      BAE_HIP(hipGetLastError());
+    }
+    if ((rc = sum_partials(e, nb, 3, h, true))) return rc;
+    out->rhs_l_sq = h[0]; out->gn_l_sq = h[1]; out->rhs_gn_l = h[2];
+  }
+  {  // || J_pr rhs_p + J_l rhs_l ||^2 over the observations (BundleAdjuster.cpp:881-906)
+    const uint32_t nb = st.O > 0 ? (st.O + 255) / 256 : 0;
+    if (nb) {
+      hipLaunchKernelGGL(k_jrhs, dim3(nb), dim3(256), 0, e->stream, st.O, e->pose_dim, e->lm_dim,
+                         e->obs_jrow_m.p, e->obs_jrow_r.p, e->obs_pose.p, e->obs_lm.p,
+                         e->lm_ref_pose.p, e->pose_opt.p, e->lm_opt.p, e->frow.p, e->obs_jl.p,
+                         e->rhs_p.p, e->lm_bl.p, e->partials.p);
+      BAE_HIP(hipGetLastError());
+    }
+    if ((rc = sum_partials(e, nb, 1, h, true))) return rc;
+    out->j_rhs_sq = h[0];
+  }
+  return 0;
 }
 
 }  // namespace bae

@@ -265,3 +265,57 @@ def add_scene_to(ba, sc, pose_dim=6, active=None):
     ba.add_poses(sc.poses, v_w=v, is_active=act, time=getattr(sc, 'pose_time', None))
     ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
     return ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+
+
+# ---------------------------------------------------------------------------------------
+# visual-inertial extension (BASELINE.json configs[2] / configs[4])
+def _traj_at(t, period, radius=7.5, height=-1.5):
+    """Position and rotation matrix of the curvy-square trajectory at time(s) t."""
+    s = np.asarray(t, dtype=np.float64) / period * 2 * np.pi
+    r = radius * (1.0 + 0.15 * np.cos(4 * s))
+    pos = np.stack([r * np.cos(s), r * np.sin(s), height + 0.3 * np.sin(3 * s)], -1)
+    dr = -radius * 0.6 * np.sin(4 * s)
+    vel = np.stack([dr * np.cos(s) - r * np.sin(s), dr * np.sin(s) + r * np.cos(s),
+                    0.9 * np.cos(3 * s)], -1)
+    zc = vel / np.linalg.norm(vel, axis=-1, keepdims=True)
+    down = np.array([0.0, 0.0, 1.0])
+    xc = np.cross(np.broadcast_to(down, zc.shape), zc)
+    xc /= np.linalg.norm(xc, axis=-1, keepdims=True)
+    yc = np.cross(zc, xc)
+    return pos, np.stack([xc, yc, zc], -1)
+
+
+def add_inertial(sc, period=60.0, samples_per_interval=10, seed=0, vel_sigma=0.02,
+                 gyro_sigma=5.3088444e-5, accel_sigma=0.001883649, gravity=None):
+    """Attach pose times, velocities, IMU samples (one residual per consecutive pose pair,
+    /root/reference/matlab/simulate_vins.py:155-156) to a Scene.  Body rates and specific
+    force come from central differences of the analytic trajectory; the integrator model
+    is the reference's:  v' = R (a_m + b_a) - g,  q' = exp(R (w_m + b_g) dt) q
+    (/root/reference/include/ba/Types.h:376-416)."""
+    P = sc.num_poses
+    g = GRAVITY if gravity is None else np.asarray(gravity, dtype=np.float64)
+    tp = np.arange(P) * (period / P)
+    h = 1e-4
+    n = samples_per_interval
+    # sample times: n+1 samples spanning each pose interval (shared end points)
+    ts = (tp[:-1, None] + (tp[1] - tp[0]) * np.arange(n + 1)[None, :] / n)  # (P-1, n+1)
+    p0, R0 = _traj_at(ts, period)
+    pp, Rp = _traj_at(ts + h, period)
+    pm, Rm = _traj_at(ts - h, period)
+    acc = (pp - 2 * p0 + pm) / (h * h)
+    dR = (Rp - Rm) / (2 * h)
+    W = np.einsum('...ji,...jk->...ik', R0, dR)  # R^T dR = [w_body]x
+    w_body = np.stack([W[..., 2, 1], W[..., 0, 2], W[..., 1, 0]], -1)
+    a_body = np.einsum('...ji,...j->...i', R0, acc + g)
+    rng = np.random.Generator(np.random.PCG64([seed, 0xBA5E, 7]))
+    w_body = w_body + rng.normal(0, gyro_sigma, w_body.shape)
+    a_body = a_body + rng.normal(0, accel_sigma, a_body.shape)
+    sc.imu_meas = np.concatenate([w_body, a_body, ts[..., None]], -1)  # (P-1, n+1, 7)
+    _, Rg = _traj_at(tp, period)
+    vel = (_traj_at(tp + h, period)[0] - _traj_at(tp - h, period)[0]) / (2 * h)
+    sc.gt_vel = vel
+    sc.init_vel = vel + rng.normal(0, vel_sigma, vel.shape)
+    sc.init_bias = np.zeros((P, 6))
+    sc.pose_time = tp
+    sc.gravity = g
+    return sc

@@ -711,6 +711,14 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     ba_hip_get_step(engine_, last_step_.delta_p.data(), last_step_.delta_l.data());
   }
   if (!DownloadState()) return;
+  if (!un_pose_.empty()) {
+    // the reference scales each unary cov_inv in place every BuildProblem
+    // (BundleAdjuster.cpp:1469), so the compounded weights survive across Solve() calls
+    std::vector<double> sc(un_pose_.size(), 1.0);
+    if (Check(ba_hip_get_unary_scales(engine_, sc.data()), "ba_hip_get_unary_scales"))
+      for (size_t i = 0; i < sc.size(); ++i)
+        for (int k = 0; k < 36; ++k) un_cov_inv_[36 * i + k] *= sc[i];
+  }
   if (kBiasInState && !poses_.empty()) {  // :666-669
     for (int i = 0; i < 3; ++i) { imu_.b_g[i] = poses_.back().b[i]; imu_.b_a[i] = poses_.back().b[3 + i]; }
   }

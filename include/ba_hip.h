@@ -166,6 +166,9 @@ int ba_hip_get_delta_gn(ba_hip_engine* e, double* delta_p, double* delta_l);
 int ba_hip_get_step(ba_hip_engine* e, double* delta_p, double* delta_l);
 int ba_hip_get_proj_weights(ba_hip_engine* e, double* weight); /* per residual id */
 int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
+/* cumulative Huber scale of every unary residual's cov^-1 (the reference multiplies
+ * cov_inv in place every BuildProblem, BundleAdjuster.cpp:1469) */
+int ba_hip_get_unary_scales(ba_hip_engine* e, double* scale);
 
 /* Per-kernel device time, accumulated since ba_hip_set_profiling(e, 1): HIP events on
  * the engine's stream around every launch of the three hot kernels (used by bench.py's

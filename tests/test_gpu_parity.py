@@ -30,10 +30,10 @@ def hip_options(**kw):
     return o
 
 
-def both(po, sc, lm_dim, active=None, lm_active=None, **kw):
-    o = po.OracleBundleAdjuster(lm_dim, 6)
+def both(po, sc, lm_dim, active=None, lm_active=None, pose_dim=6, **kw):
+    o = po.OracleBundleAdjuster(lm_dim, pose_dim)
     o.Init(gn_options(po, **kw))
-    h = adjuster.BundleAdjuster(lm_dim, 6)
+    h = adjuster.BundleAdjuster(lm_dim, pose_dim)
     h.Init(hip_options(**kw))
     fill(o, sc, active=active, lm_active=lm_active)
     fill(h, sc, active=active, lm_active=lm_active)
@@ -64,8 +64,18 @@ def test_dense_cholesky_solve_matches_numpy():
         x, rc = eng.dense_solve(np.tril(a), b)
         assert rc == 0
         assert rel_err(x, np.linalg.solve(a, b)) < 1e-11
-    # a non-SPD matrix is reported as FactorizationError (ba::FactorizationError = 4)
-    a = -np.eye(10)
+    # symmetric indefinite (quasi-definite) systems factor as L D L^T like the reference's
+    # un-pivoted LDLT (BundleAdjuster.cpp:752-761)
+    for n in (10, 130, 500):
+        m = rng.normal(size=(n, n))
+        a = m @ m.T + n * np.eye(n)
+        a[n // 2:, n // 2:] -= 2.5 * (m @ m.T + n * np.eye(n))[n // 2:, n // 2:]
+        b = rng.normal(size=n)
+        x, rc = eng.dense_solve(np.tril(a), b)
+        assert rc == 0
+        assert rel_err(a @ x, b) < 1e-9
+    # an exactly singular pivot is reported as FactorizationError (ba::FactorizationError = 4)
+    a = np.zeros((10, 10))
     _, rc = eng.dense_solve(a, np.ones(10))
     assert rc == 4
 
@@ -105,10 +115,8 @@ def test_reduced_system_and_step(oracle_lib, lm_dim, variant):
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_golden_fixtures(path):
     g = np.load(path)
-    if int(g["use_dogleg"]):
-        pytest.skip("dogleg fixture: covered by test_dogleg_matches_oracle")
     h = adjuster.BundleAdjuster(int(g["lm_dim"]), 6)
-    h.Init(hip_options())
+    h.Init(hip_options(use_dogleg=int(g["use_dogleg"])))
     h.AddCamera(g["cam_params"])
     h.add_poses(g["poses"], is_active=g["pose_active"])
     h.add_landmarks(g["landmarks"], g["lm_ref_pose"])
@@ -150,6 +158,31 @@ def test_gauss_newton_iterations_track_oracle(oracle_lib, lm_dim):
         assert o.LandmarkOutlierRatio(l) == h.LandmarkOutlierRatio(l)
 
 
+@pytest.mark.parametrize("lm_dim", [1, 3])
+@pytest.mark.parametrize("trust_region", [-1.0, 0.05, 1e3])
+def test_dogleg_matches_oracle(oracle_lib, lm_dim, trust_region):
+    """Dogleg branch (BundleAdjuster.cpp:850-1083): auto trust region, a tiny one (scaled
+    steepest descent / blended steps, inner-loop rejections) and a huge one (pure GN)."""
+    po = oracle_lib
+    sc = scene.make_scene(40, 120, 6, lm_dim=lm_dim, seed=21)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    o, h = both(po, sc, lm_dim, active=pa, use_dogleg=1, trust_region_size=trust_region)
+    for it in range(4):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        assert abs(so.trust_region_size - sh.trust_region_size) <= 1e-7 * abs(so.trust_region_size)
+        assert abs(so.pre_solve_norm - sh.pre_solve_norm) < 1e-8 * so.pre_solve_norm
+        assert abs(so.post_solve_norm - sh.post_solve_norm) < 1e-8 * so.post_solve_norm
+        assert abs(so.delta_norm - sh.delta_norm) < 1e-6 * max(so.delta_norm, 1e-12)
+    to, _, _ = o.poses()
+    th, _, _ = h.poses()
+    assert rel_err(th, to) < 1e-8
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-8
+
+
 def test_multi_iteration_solve_equals_repeated_single(oracle_lib):
     po = oracle_lib
     sc = scene.make_scene(40, 120, 6, lm_dim=1, seed=3)
@@ -178,6 +211,106 @@ def test_error_increase_is_rolled_back(oracle_lib):
     assert o.summary().result == h.summary().result
     th, _, _ = h.poses()
     assert rel_err(th, sc.poses) < 1e-12  # state restored exactly (snapshot buffer)
+
+
+# ---- pose-pose residuals: unary, binary, IMU ------------------------------------------------
+def _state_close(o, h, tol=1e-8):
+    to, vo, bo = o.poses()
+    th, vh, bh = h.poses()
+    assert rel_err(th, to) < tol
+    assert np.abs(vh - vo).max() <= tol * max(1.0, np.abs(vo).max())
+    assert np.abs(bh - bo).max() <= tol * max(1.0, np.abs(bo).max())
+
+
+@pytest.mark.parametrize("use_dogleg", [0, 1])
+def test_pose_graph_unary_binary(oracle_lib, use_dogleg):
+    """LmSize = 0 pose graph (the shape of applications/unary_binary_imu_test): GPS-like
+    unary priors with and without rotation, odometry-like binary constraints with full
+    covariances and weights."""
+    po = oracle_lib
+    rng = np.random.default_rng(41)
+    gt, _ = scene.trajectory(30)
+    init = gt.copy()
+    init[:, :3] += rng.normal(0, 0.05, (30, 3))
+    for i in range(30):
+        init[i] = po.exp_decoupled(init[i], np.concatenate([np.zeros(3), rng.normal(0, 0.02, 3)]))
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, use_dogleg=use_dogleg)),
+                      (adjuster.BundleAdjuster, hip_options(use_dogleg=use_dogleg))):
+        b = cls(0, 6)
+        b.Init(opts)
+        b.add_poses(init)
+        r2 = np.random.default_rng(42)
+        for i in range(0, 30, 3):
+            m = r2.normal(size=(6, 6))
+            cov = 1e-3 * (m @ m.T + 6 * np.eye(6))
+            prior = po.exp_decoupled(gt[i], r2.normal(0, 0.01, 6))
+            b.AddUnaryConstraint(i, prior, cov, bool(i % 2 == 0))
+        for i in range(29):
+            m = r2.normal(size=(6, 6))
+            cov = 1e-4 * (m @ m.T + 6 * np.eye(6))
+            t12 = po.se3_mul(po.se3_inv(gt[i]), gt[i + 1])
+            t12 = po.exp_decoupled(t12, r2.normal(0, 0.003, 6))
+            b.AddBinaryConstraint(i, i + 1, t12, cov, float(r2.uniform(0.5, 2.0)), bool(i % 5 != 0))
+        b.AddBinaryConstraint(0, 29, po.se3_mul(po.se3_inv(gt[0]), gt[29]))  # loop closure, identity cov
+        objs.append(b)
+    o, h = objs
+    for it in range(4):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        if so.delta_norm < 1e-9:
+            # converged: the accept test post <= pre is decided by the last bit of two
+            # equal sums, which no two implementations share
+            break
+        assert so.result == sh.result
+        if it == 0:
+            assert rel_err(h.S(), o.S()) < 1e-11
+            assert rel_err(h.rhs(), o.rhs()) < 1e-10
+        assert abs(so.unary_error - sh.unary_error) <= 1e-8 * max(so.unary_error, 1e-12)
+        assert abs(so.binary_error - sh.binary_error) <= 1e-8 * max(so.binary_error, 1e-12)
+        assert abs(so.delta_norm - sh.delta_norm) <= 1e-6 * max(so.delta_norm, 1e-12)
+    _state_close(o, h)
+
+
+@pytest.mark.parametrize("lm_dim,pose_dim", [(1, 15), (3, 15), (1, 9), (0, 15)])
+@pytest.mark.parametrize("use_dogleg", [0, 1])
+def test_visual_inertial(oracle_lib, lm_dim, pose_dim, use_dogleg):
+    """BASELINE.json configs[2] in miniature: reprojection + IMU pre-integration residuals,
+    velocities (and biases) in the state, gravity-axis gauge regularisation."""
+    po = oracle_lib
+    P = 30
+    sc = scene.make_scene(P, 80 if lm_dim else 1, 5, lm_dim=max(lm_dim, 1), seed=51)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, use_dogleg=use_dogleg)),
+                      (adjuster.BundleAdjuster, hip_options(use_dogleg=use_dogleg))):
+        b = cls(lm_dim, pose_dim)
+        b.Init(opts)
+        b.SetGravity(sc.gravity)
+        if lm_dim:
+            fill(b, sc)
+        else:
+            b.add_poses(sc.poses, v_w=sc.init_vel, b=sc.init_bias, time=sc.pose_time)
+            for i in range(0, P, 5):  # a single prior leaves cond(S) ~ 1e16: solver-dependent
+                b.AddUnaryConstraint(i, sc.gt_poses[i], 1e-4 * np.eye(6), True)
+        for i in range(P - 1):
+            b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+        objs.append(b)
+    o, h = objs
+    for it in range(3):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        if it == 0:
+            assert rel_err(h.S(), o.S()) < 1e-9
+            assert rel_err(h.rhs(), o.rhs()) < 1e-9
+        # cond(S) reaches 1e9-1e10 with velocities and biases in the state: the step agrees
+        # to ~cond * eps; north_star asks for 1e-6 relative
+        assert abs(so.inertial_error - sh.inertial_error) <= 1e-6 * max(so.inertial_error, 1e-12)
+        assert abs(so.proj_error - sh.proj_error) <= 1e-6 * max(so.proj_error, 1e-12)
+    _state_close(o, h, 1e-6)
 
 
 # ---- edge cases ---------------------------------------------------------------------------
