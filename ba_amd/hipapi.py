@@ -96,6 +96,16 @@ def lib():
                 "ba_amd: %s is missing — build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
                 % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 /
+        # libhsa-runtime64.  If the engine pulled in /opt/rocm's copies first, a later
+        # `import torch` would bring a second HSA runtime into the process and torch would
+        # see no GPU (measured on the MI355X box).  Importing torch first makes the engine
+        # bind to torch's runtime (same SONAME), so torch.distributed/RCCL and the engine
+        # share one device context.  C++ users without torch link /opt/rocm directly.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent: the engine uses the ROCm runtime it was linked with
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.ba_hip_last_error.restype = C.c_char_p
         _lib.ba_hip_num_pose_params.restype = C.c_uint32

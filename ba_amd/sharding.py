@@ -1,0 +1,110 @@
+"""Landmark sharding for multi-GPU runs.
+
+The reduced pose system is a sum of independent per-landmark terms
+(/root/reference/src/BundleAdjuster.cpp:409-485), so landmarks — with all their
+observations — are split into contiguous ranges, one per rank; poses, cameras and masks
+are replicated; pose-pose residuals (unary/binary/IMU) are added on rank 0 only.  Per
+iteration the engine asks for a cross-shard SUM of: the lower storage of S with its rhs
+row, the un-reduced rhs_p, a few scalars, and the selection histograms of the Huber median
+(doubles or uint64 counts).  This module provides the partition and two all-reduce hooks
+for ba_hip_set_allreduce: torch.distributed (RCCL on GPUs, gloo on CPU buffers) and an
+in-process hook for several engines driven by threads on one device (tests).
+"""
+import ctypes
+import threading
+
+import numpy as np
+
+
+def landmark_shards(obs_per_landmark, nranks):
+    """Contiguous landmark ranges [lo, hi) balanced by the Schur work  sum k(k+1)/2  of the
+    landmarks' track lengths k (not by count)."""
+    k = np.asarray(obs_per_landmark, dtype=np.float64)
+    work = np.concatenate([[0.0], np.cumsum(k * (k + 1) / 2.0)])
+    total = work[-1]
+    bounds = [0]
+    for r in range(1, nranks):
+        bounds.append(int(np.searchsorted(work, total * r / nranks, side="left")))
+    bounds.append(len(k))
+    bounds = np.maximum.accumulate(np.array(bounds))
+    return [(int(bounds[r]), int(bounds[r + 1])) for r in range(nranks)]
+
+
+class _DevArray:
+    """__cuda_array_interface__ view of a raw device pointer."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr,
+                                         "data": (ptr, False), "version": 2}
+
+
+def _host_view(ptr, count, dtype):
+    ctype = ctypes.c_double if dtype == 0 else ctypes.c_uint64
+    return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype)), shape=(count,))
+
+
+def torch_allreduce_hook(dist, device="cuda"):
+    """Hook (ptr, count, dtype) -> 0 summing over the torch.distributed default group.
+    device="cuda": ptr is device memory (backend nccl = RCCL over xGMI);
+    device="cpu": ptr is host memory (backend gloo; used by the CPU tests)."""
+    import torch
+
+    def fn(ptr, count, dtype):
+        try:
+            if device == "cuda":
+                t = torch.as_tensor(_DevArray(ptr, count, "<f8" if dtype == 0 else "<i8"), device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+            else:
+                a = _host_view(ptr, count, dtype)
+                t = torch.from_numpy(a.view(np.int64) if dtype == 1 else a)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return 0
+        except Exception as exc:  # the engine reports "allreduce hook failed"
+            import sys
+            print("allreduce hook:", exc, file=sys.stderr)
+            return 1
+    return fn
+
+
+class ThreadAllReduce:
+    """Sums buffers of `nranks` engines that live in one process and are driven by one
+    thread each (shards emulated on a single GPU)."""
+
+    def __init__(self, nranks):
+        import torch
+        self.torch = torch
+        self.n = nranks
+        self.barrier = threading.Barrier(nranks)
+        self.slots = [None] * nranks
+        self.failed = False
+
+    def hook(self, rank):
+        torch = self.torch
+
+        def fn(ptr, count, dtype):
+            try:
+                t = torch.as_tensor(_DevArray(ptr, count, "<f8" if dtype == 0 else "<i8"), device="cuda")
+                self.slots[rank] = t
+                self.barrier.wait()
+                if rank == 0:
+                    total = self.slots[0].clone()
+                    for r in range(1, self.n):  # fixed rank order: reproducible sums
+                        total += self.slots[r]
+                    self.total = total
+                    torch.cuda.synchronize()
+                self.barrier.wait()
+                t.copy_(self.total)
+                torch.cuda.synchronize()
+                self.barrier.wait()
+                return 0
+            except Exception as exc:
+                import sys
+                print("ThreadAllReduce:", exc, file=sys.stderr)
+                self.failed = True
+                try:
+                    self.barrier.abort()
+                except Exception:
+                    pass
+                return 1
+        return fn

@@ -32,31 +32,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ba_amd import hipapi, scene  # noqa: E402
+from ba_amd import hipapi, scene, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet FP64 matrix peak (not listed in the local guide)
-
-
-class _CudaArray:
-    """Minimal __cuda_array_interface__ holder so torch can view an engine buffer."""
-
-    def __init__(self, ptr, count, typestr):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr,
-                                         "data": (ptr, False), "version": 2}
-
-
-def make_allreduce(torch, dist):
-    def fn(ptr, count, dtype):
-        try:
-            t = torch.as_tensor(_CudaArray(ptr, count, "<f8" if dtype == 0 else "<i8"), device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-            return 0
-        except Exception as exc:  # surfaced by the engine as "allreduce hook failed"
-            print("allreduce hook:", exc, file=sys.stderr)
-            return 1
-    return fn
 
 
 def build_engine(sc, lm_dim, lo, hi, device, stream=None):
@@ -148,10 +127,10 @@ def main():
     sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=2)
     # landmark shards: contiguous, equal counts (every landmark has K residuals, so the
     # Schur work  sum k(k+1)/2  is balanced too)
-    lo, hi = (L * rank) // world, (L * (rank + 1)) // world
+    lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
     eng, n_obs_local = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
     if world > 1:
-        eng.set_allreduce(make_allreduce(torch, dist), rank, world)
+        eng.set_allreduce(sharding.torch_allreduce_hook(dist, "cuda"), rank, world)
 
     def barrier():
         if world > 1:

@@ -363,6 +363,86 @@ def test_poses_without_residuals_and_empty_landmarks(oracle_lib):
     assert h.S()[n - 1, n - 1] == 1e6
 
 
+# ---- landmark sharding on one device ------------------------------------------
+def _run_engine_steps(eng, iters, out, key):
+    try:
+        res = []
+        for _ in range(iters):
+            e0 = eng.linearize()
+            rc = eng.solve_gn()
+            nrm = eng.compose_step(0.0, 1.0)
+            pre = eng.eval_residuals()
+            eng.apply_step()
+            post = eng.eval_residuals()
+            if post.total() > pre.total():
+                eng.rollback()
+            res.append((rc, e0.proj_error, pre.total(), post.total(), nrm.step_p_norm, nrm.step_l_norm))
+        out[key] = res
+    except Exception as exc:  # surfaced by the assertions below
+        out[key] = exc
+
+
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_two_shards_equal_one(lm_dim):
+    """The same scene solved by ONE engine and by TWO engines holding half of the landmarks
+    each (threads + in-process all-reduce hook): S, rhs, Huber median, errors, steps and
+    the final state must agree — the 8-GPU path of bench.py, emulated on one GPU."""
+    import threading
+
+    from ba_amd import sharding
+    sc = scene.make_scene(40, 200, 6, lm_dim=lm_dim, seed=61)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    nsel = sc.obs_per_landmark + (1 if lm_dim == 1 else 0)
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    if lm_dim == 1:
+        keep[::nsel] = False
+
+    def make(lo, hi):
+        sel = keep & (sc.obs_lm >= lo) & (sc.obs_lm < hi)
+        eng = hipapi.Engine(lm_dim, 6)
+        eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+        eng.set_poses(sc.poses, is_active=pa)
+        eng.set_landmarks(sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi])
+        eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], sc.obs_lm[sel] - lo)
+        eng.finalize()
+        eng.begin_solve()
+        eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+        return eng
+
+    L = sc.num_landmarks
+    single = make(0, L)
+    out = {}
+    _run_engine_steps(single, 3, out, "single")
+    shards = sharding.landmark_shards(np.full(L, sc.obs_per_landmark), 2)
+    engs = [make(*shards[r]) for r in range(2)]
+    ar = sharding.ThreadAllReduce(2)
+    for r in range(2):
+        engs[r].set_allreduce(ar.hook(r), r, 2)
+    th = [threading.Thread(target=_run_engine_steps, args=(engs[r], 3, out, r)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not ar.failed
+    for k in ("single", 0, 1):
+        assert not isinstance(out[k], Exception), out[k]
+    for it in range(3):
+        a, b0, b1 = out["single"][it], out[0][it], out[1][it]
+        assert b0 == b1 or np.allclose(b0, b1, rtol=1e-12)  # both ranks see the same sums
+        assert a[0] == b0[0] == 0
+        for x, y in zip(a[1:], b0[1:]):
+            assert abs(x - y) <= 1e-9 * max(abs(x), 1e-12)
+    ps, _, _ = single.get_poses(sc.num_poses)
+    p0, _, _ = engs[0].get_poses(sc.num_poses)
+    p1, _, _ = engs[1].get_poses(sc.num_poses)
+    assert rel_err(p0, ps) < 1e-9 and np.array_equal(p0, p1)
+    for e_ in engs + [single]:
+        e_.end_solve()
+    lms = np.concatenate([engs[r].get_landmarks(shards[r][1] - shards[r][0]) for r in range(2)])
+    assert rel_err(lms, single.get_landmarks(L)) < 1e-9
+
+
 # ---- full-size properties (BASELINE.json configs[1]) ---------------------------------------
 def test_config2_size_properties():
     """1k poses / 100k landmarks / 1M residuals: size-independent properties —

@@ -194,3 +194,90 @@ def test_unary_and_binary_jacobians(oracle_lib):
     assert np.linalg.norm(ju - fu) < NORM_THRESHOLD
     assert np.linalg.norm(j1 - f1) < NORM_THRESHOLD
     assert np.linalg.norm(j2 - f2) < NORM_THRESHOLD
+
+
+def _imu_graph(po, p1, p2, meas, g, pose_dim=15):
+    ba = po.OracleBundleAdjuster(0, pose_dim)
+    o = po.default_options()
+    o.use_dogleg = 0
+    o.apply_results = 0
+    ba.Init(o)
+    ba.SetGravity(g)
+    ba.AddPose(p1[:7], True, 0.0, p1[7:10], p1[10:16])
+    ba.AddPose(p2[:7], True, 0.1, p2[7:10], p2[10:16])
+    ba.AddImuResidual(0, 1, meas)
+    ba.Solve(1)
+    return ba.imu_jacobians(0)
+
+
+def _perturb(po, p, j, eps):
+    q = p.copy()
+    if j < 6:
+        d = np.zeros(6)
+        d[j] = eps
+        q[:7] = po.exp_decoupled(p[:7], d)
+    else:
+        q[7 + (j - 6)] += eps  # v (3) then b (6) follow t,q in the 16-vector
+    return q
+
+
+@pytest.mark.parametrize("pose_dim", [9, 15])
+def test_imu_residual_jacobians(oracle_lib, pose_dim):
+    """_Test_dImuResidual_dX (BundleAdjusterTest.h:206-568) re-created: the 15x15 Jacobians
+    of the inertial residual w.r.t. both pose states against central differences of the
+    residual (RK4 pre-integration included), at the reference's 1e-3 norm threshold."""
+    po = oracle_lib
+    rng = np.random.default_rng(17)
+    g = np.array([0.0, 0.0, 9.8007])
+    p1 = np.zeros(16)
+    p1[:7] = np.concatenate([rng.normal(0, 2, 3), po.so3_exp(rng.normal(0, 0.6, 3))])
+    p1[7:10] = rng.normal(0, 1, 3)
+    p1[10:16] = rng.normal(0, 0.01, 6) if pose_dim == 15 else 0.0
+    n = 11
+    meas = np.zeros((n, 7))
+    meas[:, :3] = rng.normal(0, 0.3, (n, 3))
+    meas[:, 3:6] = rng.normal(0, 1, (n, 3)) + np.array([0, 0, 9.8])
+    meas[:, 6] = np.arange(n) * 0.01
+    t_int, v_int = po.integrate(p1[:7], p1[7:10], meas, p1[10:13], p1[13:16], g)
+    p2 = np.zeros(16)
+    p2[:7] = po.exp_decoupled(t_int, rng.normal(0, 0.02, 6))
+    p2[7:10] = v_int + rng.normal(0, 0.02, 3)
+    p2[10:16] = p1[10:16] + (rng.normal(0, 0.001, 6) if pose_dim == 15 else 0.0)
+    dz1, dz2, _, r0 = _imu_graph(po, p1, p2, meas, g, pose_dim)
+    fd1, fd2 = np.zeros((15, 15)), np.zeros((15, 15))
+    for j in range(pose_dim):
+        eps = 1e-6
+        rp = _imu_graph(po, _perturb(po, p1, j, eps), p2, meas, g, pose_dim)[3]
+        rm = _imu_graph(po, _perturb(po, p1, j, -eps), p2, meas, g, pose_dim)[3]
+        fd1[:, j] = (rp - rm) / (2 * eps)
+        rp = _imu_graph(po, p1, _perturb(po, p2, j, eps), meas, g, pose_dim)[3]
+        rm = _imu_graph(po, p1, _perturb(po, p2, j, -eps), meas, g, pose_dim)[3]
+        fd2[:, j] = (rp - rm) / (2 * eps)
+    assert np.abs(dz1).max() > 0.5 and np.abs(dz2).max() > 0.5
+    assert np.linalg.norm(dz1[:pose_dim, :pose_dim] - fd1[:pose_dim, :pose_dim]) < NORM_THRESHOLD * (1 + np.linalg.norm(fd1))
+    assert np.linalg.norm(dz2[:pose_dim, :pose_dim] - fd2[:pose_dim, :pose_dim]) < NORM_THRESHOLD * (1 + np.linalg.norm(fd2))
+
+
+def test_imu_integration_bias_jacobian(oracle_lib):
+    """_Test_IntegrateResidual_BiasJacobian (Types.h:741ff) re-created: d(pose,vel)/d(bias)
+    of the RK4 pre-integration against central differences."""
+    po = oracle_lib
+    rng = np.random.default_rng(19)
+    g = np.array([0.0, 0.0, 9.8007])
+    t0 = np.concatenate([rng.normal(0, 2, 3), po.so3_exp(rng.normal(0, 0.6, 3))])
+    v0 = rng.normal(0, 1, 3)
+    n = 11
+    meas = np.zeros((n, 7))
+    meas[:, :3] = rng.normal(0, 0.3, (n, 3))
+    meas[:, 3:6] = rng.normal(0, 1, (n, 3)) + np.array([0, 0, 9.8])
+    meas[:, 6] = np.arange(n) * 0.01
+    b = rng.normal(0, 0.01, 6)
+    _, _, db, _ = po.integrate(t0, v0, meas, b[:3], b[3:], g, r6=np.ones(6) * 1e-6, jac=True)
+    fd = np.zeros((10, 6))
+    for j in range(6):
+        e = np.zeros(6)
+        e[j] = 1e-6
+        tp, vp = po.integrate(t0, v0, meas, (b + e)[:3], (b + e)[3:], g)
+        tm, vm = po.integrate(t0, v0, meas, (b - e)[:3], (b - e)[3:], g)
+        fd[:, j] = (np.concatenate([tp, vp]) - np.concatenate([tm, vm])) / 2e-6
+    assert np.linalg.norm(db - fd) < NORM_THRESHOLD * (1 + np.linalg.norm(fd))
