@@ -54,7 +54,7 @@ struct SolutionSummary {  // reference BundleAdjuster.h:48-70
   Scalar pre_solve_norm = 0;
   Scalar post_solve_norm = 0;
   OptimizationResult result = Success;
-  bool IsResultGood() { return (result != SolverError) && (result != FactorizationError); }
+  bool IsResultGood() const { return (result != SolverError) && (result != FactorizationError); }
 };
 
 template <typename Scalar = double>

@@ -363,6 +363,17 @@ def test_poses_without_residuals_and_empty_landmarks(oracle_lib):
     assert h.S()[n - 1, n - 1] == 1e6
 
 
+# ---- the C++ host class used directly by a C++ application ---------------------------------
+def test_cpp_application_runs_on_the_engine():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ba_amd", "lib", "visual_ba_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "proj error" in r.stdout
+
+
 # ---- landmark sharding on one device ------------------------------------------
 def _run_engine_steps(eng, iters, out, key):
     try:
