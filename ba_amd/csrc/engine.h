@@ -75,6 +75,8 @@ struct Structure {
 struct Engine {
   int lm_dim = 1, pose_dim = 6, device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // bulk trailing updates of the factorisation (look-ahead)
+  std::vector<hipEvent_t> ev_panel, ev_bulk;
   bool own_stream = false;
   std::string err;
   ba_hip_options opt;
@@ -150,16 +152,16 @@ struct Engine {
   bool profiling = false;
   ba_hip_kernel_stats kstats = {};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_syrk, ev_gather, ev_landmarks;
-  void prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+  void prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s = nullptr) {
     if (!profiling) return;
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, stream);
+    (void)hipEventRecord(a, s ? s : stream);
     v.push_back({a, b});
   }
-  void prof_end(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v) {
+  void prof_end(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s = nullptr) {
     if (!profiling) return;
-    (void)hipEventRecord(v.back().second, stream);
+    (void)hipEventRecord(v.back().second, s ? s : stream);
   }
   void prof_collect();
 

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -496,9 +497,28 @@ int ba_hip_create(int lm_dim, int pose_dim, int device, void* stream, ba_hip_eng
   if (stream) {
     e->stream = (hipStream_t)stream;
   } else {
-    err = hipStreamCreate(&e->stream);
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically smallest = highest priority
+    err = hipStreamCreateWithPriority(&e->stream, hipStreamDefault, hi);
     if (err != hipSuccess) { delete e; return -(int)err; }
     e->own_stream = true;
+  }
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // Second stream for the bulk trailing updates of the dense factorisation: lowest
+    // priority, so the serial panel chain on the main stream wins the dispatch.  (CU masks
+    // were measured — r01: every partial mask was slower than none; BA_HIP_BULK_CU_MASK
+    // keeps the experiment reachable.)
+    const char* env = getenv("BA_HIP_BULK_CU_MASK");
+    if (env) {
+      uint32_t mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = (uint32_t)strtoul(env, nullptr, 16);
+      err = hipExtStreamCreateWithCUMask(&e->stream2, 8, mask);
+      if (err != hipSuccess) { (void)hipGetLastError(); e->stream2 = nullptr; }
+    }
+    if (!e->stream2) err = hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo);
+    if (err != hipSuccess) { delete e; return -(int)err; }
   }
   *out = reinterpret_cast<ba_hip_engine*>(e);
   return 0;
@@ -528,6 +548,9 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(pp_h); REL(pp_g); REL(pp_dz); REL(pp_info); REL(pp_err); REL(pp_ptr); REL(pp_res_p1);
   REL(pp_res_p2); REL(pp_ent);
 #undef REL
+  for (hipEvent_t ev : e->ev_panel) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->ev_bulk) (void)hipEventDestroy(ev);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
   delete e;
 }

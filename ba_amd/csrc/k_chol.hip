@@ -27,6 +27,7 @@
 // the diagonal); a non-positive pivot raises the status flag (-> FactorizationError,
 // BundleAdjuster.cpp:756-759).
 #include "engine.h"
+#include <cstdlib>
 
 namespace bae {
 
@@ -113,19 +114,24 @@ k_potrf64(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ 
 __global__ void __launch_bounds__(64)
 k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
          const double* __restrict__ dsgn, double* __restrict__ Apanel, uint32_t ld,
-         uint32_t nrowblk) {
+         uint32_t nrowblk, int inverse_mode) {
   __shared__ double Xs[NB][LDP];
   __shared__ __attribute__((aligned(16))) double LsT[NB][LDT];  // LsT[p][j] = L[j][p] / L[j][j]
   __shared__ double dv[NB];
   const int lane = threadIdx.x;
   const int rows = (blockIdx.x + 1 == nrowblk) ? 1 : NB;  // the last block is the rhs row
-  double* Aik = Apanel + ((size_t)blockIdx.x * NB) * ld;
+  // inverse_mode: block b inverts diagonal tile b — the "panel" is the identity and the
+  // result X = L_bb^-T goes to a dense 64x64 slot (used by the backward substitution)
+  const size_t tile = (size_t)blockIdx.x * NB;
+  if (inverse_mode) { Lkk += tile * ld + tile; dinv += tile; dsgn += tile; }
+  double* Aik = inverse_mode ? Apanel + tile * NB : Apanel + tile * ld;
+  const uint32_t ldo = inverse_mode ? NB : ld;
   {
     double ta[NB], tl[NB];  // all loads in flight before the first use
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      ta[r] = (r < rows) ? Aik[(size_t)r * ld + lane] : 0.0;
-      tl[r] = Lkk[(size_t)r * ld + lane];
+      ta[r] = inverse_mode ? (r == lane ? 1.0 : 0.0) : ((r < rows) ? Aik[(size_t)r * ld + lane] : 0.0);
+      tl[r] = (lane <= r) ? Lkk[(size_t)r * ld + lane] : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
@@ -133,10 +139,11 @@ k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
       // row r of L, element (r, lane), pre-scaled by 1/L[r][r]: with t_j = s_j / L[j][j]
       // the substitution needs no multiply on its serial chain (x_p = t_p)
       // (column sign d_lane, row scale d_r / L[r][r]:  x_j = d_j (a_j - sum x_p d_p L[j][p]) / L[j][j])
-      LsT[lane][r] = tl[r] * dinv[r] * dsgn[r] * dsgn[lane];
+      // inverse_mode solves X L^T = I (no D): plain L^-T for the backward substitution
+      LsT[lane][r] = tl[r] * dinv[r] * (inverse_mode ? 1.0 : dsgn[r] * dsgn[lane]);
     }
   }
-  dv[lane] = dinv[lane] * dsgn[lane];
+  dv[lane] = dinv[lane] * (inverse_mode ? 1.0 : dsgn[lane]);
   __syncthreads();
   double s[NB];
 #pragma unroll
@@ -165,7 +172,196 @@ k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < NB; ++r)
-    if (r < rows) Aik[(size_t)r * ld + lane] = Xs[r][lane];
+    if (r < rows) Aik[(size_t)r * ldo + lane] = Xs[r][lane];
+}
+
+// ---------------------------------------------------------------------------------
+// One 64-column step of the panel factorisation in ONE kernel (the serial chain of the
+// solver: 94 of these at n = 6000):
+//   block 0            factorises the diagonal tile jj, stores the pivot signs and
+//                      L_jj^-T (for the backward substitution);
+//   blocks 1 .. m      row tile jj + b (the last one is the rhs row): X = A L_jj^-T D.
+// EVERY block factorises the (same) diagonal tile itself in LDS — redundant flops instead
+// of a second launch and a trip through HBM on the critical path — while the global loads
+// of its own rows are in flight.  The factorisation works on 16-column panels: the panel
+// is factorised by one wavefront with a row per lane (16 columns in registers, pivots and
+// the 15 in-panel multipliers broadcast by v_readlane), the rest of the tile is updated on
+// the FP64 matrix cores straight out of LDS.  M = L^-1 follows from the four 16x16
+// diagonal inverses (column per lane, 4 blocks side by side) and 16 small MFMA products;
+// the triangular solve of the block's rows is then one 64x64x64 MFMA product with D M.
+__device__ __forceinline__ double4_t mm16(const double* __restrict__ Ab, const double* __restrict__ Bb,
+                                          double asign, int li, int lk, double4_t acc) {
+  // acc += asign * A(16x16 row-major at Ab) * B(16x16 row-major at Bb), LDS stride LDT
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const double a = asign * Ab[li * LDT + 4 * ks + lk];
+    const double b = Bb[(4 * ks + lk) * LDT + li];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void store16(double* __restrict__ Cb, int li, int lk, double4_t acc) {
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) Cb[(lk + 4 * reg) * LDT + li] = acc[reg];
+}
+
+__global__ void __launch_bounds__(256)
+k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
+          double* __restrict__ dsgn_out, double* __restrict__ linvT_out, int* __restrict__ status) {
+  __shared__ double T[NB][LDT];   // the diagonal tile: A_jj -> L_jj (upper part zero)
+  __shared__ double Mi[NB][LDT];  // M = L_jj^-1
+  __shared__ double dv[NB];       // 1 / L[j][j]
+  __shared__ double sg[NB];       // pivot signs d_j
+  __shared__ int bad_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const uint32_t i = jj + blockIdx.x;          // row tile of this block (jj: the diagonal)
+  const int rows = (i == nblk) ? 1 : NB;
+  const double* Akk = A + ((size_t)jj * NB) * ld + (size_t)jj * NB;
+  double* Aik = A + ((size_t)i * NB) * ld + (size_t)jj * NB;
+  // this wave's A fragments (rows rb.., all 64 k) straight into the MFMA operand layout;
+  // the loads stay in flight during the factorisation
+  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
+  double af[2][16];
+  if (blockIdx.x != 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int r = rb + 16 * t + li;
+        af[t][ks] = (r < rows) ? Aik[(size_t)r * ld + 4 * ks + lk] : 0.0;
+      }
+  }
+  for (int idx = tid; idx < NB * (NB / 2); idx += 256) {
+    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
+    double2 v = make_double2(0.0, 0.0);
+    if (c2 <= r) v = *reinterpret_cast<const double2*>(Akk + (size_t)r * ld + c2);
+    T[r][c2] = v.x;
+    T[r][c2 + 1] = (c2 + 1 <= r) ? v.y : 0.0;
+    Mi[r][c2] = 0.0;
+    Mi[r][c2 + 1] = 0.0;
+  }
+  if (tid == 0) bad_s = 0;
+  __syncthreads();
+  if (wave == 0) {
+    int bad = 0;
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+      const int c0 = 16 * pb;
+      double p[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) p[c] = (c0 + c <= lane) ? T[lane][c0 + c] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int J = c0 + j;
+        const double d = readlane_f64(p[j], J);
+        const double ad = fabs(d);
+        const bool ok = (ad > 0.0) && (ad < 1e300);  // zero / NaN / Inf pivot
+        if (!ok) bad = 1;
+        const double sgn = d < 0.0 ? -1.0 : 1.0;
+        const double dd = ok ? ad : 1.0;
+        // y ~ 1/sqrt(dd): hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 dd y^2)
+        double y = __builtin_amdgcn_rsq(dd);
+        y = y * fma(-0.5 * dd * y, y, 1.5);
+        y = y * fma(-0.5 * dd * y, y, 1.5);
+        p[j] *= y * sgn;                       // rows below: L[r][J] = d_J A[r][J] / sqrt|d|
+        if (lane == J) { p[j] = fabs(p[j]); dv[J] = y; sg[J] = sgn; }  // L[J][J] = sqrt|d|
+        const double sa = sgn * p[j];
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) p[c] -= sa * readlane_f64(p[j], c0 + c);  // d_J L[r][J] L[c][J]
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) T[lane][c0 + c] = (c0 + c <= lane) ? p[c] : 0.0;
+      // trailing 16x16 blocks (rbk, cbk), pb < cbk <= rbk:  C -= L_rbk,pb D L_cbk,pb^T
+#pragma unroll
+      for (int rbk = pb + 1; rbk < 4; ++rbk)
+#pragma unroll
+        for (int cbk = pb + 1; cbk <= rbk; ++cbk) {
+          double4_t acc;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[reg] = T[16 * rbk + lk + 4 * reg][16 * cbk + li];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int k = c0 + 4 * ks + lk;
+            const double a = T[16 * rbk + li][k];
+            const double b = -sg[k] * T[16 * cbk + li][k];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) T[16 * rbk + lk + 4 * reg][16 * cbk + li] = acc[reg];
+        }
+    }
+    if (bad) bad_s = 1;
+    // diagonal 16x16 inverses, lane = (block b, column c): forward substitution L x = e_c
+    {
+      const int base = 16 * lk, c = li;
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double sacc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) sacc -= T[base + r][base + k] * x[k];
+        x[r] = sacc * dv[base + r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Mi[base + r][base + c] = (r >= c) ? x[r] : 0.0;
+    }
+    // off-diagonal blocks by distance from the diagonal:
+    //   M_ij = -M_ii (sum_{k = j}^{i-1} L_ik M_kj)
+#pragma unroll
+    for (int dist = 1; dist < 4; ++dist)
+#pragma unroll
+      for (int bi = dist; bi < 4; ++bi) {
+        const int bj = bi - dist;
+        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = bj; k < bi; ++k) acc = mm16(&T[16 * bi][16 * k], &Mi[16 * k][16 * bj], 1.0, li, lk, acc);
+        store16(&Mi[16 * bi][16 * bj], li, lk, acc);
+        double4_t acc2 = (double4_t){0.0, 0.0, 0.0, 0.0};
+        acc2 = mm16(&Mi[16 * bi][16 * bi], &Mi[16 * bi][16 * bj], -1.0, li, lk, acc2);
+        store16(&Mi[16 * bi][16 * bj], li, lk, acc2);
+      }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    // the pivot signs and L^-T (linvT[r][c] = M[c][r]).  L_jj itself is NOT written back:
+    // the other blocks of this launch may still be reading A_jj, and nothing downstream
+    // needs the diagonal factor tile (the backward substitution uses L_jj^-T).
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+      const int r = idx >> 6, c = idx & 63;
+      linvT_out[(size_t)jj * NB * NB + idx] = Mi[c][r];
+    }
+    if (tid < NB) dsgn_out[(size_t)jj * NB + tid] = sg[tid];
+    if (tid == 0 && bad_s) atomicExch(status, 1);
+    return;
+  }
+  // X = A (D M)^T:  X[r][c] = d_c sum_{k <= c} A[r][k] M[c][k]
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const double s0 = sg[cb + li], s1 = sg[cb + 16 + li];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const double b0 = s0 * Mi[cb + li][4 * ks + lk];
+    const double b1 = s1 * Mi[cb + 16 + li][4 * ks + lk];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][ks], b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][ks], b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][ks], b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][ks], b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        const int cc = cb + 16 * tj + li;
+        if (r < rows) Aik[(size_t)r * ld + cc] = acc[ti][tj][reg];
+      }
 }
 
 // ---------------------------------------------------------------------------------
@@ -217,11 +413,17 @@ __device__ __forceinline__ void load_tile_signed(double (*T)[LDT], const double*
 // rhs row) with the tile columns [kb0, kb1):
 //     A_ic -= sum_kb A_i,kb * A_c,kb^T
 // grid = (nblk - c0 + 1, number of tile columns); blockIdx.x counts rows from c.
+// LDSPAD > 0 inflates the LDS footprint so that only ONE workgroup fits per CU: the bulk
+// updates running beside the serial panel factorisation then always leave LDS, wave slots
+// and issue bandwidth for the critical-path kernels on every CU.
+template <int LDSPAD>
 __global__ void __launch_bounds__(256)
 k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
          uint32_t kb1, const double* __restrict__ dsgn) {
   __shared__ double X[NB][LDT];
   __shared__ double Y[NB][LDT];
+  __shared__ double pad_[LDSPAD > 0 ? LDSPAD : 1];
+  if (LDSPAD > 0 && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the array allocated
   const uint32_t c = c0 + blockIdx.y;
   const uint32_t i = c + blockIdx.x;
   if (i > nblk) return;
@@ -256,43 +458,133 @@ k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32
       }
 }
 
+// ---------------------------------------------------------------------------------
+// Trailing update with 128x128 output tiles (the bulk of the n^3/3 flops):
+//     A[R, C] -= sum_{k in [kb0*64, kb1*64)} A[R, k] d_k A[C, k]^T
+// for the lower-triangular region right of a panel: block columns >= c0 (c0 even), block
+// rows >= column, the rhs row included.  4 waves, each owns a 64x64 quadrant as 4x4 MFMA
+// tiles (v_mfma_f64_16x16x4_f64); K is consumed in chunks of 32 staged through LDS, the
+// next chunk's global loads are issued before the current chunk's MFMAs (register double
+// buffering), so HBM/L2 latency overlaps the matrix pipe.  Versus 64x64 tiles this halves
+// the operand traffic per flop (16 flop per operand byte at K = 32).
+static const int KC = 32;
+static const int LDK = KC + 2;
+
+__global__ void __launch_bounds__(256)
+k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
+            uint32_t kb1, const double* __restrict__ dsgn) {
+  __shared__ double X[128][LDK];
+  __shared__ double Y[128][LDK];
+  const uint32_t trows = (nblk + 1 - c0 + 1) / 2;   // 128-row tiles incl. the rhs row
+  const uint32_t ty = blockIdx.y, tx = blockIdx.x + ty;
+  if (tx >= trows) return;
+  const uint32_t n_pad = nblk * NB;
+  const uint32_t row0 = (c0 + 2 * tx) * NB, col0 = (c0 + 2 * ty) * NB;  // global indices
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int rb = 64 * (wave >> 1), cb = 64 * (wave & 1);
+  double4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // staging: thread t moves 8 double2 of X and 8 of Y per chunk: row = (t + 256 u) / 16
+  const int sr = tid >> 4, sc = (tid & 15) * 2;
+  double2 px[8], py[8];
+  const uint32_t k_begin = kb0 * NB, k_end = kb1 * NB;
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t r = sr + 16 * u;
+      const uint32_t gr = row0 + r, gc = col0 + r;  // X row / Y row (a column block row)
+      px[u] = (gr <= n_pad) ? *reinterpret_cast<const double2*>(A + (size_t)gr * ld + k0 + sc)
+                            : make_double2(0.0, 0.0);
+      py[u] = (gc < n_pad) ? *reinterpret_cast<const double2*>(A + (size_t)gc * ld + k0 + sc)
+                           : make_double2(0.0, 0.0);
+    }
+  };
+  auto sstore = [&](uint32_t k0) {
+    const double s0 = dsgn[k0 + sc], s1 = dsgn[k0 + sc + 1];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = sr + 16 * u;
+      X[r][sc] = px[u].x; X[r][sc + 1] = px[u].y;
+      Y[r][sc] = py[u].x * s0; Y[r][sc + 1] = py[u].y * s1;
+    }
+  };
+  gload(k_begin);
+  sstore(k_begin);
+  __syncthreads();
+  for (uint32_t k0 = k_begin; k0 < k_end; k0 += KC) {
+    const bool more = k0 + KC < k_end;
+    if (more) gload(k0 + KC);
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = X[rb + 16 * t + li][kk + lk];
+        b[t] = Y[cb + 16 * t + li][kk + lk];
+      }
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      sstore(k0 + KC);
+      __syncthreads();
+    }
+  }
+  // epilogue: lower-triangular part only (64-block granularity, then element-wise on the
+  // diagonal blocks), rows up to the rhs row, columns inside the matrix
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const uint32_t gr = row0 + rb + 16 * ti + (lane >> 4) + 4 * reg;
+        const uint32_t gc = col0 + cb + 16 * tj + (lane & 15);
+        if (gr <= n_pad && gc < n_pad && (gc <= gr || gr == n_pad))
+          A[(size_t)gr * ld + gc] -= acc[ti][tj][reg];
+      }
+}
+
 // Backward substitution, block row i (from the last to the first):
-//   L_ii^T x_i = y_i ;  y[0 : i*NB] -= L[i-block, 0:i*NB]^T x_i
-// y lives in the rhs row of A.  Wave 0 of every workgroup solves the 64x64 triangular
-// system (column sweep, pivots broadcast by readlane); then each thread updates one
-// column.  Workgroup 0 also stores x_i.
+//   x_i = L_ii^-T y_i ;  y[0 : i*NB] -= L[i-block, 0:i*NB]^T x_i
+// y lives in the rhs row of A.  linvT[i] holds L_ii^-T (row-major), so x_i is a 64x64
+// mat-vec (4 partial sums per row, fixed order); then each thread updates one column.
+// Workgroup 0 also stores x_i.
 __global__ void __launch_bounds__(256)
 k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
-           const double* __restrict__ dinv, double* __restrict__ x) {
-  __shared__ double Ls[NB][LDP];
+           const double* __restrict__ linvT, double* __restrict__ x) {
   __shared__ double xi[NB];
+  __shared__ double part[4][NB];
   const int tid = threadIdx.x;
-  const double* Aii = A + ((size_t)i * NB) * ld + (size_t)i * NB;
+  const double* y = A + ((size_t)nblk * NB) * ld + (size_t)i * NB;
   {
-    double tmp[16];
+    const int r = tid & 63, q = tid >> 6;
+    const double* Xr = linvT + (size_t)i * NB * NB + (size_t)r * NB;
+    double s = 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) tmp[u] = Aii[(size_t)(4 * u + (tid >> 6)) * ld + (tid & 63)];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) Ls[4 * u + (tid >> 6)][tid & 63] = tmp[u];
+    for (int c = q * 16; c < q * 16 + 16; ++c) s += Xr[c] * y[c];
+    part[q][r] = s;
   }
   __syncthreads();
   if (tid < NB) {
-    double yv = A[((size_t)nblk * NB) * ld + (size_t)i * NB + tid];
-    // for j = 63..0: x_j = y_j / L[j][j]; y_r -= L[j][r] x_j for r < j
-    for (int j = NB - 1; j >= 0; --j) {
-      const double xj = readlane_f64(yv, j) * dinv[(size_t)i * NB + j];
-      if (tid == j) yv = xj;
-      else if (tid < j) yv -= Ls[j][tid] * xj;
-    }
-    xi[tid] = yv;
-    if (blockIdx.x == 0) x[(size_t)i * NB + tid] = yv;
+    const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    xi[tid] = v;
+    if (blockIdx.x == 0) x[(size_t)i * NB + tid] = v;
   }
   __syncthreads();
   const uint32_t col = blockIdx.x * 256 + tid;
   if (col < i * NB) {
     const double* Li = A + ((size_t)i * NB) * ld + col;
     double s = 0.0;
-#pragma unroll 8
+#pragma unroll 16
     for (int r = 0; r < NB; ++r) s += Li[(size_t)r * ld] * xi[r];
     A[((size_t)nblk * NB) * ld + col] -= s;
   }
@@ -303,48 +595,102 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status) {
   (void)n;
   const uint32_t nblk = ld / NB;
-  BAE_HIP(e->invdiag.alloc((size_t)2 * nblk * NB));  // 1 / diag(L), then the pivot signs
-  double* dsgn = e->invdiag.p + (size_t)nblk * NB;
-  BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), e->stream));
-  for (uint32_t J = 0; J < nblk; J += KOUT) {
+  BAE_HIP(e->invdiag.alloc((size_t)2 * nblk * NB + (size_t)nblk * NB * NB));
+  double* dsgn = e->invdiag.p + (size_t)nblk * NB;            // pivot signs
+  double* linvT = e->invdiag.p + (size_t)2 * nblk * NB;       // inverse-transposed diagonal tiles
+  static const bool no_lookahead = getenv("BA_HIP_NO_LOOKAHEAD") != nullptr;  // A/B switches
+  static const bool use64 = getenv("BA_HIP_UPDATE128") == nullptr;  // 64x64 tiles measured faster (r01)
+  static const bool old_panel = getenv("BA_HIP_OLD_PANEL") != nullptr;
+  static const bool one_per_cu = getenv("BA_HIP_BULK_ONE_PER_CU") != nullptr;
+  hipStream_t s0 = e->stream, s1 = no_lookahead ? e->stream : e->stream2;
+  const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
+  while (e->ev_panel.size() < npanels) {
+    hipEvent_t a, b;
+    BAE_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    BAE_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    e->ev_panel.push_back(a);
+    e->ev_bulk.push_back(b);
+  }
+  BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), s0));
+  // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
+  // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
+  // overlapping the serial factorisation of the next panel.
+  int prev_bulk = -1;  // index of the last recorded ev_bulk
+  uint32_t pj = 0;
+  for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
     const uint32_t Jend = J + KOUT < nblk ? J + KOUT : nblk;
     for (uint32_t jj = J; jj < Jend; ++jj) {
-      hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, e->stream, dA, ld, jj, e->invdiag.p,
-                         dsgn, e->flags.p);
-      hipLaunchKernelGGL(k_trsm64, dim3(nblk - jj), dim3(64), 0, e->stream,
-                         (const double*)(dA + ((size_t)jj * NB) * ld + (size_t)jj * NB),
-                         (const double*)(e->invdiag.p + (size_t)jj * NB),
-                         (const double*)(dsgn + (size_t)jj * NB),
-                         dA + ((size_t)(jj + 1) * NB) * ld + (size_t)jj * NB, ld, nblk - jj);
+      if (old_panel) {
+        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s0, dA, ld, jj, e->invdiag.p, dsgn,
+                           e->flags.p);
+        hipLaunchKernelGGL(k_trsm64, dim3(nblk - jj), dim3(64), 0, s0,
+                           (const double*)(dA + ((size_t)jj * NB) * ld + (size_t)jj * NB),
+                           (const double*)(e->invdiag.p + (size_t)jj * NB),
+                           (const double*)(dsgn + (size_t)jj * NB),
+                           dA + ((size_t)(jj + 1) * NB) * ld + (size_t)jj * NB, ld, nblk - jj, 0);
+      } else {
+        hipLaunchKernelGGL(k_panel64, dim3(nblk - jj + 1), dim3(256), 0, s0, dA, ld, jj, nblk, dsgn,
+                           linvT, e->flags.p);
+      }
       if (jj + 1 < Jend) {
         // in-panel update of the panel's remaining tile columns with tile column jj
-        hipLaunchKernelGGL(k_update, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0,
-                           e->stream, dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
+        hipLaunchKernelGGL(k_update<0>, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
+                           dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
       }
     }
-    if (Jend < nblk) {
-      // trailing update right of the panel, K = 64 * (Jend - J)
-      e->prof_begin(e->ev_syrk);
-      hipLaunchKernelGGL(k_update, dim3(nblk - Jend + 1, nblk - Jend), dim3(256), 0, e->stream, dA,
-                         ld, nblk, Jend, J, Jend, (const double*)dsgn);
-      e->prof_end(e->ev_syrk);
+    if (Jend >= nblk) break;
+    BAE_HIP(hipEventRecord(e->ev_panel[pj], s0));
+    const uint32_t a_end = Jend + KOUT < nblk ? Jend + KOUT : nblk;  // columns of the next panel
+    // (a) next panel's columns: needs every earlier bulk update of those columns
+    if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
+    if (use64) {
+      hipLaunchKernelGGL(k_update<0>, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld, nblk,
+                         Jend, J, Jend, (const double*)dsgn);
+    } else {
+      const uint32_t trows = (nblk + 1 - Jend + 1) / 2, tcols = (a_end - Jend + 1) / 2;
+      hipLaunchKernelGGL(k_update128, dim3(trows, tcols), dim3(256), 0, s0, dA, ld, nblk, Jend, J,
+                         Jend, (const double*)dsgn);
+    }
+    // (b) the rest, concurrently with the next panel's factorisation
+    if (a_end < nblk) {
+      BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
+      e->prof_begin(e->ev_syrk, s1);
+      if (use64) {
+        if (one_per_cu)
+          hipLaunchKernelGGL(k_update<2048>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
+                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
+        else
+          hipLaunchKernelGGL(k_update<0>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
+                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
+      } else {
+        const uint32_t trows = (nblk + 1 - a_end + 1) / 2, tcols = (nblk - a_end + 1) / 2;
+        hipLaunchKernelGGL(k_update128, dim3(trows, tcols), dim3(256), 0, s1, dA, ld, nblk, a_end, J,
+                           Jend, (const double*)dsgn);
+      }
+      e->prof_end(e->ev_syrk, s1);
+      BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
+      prev_bulk = (int)pj;
       if (e->profiling) {
-        const double m = (double)(nblk - Jend);
+        const double m = (double)(nblk - a_end);
         e->kstats.syrk_flops += (m * (m + 1) / 2 + m) * 2.0 * NB * NB * NB * (Jend - J);
       }
     }
   }
   BAE_HIP(hipGetLastError());
+  // inverse-transposed diagonal tiles (all in parallel): X L_ii^T = I  ->  X = L_ii^-T
+  if (old_panel)
+    hipLaunchKernelGGL(k_trsm64, dim3(nblk), dim3(64), 0, s0, (const double*)dA,
+                       (const double*)e->invdiag.p, (const double*)dsgn, linvT, ld, nblk + 1, 1);
   for (uint32_t ii = nblk; ii-- > 0;) {
     const uint32_t cols = ii * NB;
     const uint32_t grid = cols == 0 ? 1 : (cols + 255) / 256;
-    hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, e->stream, dA, ld, ii, nblk,
-                       (const double*)e->invdiag.p, dx);
+    hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, s0, dA, ld, ii, nblk,
+                       (const double*)linvT, dx);
   }
   BAE_HIP(hipGetLastError());
   int st = 0;
-  BAE_HIP(hipMemcpyAsync(&st, e->flags.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  BAE_HIP(hipStreamSynchronize(e->stream));
+  BAE_HIP(hipMemcpyAsync(&st, e->flags.p, sizeof(int), hipMemcpyDeviceToHost, s0));
+  BAE_HIP(hipStreamSynchronize(s0));
   *status = st;
   return 0;
 }
