@@ -185,67 +185,75 @@ k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
 // of a second launch and a trip through HBM on the critical path — while the global loads
 // of its own rows are in flight.  The factorisation works on 16-column panels: the panel
 // is factorised by one wavefront with a row per lane (16 columns in registers, pivots and
-// the 15 in-panel multipliers broadcast by v_readlane), the rest of the tile is updated on
-// the FP64 matrix cores straight out of LDS.  M = L^-1 follows from the four 16x16
-// diagonal inverses (column per lane, 4 blocks side by side) and 16 small MFMA products;
-// the triangular solve of the block's rows is then one 64x64x64 MFMA product with D M.
-__device__ __forceinline__ double4_t mm16(const double* __restrict__ Ab, const double* __restrict__ Bb,
-                                          double asign, int li, int lk, double4_t acc) {
-  // acc += asign * A(16x16 row-major at Ab) * B(16x16 row-major at Bb), LDS stride LDT
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const double a = asign * Ab[li * LDT + 4 * ks + lk];
-    const double b = Bb[(4 * ks + lk) * LDT + li];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
-  return acc;
-}
+// the in-panel multipliers broadcast by v_readlane; branch-free so that the scheduler can
+// overlap the rank-1 updates of column j with the reciprocal-square-root chain of column
+// j + 1), the rest of the tile is updated on the FP64 matrix cores straight out of LDS.
+// The four 16x16 diagonal inverses M_cc = L_cc^-1 follow (column per lane, four blocks
+// side by side).  The triangular solve of the block's rows is a blocked substitution on
+// the matrix cores, carried out on the TRANSPOSE so that it never leaves registers:
+//     R_c^T = A_c^T - sum_{k<c} (L_ck D_k) Z_k ,   Z_c = X_c^T = (D_c M_cc) R_c^T
+// — the C/D fragment of v_mfma_f64_16x16x4_f64 (row = (lane>>4) + 4 reg, col = lane&15)
+// is exactly its B fragment for k-step `reg`, so Z_k and R_c^T feed the next product
+// directly; only L and M_cc (A operands) come from LDS.  Wave w owns rows 16w .. 16w+15.
+// Block 0 runs the same substitution on the identity without signs: X = L_jj^-T.
+static const int LDM = 18;  // LDS row stride of the 16x16 diagonal inverses
 
-__device__ __forceinline__ void store16(double* __restrict__ Cb, int li, int lk, double4_t acc) {
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) Cb[(lk + 4 * reg) * LDT + li] = acc[reg];
-}
+#ifdef BAE_PANEL_CLOCKS
+__device__ long long g_clk[16];
+#define PCLK(n) do { if (blockIdx.x == 1 && lane == 0 && wave == 0) g_clk[n] = clock64(); } while (0)
+#else
+#define PCLK(n) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(256)
 k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
           double* __restrict__ dsgn_out, double* __restrict__ linvT_out, int* __restrict__ status) {
-  __shared__ double T[NB][LDT];   // the diagonal tile: A_jj -> L_jj (upper part zero)
-  __shared__ double Mi[NB][LDT];  // M = L_jj^-1
-  __shared__ double dv[NB];       // 1 / L[j][j]
-  __shared__ double sg[NB];       // pivot signs d_j
+  __shared__ double T[NB][LDT];        // the diagonal tile: A_jj -> L_jj (upper part zero)
+  __shared__ double Md[4][16][LDM];    // M_cc = L_cc^-1, c = 0..3
+  __shared__ double dv[NB];            // 1 / L[j][j]
+  __shared__ double sg[NB];            // pivot signs d_j
   __shared__ int bad_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const uint32_t i = jj + blockIdx.x;          // row tile of this block (jj: the diagonal)
   const int rows = (i == nblk) ? 1 : NB;
+  const bool invert = blockIdx.x == 0;         // block 0: X = L^-T of the diagonal tile
   const double* Akk = A + ((size_t)jj * NB) * ld + (size_t)jj * NB;
-  double* Aik = A + ((size_t)i * NB) * ld + (size_t)jj * NB;
-  // this wave's A fragments (rows rb.., all 64 k) straight into the MFMA operand layout;
-  // the loads stay in flight during the factorisation
-  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
-  double af[2][16];
-  if (blockIdx.x != 0) {
+  PCLK(0);
+  // the diagonal tile first (it gates the serial chain) ...
+  double2 tl[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int r = rb + 16 * t + li;
-        af[t][ks] = (r < rows) ? Aik[(size_t)r * ld + 4 * ks + lk] : 0.0;
-      }
+  for (int u = 0; u < 8; ++u) {
+    const int idx = tid + 256 * u;
+    const int r = idx >> 5, c2 = (idx & 31) * 2;
+    tl[u] = (c2 <= r) ? *reinterpret_cast<const double2*>(Akk + (size_t)r * ld + c2) : make_double2(0.0, 0.0);
   }
-  for (int idx = tid; idx < NB * (NB / 2); idx += 256) {
-    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
-    double2 v = make_double2(0.0, 0.0);
-    if (c2 <= r) v = *reinterpret_cast<const double2*>(Akk + (size_t)r * ld + c2);
-    T[r][c2] = v.x;
-    T[r][c2 + 1] = (c2 + 1 <= r) ? v.y : 0.0;
-    Mi[r][c2] = 0.0;
-    Mi[r][c2 + 1] = 0.0;
+  // ... then this wave's rows (16w + li) in the C/B fragment layout; these loads stay in
+  // flight during the factorisation
+  double4_t R[4];
+  const int myrow = 16 * wave + li;
+  double* Xrow = invert ? linvT_out + (size_t)jj * NB * NB + (size_t)myrow * NB
+                        : A + ((size_t)i * NB + myrow) * ld + (size_t)jj * NB;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int col = 16 * c + lk + 4 * reg;
+      R[c][reg] = invert ? (col == myrow ? 1.0 : 0.0) : (myrow < rows ? Xrow[col] : 0.0);
+    }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = tid + 256 * u;
+    const int r = idx >> 5, c2 = (idx & 31) * 2;
+    T[r][c2] = tl[u].x;
+    T[r][c2 + 1] = (c2 + 1 <= r) ? tl[u].y : 0.0;
   }
   if (tid == 0) bad_s = 0;
   __syncthreads();
+  PCLK(1);
   if (wave == 0) {
     int bad = 0;
+    double my_dv = 1.0, my_sg = 1.0;
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
       const int c0 = 16 * pb;
@@ -258,110 +266,110 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
         const double d = readlane_f64(p[j], J);
         const double ad = fabs(d);
         const bool ok = (ad > 0.0) && (ad < 1e300);  // zero / NaN / Inf pivot
-        if (!ok) bad = 1;
+        bad |= ok ? 0 : 1;
         const double sgn = d < 0.0 ? -1.0 : 1.0;
         const double dd = ok ? ad : 1.0;
         // y ~ 1/sqrt(dd): hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 dd y^2)
+        const double hd = -0.5 * dd;
         double y = __builtin_amdgcn_rsq(dd);
-        y = y * fma(-0.5 * dd * y, y, 1.5);
-        y = y * fma(-0.5 * dd * y, y, 1.5);
-        p[j] *= y * sgn;                       // rows below: L[r][J] = d_J A[r][J] / sqrt|d|
-        if (lane == J) { p[j] = fabs(p[j]); dv[J] = y; sg[J] = sgn; }  // L[J][J] = sqrt|d|
-        const double sa = sgn * p[j];
+        y = y * fma(hd * y, y, 1.5);
+        y = y * fma(hd * y, y, 1.5);
+        const double sa = p[j] * y;            // d_J L[r][J]
+        const double l = sa * sgn;             // L[r][J] = d_J A[r][J] / sqrt|d|  (lane J: sqrt|d|)
+        p[j] = l;
+        my_dv = (lane == J) ? y : my_dv;
+        my_sg = (lane == J) ? sgn : my_sg;
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) p[c] -= sa * readlane_f64(p[j], c0 + c);  // d_J L[r][J] L[c][J]
+        for (int c = j + 1; c < 16; ++c) p[c] -= sa * readlane_f64(l, c0 + c);  // d_J L[r][J] L[c][J]
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) T[lane][c0 + c] = (c0 + c <= lane) ? p[c] : 0.0;
+      dv[lane] = my_dv;  // lanes beyond this panel still hold the defaults; rewritten later
+      sg[lane] = my_sg;
       // trailing 16x16 blocks (rbk, cbk), pb < cbk <= rbk:  C -= L_rbk,pb D L_cbk,pb^T
+      if (pb < 3) {
+        double la[4][3];  // L[16 b + li][k], k = c0 + 4 ks + lk, b = 1..3 : A operand of row block b
+        double nb[4][3];  // -d_k L[16 b + li][k]                          : B operand of column block b
 #pragma unroll
-      for (int rbk = pb + 1; rbk < 4; ++rbk)
+        for (int ks = 0; ks < 4; ++ks) {
+          const int k = c0 + 4 * ks + lk;
+          const double sk = -sg[k];
 #pragma unroll
-        for (int cbk = pb + 1; cbk <= rbk; ++cbk) {
-          double4_t acc;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) acc[reg] = T[16 * rbk + lk + 4 * reg][16 * cbk + li];
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const int k = c0 + 4 * ks + lk;
-            const double a = T[16 * rbk + li][k];
-            const double b = -sg[k] * T[16 * cbk + li][k];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          for (int b = pb + 1; b < 4; ++b) {
+            la[ks][b - 1] = T[16 * b + li][k];
+            nb[ks][b - 1] = sk * la[ks][b - 1];
           }
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) T[16 * rbk + lk + 4 * reg][16 * cbk + li] = acc[reg];
         }
+#pragma unroll
+        for (int rbk = pb + 1; rbk < 4; ++rbk)
+#pragma unroll
+          for (int cbk = pb + 1; cbk <= rbk; ++cbk) {
+            double4_t acc;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) acc[reg] = T[16 * rbk + lk + 4 * reg][16 * cbk + li];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks][rbk - 1], nb[ks][cbk - 1], acc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) T[16 * rbk + lk + 4 * reg][16 * cbk + li] = acc[reg];
+          }
+      }
+      PCLK(2 + pb);
     }
     if (bad) bad_s = 1;
-    // diagonal 16x16 inverses, lane = (block b, column c): forward substitution L x = e_c
+    // diagonal 16x16 inverses, lane = (block b, column c): L_bb x = e_c, column-oriented
+    // (once x_k is known the remaining rows update independently)
     {
       const int base = 16 * lk, c = li;
-      double x[16];
+      double sacc[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double sacc = (r == c) ? 1.0 : 0.0;
+      for (int r = 0; r < 16; ++r) sacc[r] = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < r; ++k) sacc -= T[base + r][base + k] * x[k];
-        x[r] = sacc * dv[base + r];
+      for (int k = 0; k < 16; ++k) {
+        const double xk = sacc[k] * dv[base + k];
+        sacc[k] = xk;
+#pragma unroll
+        for (int r = k + 1; r < 16; ++r) sacc[r] -= T[base + r][base + k] * xk;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Mi[base + r][base + c] = (r >= c) ? x[r] : 0.0;
+      for (int r = 0; r < 16; ++r) Md[lk][r][c] = sacc[r];  // zero above the diagonal by construction
     }
-    // off-diagonal blocks by distance from the diagonal:
-    //   M_ij = -M_ii (sum_{k = j}^{i-1} L_ik M_kj)
-#pragma unroll
-    for (int dist = 1; dist < 4; ++dist)
-#pragma unroll
-      for (int bi = dist; bi < 4; ++bi) {
-        const int bj = bi - dist;
-        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = bj; k < bi; ++k) acc = mm16(&T[16 * bi][16 * k], &Mi[16 * k][16 * bj], 1.0, li, lk, acc);
-        store16(&Mi[16 * bi][16 * bj], li, lk, acc);
-        double4_t acc2 = (double4_t){0.0, 0.0, 0.0, 0.0};
-        acc2 = mm16(&Mi[16 * bi][16 * bi], &Mi[16 * bi][16 * bj], -1.0, li, lk, acc2);
-        store16(&Mi[16 * bi][16 * bj], li, lk, acc2);
-      }
   }
+  PCLK(6);
   __syncthreads();
-  if (blockIdx.x == 0) {
-    // the pivot signs and L^-T (linvT[r][c] = M[c][r]).  L_jj itself is NOT written back:
-    // the other blocks of this launch may still be reading A_jj, and nothing downstream
-    // needs the diagonal factor tile (the backward substitution uses L_jj^-T).
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-      const int r = idx >> 6, c = idx & 63;
-      linvT_out[(size_t)jj * NB * NB + idx] = Mi[c][r];
-    }
+  PCLK(7);
+  // blocked substitution on the transpose, rows 16 wave + li (see the header comment)
+  double4_t Z[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double4_t Rc = R[c];
+#pragma unroll
+    for (int k = 0; k < c; ++k)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int kk = 16 * k + 4 * ks + lk;
+        const double a = -(invert ? 1.0 : sg[kk]) * T[16 * c + li][kk];
+        Rc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Z[k][ks], Rc, 0, 0, 0);
+      }
+    double4_t Zc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double sc = invert ? 1.0 : sg[16 * c + li];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      Zc = __builtin_amdgcn_mfma_f64_16x16x4f64(sc * Md[c][li][4 * ks + lk], Rc[ks], Zc, 0, 0, 0);
+    Z[c] = Zc;
+  }
+  PCLK(8);
+  if (invert || myrow < rows) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = Z[c][reg];
+  }
+  if (invert) {
     if (tid < NB) dsgn_out[(size_t)jj * NB + tid] = sg[tid];
     if (tid == 0 && bad_s) atomicExch(status, 1);
-    return;
   }
-  // X = A (D M)^T:  X[r][c] = d_c sum_{k <= c} A[r][k] M[c][k]
-  double4_t acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const double s0 = sg[cb + li], s1 = sg[cb + 16 + li];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const double b0 = s0 * Mi[cb + li][4 * ks + lk];
-    const double b1 = s1 * Mi[cb + 16 + li][4 * ks + lk];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][ks], b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[0][ks], b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][ks], b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[1][ks], b1, acc[1][1], 0, 0, 0);
-  }
-#pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = rb + 16 * ti + lk + 4 * reg;
-        const int cc = cb + 16 * tj + li;
-        if (r < rows) Aik[(size_t)r * ld + cc] = acc[ti][tj][reg];
-      }
+  PCLK(9);
 }
 
 // ---------------------------------------------------------------------------------
