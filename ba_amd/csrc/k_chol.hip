@@ -212,6 +212,7 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   __shared__ double Md[4][16][LDM];    // M_cc = L_cc^-1, c = 0..3
   __shared__ double dv[NB];            // 1 / L[j][j]
   __shared__ double sg[NB];            // pivot signs d_j
+  __shared__ __attribute__((aligned(16))) double colbuf[2][NB];  // column j of L, for broadcast reads
   __shared__ int bad_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -221,12 +222,13 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   const double* Akk = A + ((size_t)jj * NB) * ld + (size_t)jj * NB;
   PCLK(0);
   // the diagonal tile first (it gates the serial chain) ...
+  // (all loads unconditional — masked afterwards — so that they are issued back to back)
   double2 tl[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int idx = tid + 256 * u;
     const int r = idx >> 5, c2 = (idx & 31) * 2;
-    tl[u] = (c2 <= r) ? *reinterpret_cast<const double2*>(Akk + (size_t)r * ld + c2) : make_double2(0.0, 0.0);
+    tl[u] = *reinterpret_cast<const double2*>(Akk + (size_t)r * ld + c2);
   }
   // ... then this wave's rows (16w + li) in the C/B fragment layout; these loads stay in
   // flight during the factorisation
@@ -234,58 +236,95 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   const int myrow = 16 * wave + li;
   double* Xrow = invert ? linvT_out + (size_t)jj * NB * NB + (size_t)myrow * NB
                         : A + ((size_t)i * NB + myrow) * ld + (size_t)jj * NB;
+  {
+    const double* Lrow = A + ((size_t)i * NB + (myrow < rows ? myrow : 0)) * ld + (size_t)jj * NB;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int col = 16 * c + lk + 4 * reg;
-      R[c][reg] = invert ? (col == myrow ? 1.0 : 0.0) : (myrow < rows ? Xrow[col] : 0.0);
-    }
+      for (int reg = 0; reg < 4; ++reg) R[c][reg] = Lrow[16 * c + lk + 4 * reg];
+  }
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int idx = tid + 256 * u;
     const int r = idx >> 5, c2 = (idx & 31) * 2;
-    T[r][c2] = tl[u].x;
+    T[r][c2] = (c2 <= r) ? tl[u].x : 0.0;
     T[r][c2 + 1] = (c2 + 1 <= r) ? tl[u].y : 0.0;
   }
   if (tid == 0) bad_s = 0;
   __syncthreads();
   PCLK(1);
   if (wave == 0) {
-    int bad = 0;
-    double my_dv = 1.0, my_sg = 1.0;
+    unsigned long long negmask = 0;  // bit J: pivot J negative (wave-uniform, lives in SGPRs)
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
       const int c0 = 16 * pb;
       double p[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) p[c] = (c0 + c <= lane) ? T[lane][c0 + c] : 0.0;
+      // Software-pipelined right-looking elimination: iteration j runs the pivot chain of
+      // column j (v_rsq_f64 + two Newton steps, no division) while the rank-1 update of step
+      // j-1 on the columns right of j + 1 — independent of that chain — is issued; only the
+      // update of column j + 1 by step j sits on the serial path.  A single wave issues one
+      // VALU instruction every ~6 cycles, so the loop is kept lean: no pivot tests (a zero /
+      // NaN pivot poisons the diagonal, which is checked once at the end), the pivot sign is
+      // applied with an integer xor and collected in a scalar bit mask, the multipliers of
+      // the deferred updates come back from LDS as wave-uniform broadcast reads.
+      // sched_barrier pins the interleaving (the compiler would otherwise re-serialise the
+      // updates into dot products in front of every pivot).
+      double sa_prev = 0.0;
+      double d = readlane_f64(p[0], c0);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int J = c0 + j;
-        const double d = readlane_f64(p[j], J);
+        const int dhi = __double2hiint(d);
+        const int sbit = dhi & (int)0x80000000;
+        negmask |= (unsigned long long)((unsigned)dhi >> 31) << J;
         const double ad = fabs(d);
-        const bool ok = (ad > 0.0) && (ad < 1e300);  // zero / NaN / Inf pivot
-        bad |= ok ? 0 : 1;
-        const double sgn = d < 0.0 ? -1.0 : 1.0;
-        const double dd = ok ? ad : 1.0;
-        // y ~ 1/sqrt(dd): hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 dd y^2)
-        const double hd = -0.5 * dd;
-        double y = __builtin_amdgcn_rsq(dd);
-        y = y * fma(hd * y, y, 1.5);
-        y = y * fma(hd * y, y, 1.5);
-        const double sa = p[j] * y;            // d_J L[r][J]
-        const double l = sa * sgn;             // L[r][J] = d_J A[r][J] / sqrt|d|  (lane J: sqrt|d|)
-        p[j] = l;
-        my_dv = (lane == J) ? y : my_dv;
-        my_sg = (lane == J) ? sgn : my_sg;
+        double lb[16];
+        if (j > 0) {
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) p[c] -= sa * readlane_f64(l, c0 + c);  // d_J L[r][J] L[c][J]
+          for (int c = j + 1; c < 16; ++c) lb[c] = colbuf[(j - 1) & 1][c0 + c];
+        }
+#define BAE_UPD(n)                                                  \
+  {                                                                 \
+    const int c_ = j + 1 + (n);                                     \
+    if (j > 0 && c_ < 16) p[c_] -= sa_prev * lb[c_];                \
+  }
+#define BAE_SB __builtin_amdgcn_sched_barrier(0)
+        // y ~ 1/sqrt|d|: hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 |d| y^2)
+        const double hd = -0.5 * ad;
+        double y = __builtin_amdgcn_rsq(ad);
+        BAE_SB;
+        double t = hd * y;
+        BAE_SB;
+        double u = fma(t, y, 1.5);
+        BAE_UPD(0) BAE_SB;
+        y = y * u;
+        BAE_UPD(1) BAE_UPD(2) BAE_SB;
+        t = hd * y;
+        BAE_UPD(3) BAE_UPD(4) BAE_SB;
+        u = fma(t, y, 1.5);
+        BAE_UPD(5) BAE_UPD(6) BAE_SB;
+        y = y * u;
+        BAE_UPD(7) BAE_UPD(8) BAE_SB;
+        const double sa = p[j] * y;            // d_J L[r][J]
+        BAE_UPD(9) BAE_UPD(10) BAE_SB;
+        // L[r][J] = d_J A[r][J] / sqrt|d| (lane J: sqrt|d| > 0): flip the sign bit if d < 0
+        const double l = __hiloint2double(__double2hiint(sa) ^ sbit, __double2loint(sa));
+        colbuf[j & 1][lane] = l;
+        p[j] = l;
+        if (j < 15) {
+          p[j + 1] -= sa * readlane_f64(l, J + 1);  // d_J L[r][J] L[J+1][J]
+          d = readlane_f64(p[j + 1], J + 1);
+        }
+        BAE_UPD(11) BAE_UPD(12) BAE_UPD(13) BAE_UPD(14) BAE_SB;
+#undef BAE_UPD
+#undef BAE_SB
+        sa_prev = sa;
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c) T[lane][c0 + c] = (c0 + c <= lane) ? p[c] : 0.0;
-      dv[lane] = my_dv;  // lanes beyond this panel still hold the defaults; rewritten later
-      sg[lane] = my_sg;
+      sg[lane] = ((negmask >> lane) & 1ull) ? -1.0 : 1.0;  // later panels rewrite their bits
       // trailing 16x16 blocks (rbk, cbk), pb < cbk <= rbk:  C -= L_rbk,pb D L_cbk,pb^T
       if (pb < 3) {
         double la[4][3];  // L[16 b + li][k], k = c0 + 4 ks + lk, b = 1..3 : A operand of row block b
@@ -316,7 +355,12 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
       }
       PCLK(2 + pb);
     }
-    if (bad) bad_s = 1;
+    {
+      // 1 / L[j][j]; a zero, negative-zero, NaN or Inf pivot shows up on the diagonal
+      const double q = T[lane][lane];
+      if (!(q > 0.0 && q < 1e150)) bad_s = 1;
+      dv[lane] = 1.0 / q;
+    }
     // diagonal 16x16 inverses, lane = (block b, column c): L_bb x = e_c, column-oriented
     // (once x_k is known the remaining rows update independently)
     {
@@ -342,7 +386,12 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   double4_t Z[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    double4_t Rc = R[c];
+    double4_t Rc;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int col = 16 * c + lk + 4 * reg;
+      Rc[reg] = invert ? (col == myrow ? 1.0 : 0.0) : (myrow < rows ? R[c][reg] : 0.0);
+    }
 #pragma unroll
     for (int k = 0; k < c; ++k)
 #pragma unroll
