@@ -196,6 +196,9 @@ k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
 // is exactly its B fragment for k-step `reg`, so Z_k and R_c^T feed the next product
 // directly; only L and M_cc (A operands) come from LDS.  Wave w owns rows 16w .. 16w+15.
 // Block 0 runs the same substitution on the identity without signs: X = L_jj^-T.
+#ifndef BAE_EXP_UPD
+#define BAE_EXP_UPD 1
+#endif
 static const int LDM = 18;  // LDS row stride of the 16x16 diagonal inverses
 
 #ifdef BAE_PANEL_CLOCKS
@@ -236,7 +239,12 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   const int myrow = 16 * wave + li;
   double* Xrow = invert ? linvT_out + (size_t)jj * NB * NB + (size_t)myrow * NB
                         : A + ((size_t)i * NB + myrow) * ld + (size_t)jj * NB;
-  {
+  if (invert) {  // block-uniform: the identity
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) R[c][reg] = (16 * c + lk + 4 * reg == myrow) ? 1.0 : 0.0;
+  } else {
     const double* Lrow = A + ((size_t)i * NB + (myrow < rows ? myrow : 0)) * ld + (size_t)jj * NB;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -272,6 +280,7 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
       // sched_barrier pins the interleaving (the compiler would otherwise re-serialise the
       // updates into dot products in front of every pivot).
       double sa_prev = 0.0;
+      double lb[16];  // multipliers of the previous step: L[c0 + c][J - 1]
       double d = readlane_f64(p[0], c0);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -280,44 +289,42 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
         const int sbit = dhi & (int)0x80000000;
         negmask |= (unsigned long long)((unsigned)dhi >> 31) << J;
         const double ad = fabs(d);
-        double lb[16];
-        if (j > 0) {
-#pragma unroll
-          for (int c = j + 1; c < 16; ++c) lb[c] = colbuf[(j - 1) & 1][c0 + c];
-        }
 #define BAE_UPD(n)                                                  \
   {                                                                 \
     const int c_ = j + 1 + (n);                                     \
-    if (j > 0 && c_ < 16) p[c_] -= sa_prev * lb[c_];                \
+    if (j > 0 && c_ < 16 && BAE_EXP_UPD) p[c_] -= sa_prev * lb[c_]; \
   }
 #define BAE_SB __builtin_amdgcn_sched_barrier(0)
-        // y ~ 1/sqrt|d|: hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 |d| y^2)
-        const double hd = -0.5 * ad;
+        // y ~ 1/sqrt|d|: hardware estimate y0 (rel. error 5e-8, measured) + ONE third-order
+        // step:  h = 1 - |d| y0^2,  y = y0 + y0 h (1/2 + 3/8 h)   (error O(h^3), below 1 ulp)
         double y = __builtin_amdgcn_rsq(ad);
         BAE_SB;
-        double t = hd * y;
+        double t = ad * y;
         BAE_SB;
-        double u = fma(t, y, 1.5);
+        double h = fma(-t, y, 1.0);
         BAE_UPD(0) BAE_SB;
-        y = y * u;
-        BAE_UPD(1) BAE_UPD(2) BAE_SB;
-        t = hd * y;
-        BAE_UPD(3) BAE_UPD(4) BAE_SB;
-        u = fma(t, y, 1.5);
-        BAE_UPD(5) BAE_UPD(6) BAE_SB;
-        y = y * u;
-        BAE_UPD(7) BAE_UPD(8) BAE_SB;
+        double q = fma(0.375, h, 0.5);
+        double yh = y * h;
+        BAE_UPD(1) BAE_UPD(2) BAE_UPD(3) BAE_SB;
+        y = fma(yh, q, y);
+        BAE_UPD(4) BAE_UPD(5) BAE_UPD(6) BAE_UPD(7) BAE_UPD(8) BAE_SB;
         const double sa = p[j] * y;            // d_J L[r][J]
         BAE_UPD(9) BAE_UPD(10) BAE_SB;
         // L[r][J] = d_J A[r][J] / sqrt|d| (lane J: sqrt|d| > 0): flip the sign bit if d < 0
         const double l = __hiloint2double(__double2hiint(sa) ^ sbit, __double2loint(sa));
         colbuf[j & 1][lane] = l;
         p[j] = l;
+        BAE_UPD(11) BAE_UPD(12) BAE_UPD(13) BAE_UPD(14) BAE_SB;
+        // the multipliers for the NEXT iteration's deferred updates: issued here, one whole
+        // serial section ahead of their first use, so the LDS round trip is hidden
+#pragma unroll
+        for (int c = j + 2; c < 16; ++c) lb[c] = colbuf[j & 1][c0 + c];
+        BAE_SB;
         if (j < 15) {
           p[j + 1] -= sa * readlane_f64(l, J + 1);  // d_J L[r][J] L[J+1][J]
           d = readlane_f64(p[j + 1], J + 1);
         }
-        BAE_UPD(11) BAE_UPD(12) BAE_UPD(13) BAE_UPD(14) BAE_SB;
+        BAE_SB;
 #undef BAE_UPD
 #undef BAE_SB
         sa_prev = sa;
@@ -382,37 +389,54 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   PCLK(6);
   __syncthreads();
   PCLK(7);
-  // blocked substitution on the transpose, rows 16 wave + li (see the header comment)
-  double4_t Z[4];
+  // blocked substitution on the transpose, rows 16 wave + li (see the header comment);
+  // right-looking (Z_c updates every later R), all A operands fetched up front.  Rows past
+  // `rows` (rhs-row block) carry row 0's data: MFMA columns are independent, and they are
+  // not stored.
+  {
+    double sgk[3][4], sgc[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    double4_t Rc;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int col = 16 * c + lk + 4 * reg;
-      Rc[reg] = invert ? (col == myrow ? 1.0 : 0.0) : (myrow < rows ? R[c][reg] : 0.0);
-    }
-#pragma unroll
-    for (int k = 0; k < c; ++k)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const int kk = 16 * k + 4 * ks + lk;
-        const double a = -(invert ? 1.0 : sg[kk]) * T[16 * c + li][kk];
-        Rc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Z[k][ks], Rc, 0, 0, 0);
+        const double v = sg[16 * k + 4 * ks + lk];
+        sgk[k][ks] = invert ? -1.0 : -v;
       }
-    double4_t Zc = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const double sc = invert ? 1.0 : sg[16 * c + li];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      Zc = __builtin_amdgcn_mfma_f64_16x16x4f64(sc * Md[c][li][4 * ks + lk], Rc[ks], Zc, 0, 0, 0);
-    Z[c] = Zc;
+    for (int c = 0; c < 4; ++c) {
+      const double v = sg[16 * c + li];
+      sgc[c] = invert ? 1.0 : v;
+    }
+    double aM[4][4], aL[4][3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) aM[c][ks] = sgc[c] * Md[c][li][4 * ks + lk];
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+#pragma unroll
+      for (int k = 0; k < c; ++k)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) aL[c][k][ks] = sgk[k][ks] * T[16 * c + li][16 * k + 4 * ks + lk];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double4_t Zc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Zc = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[c][ks], R[c][ks], Zc, 0, 0, 0);
+#pragma unroll
+      for (int c2 = c + 1; c2 < 4; ++c2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          R[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[c2][c][ks], Zc[ks], R[c2], 0, 0, 0);
+      R[c] = Zc;  // X_c^T
+    }
   }
   PCLK(8);
   if (invert || myrow < rows) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = Z[c][reg];
+      for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = R[c][reg];
   }
   if (invert) {
     if (tid < NB) dsgn_out[(size_t)jj * NB + tid] = sg[tid];
