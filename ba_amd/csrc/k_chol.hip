@@ -540,6 +540,101 @@ k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32
 }
 
 // ---------------------------------------------------------------------------------
+// The same update, software-pipelined (the default):
+//   * the C tile is fetched into the accumulators at kernel start, so its latency hides
+//     under the K loop and the epilogue is a plain store (acc = C - X D Y^T, the sign and
+//     d_k folded into the staged Y);
+//   * K is consumed in chunks of 16 through double-buffered LDS stages (stride 18: the
+//     16-lane phases of the operand reads hit distinct banks): while the matrix cores work
+//     on chunk k, chunk k+1 moves registers -> LDS and chunk k+2 global -> registers; one
+//     barrier per chunk;
+//   * 37 KB of LDS per workgroup: three of them share a CU with a k_panel64 block, so
+//     the bulk updates of the look-ahead do not starve the serial chain of LDS.
+static const int KC2 = 16;
+static const int LDK2 = KC2 + 2;
+
+__global__ void __launch_bounds__(256)
+k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
+          uint32_t kb1, const double* __restrict__ dsgn) {
+  __shared__ double X[2][NB][LDK2];
+  __shared__ double Y[2][NB][LDK2];
+  const uint32_t c = c0 + blockIdx.y;
+  const uint32_t i = c + blockIdx.x;
+  if (i > nblk) return;
+  const int rows = (i == nblk) ? 1 : NB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
+  double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
+  // C tile -> accumulators (rows past `rows` read row 0: never stored)
+  double4_t acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        acc[ti][tj][reg] = Aic[(size_t)(r < rows ? r : 0) * ld + cb + 16 * tj + li];
+      }
+  // staging: thread t moves rows sr and sr + 32, columns sc, sc + 1 of a 64 x 16 chunk
+  const int sr = tid >> 3, sc = (tid & 7) * 2;
+  const double* Xg0 = A + ((size_t)i * NB + (sr < rows ? sr : 0)) * ld + sc;
+  const double* Xg1 = A + ((size_t)i * NB + (sr + 32 < rows ? sr + 32 : 0)) * ld + sc;
+  const double* Yg0 = A + ((size_t)c * NB + sr) * ld + sc;
+  const double* Yg1 = Yg0 + (size_t)32 * ld;
+  const double xm0 = sr < rows ? 1.0 : 0.0, xm1 = sr + 32 < rows ? 1.0 : 0.0;
+  const uint32_t k_begin = kb0 * NB, k_end = kb1 * NB;
+  const int nchunk = (int)((k_end - k_begin) / KC2);
+  double2 px0, px1, py0, py1, ps;
+  auto gload = [&](uint32_t k0) {
+    px0 = *reinterpret_cast<const double2*>(Xg0 + k0);
+    px1 = *reinterpret_cast<const double2*>(Xg1 + k0);
+    py0 = *reinterpret_cast<const double2*>(Yg0 + k0);
+    py1 = *reinterpret_cast<const double2*>(Yg1 + k0);
+    ps = *reinterpret_cast<const double2*>(dsgn + k0 + sc);
+  };
+  auto sstore = [&](int b) {
+    X[b][sr][sc] = px0.x * xm0; X[b][sr][sc + 1] = px0.y * xm0;
+    X[b][sr + 32][sc] = px1.x * xm1; X[b][sr + 32][sc + 1] = px1.y * xm1;
+    Y[b][sr][sc] = -ps.x * py0.x; Y[b][sr][sc + 1] = -ps.y * py0.y;
+    Y[b][sr + 32][sc] = -ps.x * py1.x; Y[b][sr + 32][sc + 1] = -ps.y * py1.y;
+  };
+  gload(k_begin);
+  sstore(0);
+  if (nchunk > 1) gload(k_begin + KC2);
+  __syncthreads();
+  for (int kc = 0; kc < nchunk; ++kc) {
+    const int b = kc & 1;
+    if (kc + 1 < nchunk) sstore(b ^ 1);
+    if (kc + 2 < nchunk) gload(k_begin + (uint32_t)(kc + 2) * KC2);
+#pragma unroll
+    for (int ks = 0; ks < KC2 / 4; ++ks) {
+      const double a0 = X[b][rb + li][4 * ks + lk];
+      const double a1 = X[b][rb + 16 + li][4 * ks + lk];
+      const double b0 = Y[b][cb + li][4 * ks + lk];
+      const double b1 = Y[b][cb + 16 + li][4 * ks + lk];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const bool diag = (i == c);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        const int cc = cb + 16 * tj + li;
+        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = acc[ti][tj][reg];
+      }
+}
+
+// ---------------------------------------------------------------------------------
 // Trailing update with 128x128 output tiles (the bulk of the n^3/3 flops):
 //     A[R, C] -= sum_{k in [kb0*64, kb1*64)} A[R, k] d_k A[C, k]^T
 // for the lower-triangular region right of a panel: block columns >= c0 (c0 even), block
@@ -681,6 +776,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   double* linvT = e->invdiag.p + (size_t)2 * nblk * NB;       // inverse-transposed diagonal tiles
   static const bool no_lookahead = getenv("BA_HIP_NO_LOOKAHEAD") != nullptr;  // A/B switches
   static const bool use64 = getenv("BA_HIP_UPDATE128") == nullptr;  // 64x64 tiles measured faster (r01)
+  static const bool upd_v1 = getenv("BA_HIP_UPDATE_V1") != nullptr;
   static const bool old_panel = getenv("BA_HIP_OLD_PANEL") != nullptr;
   static const bool one_per_cu = getenv("BA_HIP_BULK_ONE_PER_CU") != nullptr;
   hipStream_t s0 = e->stream, s1 = no_lookahead ? e->stream : e->stream2;
@@ -715,8 +811,12 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
       }
       if (jj + 1 < Jend) {
         // in-panel update of the panel's remaining tile columns with tile column jj
-        hipLaunchKernelGGL(k_update<0>, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
-                           dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
+        if (upd_v1)
+          hipLaunchKernelGGL(k_update<0>, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
+                             dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
+        else
+          hipLaunchKernelGGL(k_update2, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
+                             dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
       }
     }
     if (Jend >= nblk) break;
@@ -725,8 +825,12 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     // (a) next panel's columns: needs every earlier bulk update of those columns
     if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
     if (use64) {
-      hipLaunchKernelGGL(k_update<0>, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld, nblk,
-                         Jend, J, Jend, (const double*)dsgn);
+      if (upd_v1)
+        hipLaunchKernelGGL(k_update<0>, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld,
+                           nblk, Jend, J, Jend, (const double*)dsgn);
+      else
+        hipLaunchKernelGGL(k_update2, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld,
+                           nblk, Jend, J, Jend, (const double*)dsgn);
     } else {
       const uint32_t trows = (nblk + 1 - Jend + 1) / 2, tcols = (a_end - Jend + 1) / 2;
       hipLaunchKernelGGL(k_update128, dim3(trows, tcols), dim3(256), 0, s0, dA, ld, nblk, Jend, J,
@@ -740,8 +844,11 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
         if (one_per_cu)
           hipLaunchKernelGGL(k_update<2048>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
                              ld, nblk, a_end, J, Jend, (const double*)dsgn);
-        else
+        else if (upd_v1)
           hipLaunchKernelGGL(k_update<0>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
+                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
+        else
+          hipLaunchKernelGGL(k_update2, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
                              ld, nblk, a_end, J, Jend, (const double*)dsgn);
       } else {
         const uint32_t trows = (nblk + 1 - a_end + 1) / 2, tcols = (nblk - a_end + 1) / 2;
