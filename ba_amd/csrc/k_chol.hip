@@ -208,7 +208,7 @@ __device__ long long g_clk[16];
 #define PCLK(n) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
           double* __restrict__ dsgn_out, double* __restrict__ linvT_out, int* __restrict__ status) {
   __shared__ double T[NB][LDT];        // the diagonal tile: A_jj -> L_jj (upper part zero)
@@ -217,6 +217,9 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   __shared__ double sg[NB];            // pivot signs d_j
   __shared__ __attribute__((aligned(16))) double colbuf[2][NB];  // column j of L, for broadcast reads
   __shared__ int bad_s;
+  // the serial chain of the solver: win the issue arbitration against the bulk-update waves
+  // that share the SIMDs during the look-ahead
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const uint32_t i = jj + blockIdx.x;          // row tile of this block (jj: the diagonal)
@@ -553,11 +556,18 @@ k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32
 static const int KC2 = 16;
 static const int LDK2 = KC2 + 2;
 
+// BULK = true (the look-ahead's background updates) pads the LDS footprint to 56 KB: at most
+// two such workgroups fit on a CU, which always leaves the 44 KB + one wave per SIMD that a
+// k_panel64 block of the concurrent serial chain needs.
+template <bool BULK>
 __global__ void __launch_bounds__(256)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
           uint32_t kb1, const double* __restrict__ dsgn) {
   __shared__ double X[2][NB][LDK2];
   __shared__ double Y[2][NB][LDK2];
+  __shared__ double pad_[BULK ? 2432 : 1];
+  if (BULK && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the padding allocated
+  if (!BULK) __builtin_amdgcn_s_setprio(2);  // critical-path launches outrank the bulk waves
   const uint32_t c = c0 + blockIdx.y;
   const uint32_t i = c + blockIdx.x;
   if (i > nblk) return;
@@ -776,6 +786,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   double* linvT = e->invdiag.p + (size_t)2 * nblk * NB;       // inverse-transposed diagonal tiles
   static const bool no_lookahead = getenv("BA_HIP_NO_LOOKAHEAD") != nullptr;  // A/B switches
   static const bool use64 = getenv("BA_HIP_UPDATE128") == nullptr;  // 64x64 tiles measured faster (r01)
+  static const bool bulk_full = getenv("BA_HIP_BULK_FULL") != nullptr;
   static const bool upd_v1 = getenv("BA_HIP_UPDATE_V1") != nullptr;
   static const bool old_panel = getenv("BA_HIP_OLD_PANEL") != nullptr;
   static const bool one_per_cu = getenv("BA_HIP_BULK_ONE_PER_CU") != nullptr;
@@ -815,7 +826,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
           hipLaunchKernelGGL(k_update<0>, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
                              dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
         else
-          hipLaunchKernelGGL(k_update2, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
+          hipLaunchKernelGGL(k_update2<false>, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
                              dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
       }
     }
@@ -829,7 +840,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
         hipLaunchKernelGGL(k_update<0>, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld,
                            nblk, Jend, J, Jend, (const double*)dsgn);
       else
-        hipLaunchKernelGGL(k_update2, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld,
+        hipLaunchKernelGGL(k_update2<false>, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld,
                            nblk, Jend, J, Jend, (const double*)dsgn);
     } else {
       const uint32_t trows = (nblk + 1 - Jend + 1) / 2, tcols = (a_end - Jend + 1) / 2;
@@ -847,8 +858,11 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
         else if (upd_v1)
           hipLaunchKernelGGL(k_update<0>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
                              ld, nblk, a_end, J, Jend, (const double*)dsgn);
+        else if (no_lookahead || bulk_full)
+          hipLaunchKernelGGL(k_update2<false>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
+                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
         else
-          hipLaunchKernelGGL(k_update2, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
+          hipLaunchKernelGGL(k_update2<true>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
                              ld, nblk, a_end, J, Jend, (const double*)dsgn);
       } else {
         const uint32_t trows = (nblk + 1 - a_end + 1) / 2, tcols = (nblk - a_end + 1) / 2;
