@@ -63,6 +63,7 @@ struct Structure {
   uint32_t ld = 0;        // leading dimension of the dense reduced system (>= n+1, padded)
   uint32_t n_inc = 0;     // pose-landmark incidences (active pose, active landmark)
   uint32_t n_jslots = 0;  // (observation, side) slots carrying pose Jacobian rows
+  uint32_t jbase = 0;     // first J factor row (the W / -W V^-1 rows of the incidences come first)
   uint32_t n_rows = 0;    // factor rows
   uint32_t n_pairs = 0;   // pose pairs (i <= j) with a block in S
   uint64_t n_pair_entries = 0;
@@ -111,6 +112,7 @@ struct Engine {
   DBuf<uint32_t> pair_ptr;               // [n_pairs+1] (64-bit offsets split? entries < 2^32 assumed)
   DBuf<uint2> pair_ij;
   DBuf<uint2> pair_ent;                  // (rowA, rowB)
+  DBuf<uint32_t> pose_rows;              // [2*(Pact+1)]: pose-major J-slot ptr | incidence ptr
   DBuf<uint32_t> prhs_ptr;               // [Pact+1]
   DBuf<uint2> prhs_ent;                  // (row, scalar index)
 

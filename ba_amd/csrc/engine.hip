@@ -204,6 +204,7 @@ static int build_structure(Engine* e) {
       if (lm_linc_r[l] >= 0) lm_wrow_r[l] = (int32_t)(inc_pm[lm_linc_r[l]] * 2 * LM);
   }
   st.n_rows = jbase + 2 * st.n_jslots + 1;  // last row: all zeros
+  st.jbase = jbase;
   const uint32_t zero_row = st.n_rows - 1;
   std::vector<uint32_t> linc_row(st.n_inc);
   for (uint32_t q = 0; q < st.n_inc; ++q) linc_row[q] = inc_pm[q] * 2 * LM;
@@ -220,10 +221,13 @@ static int build_structure(Engine* e) {
     recs.reserve(est);
   }
   auto key = [](uint32_t i, uint32_t j) { return ((uint64_t)i << 32) | j; };
-  for (uint32_t p = 0; p < st.Pact; ++p) recs.push_back({key(p, p), zero_row, zero_row});
+  // The diagonal blocks (i,i) are NOT in the lists: their terms — J^T J over the pose's own
+  // J rows, (-W V^-1) W^T over its own incidences — are contiguous row ranges in the
+  // pose-major numbering and are streamed by k_gather_S_diag.
+  (void)zero_row;
   for (uint32_t l = 0; l < st.L; ++l) {
     for (uint32_t qa = linc_ptr[l]; qa < linc_ptr[l + 1]; ++qa)
-      for (uint32_t qb = qa; qb < linc_ptr[l + 1]; ++qb) {  // poses ascending within a landmark
+      for (uint32_t qb = qa + 1; qb < linc_ptr[l + 1]; ++qb) {  // poses ascending within a landmark
         const uint32_t ia = linc_pose_lm[qa], ib = linc_pose_lm[qb];
         for (int k = 0; k < LM; ++k)
           recs.push_back({key(ia, ib), linc_row[qa] + LM + k, linc_row[qb] + k});  // (-W V^-1)_a W_b^T
@@ -232,12 +236,14 @@ static int build_structure(Engine* e) {
   for (uint32_t s = 0; s < st.O; ++s) {
     const int32_t m = meas_opt(s), r = ref_opt(s);
     const int32_t jm = obs_jrow_m[s], jr = obs_jrow_r[s];
-    if (m >= 0) for (int k = 0; k < 2; ++k) recs.push_back({key(m, m), (uint32_t)jm + k, (uint32_t)jm + k});
-    if (r >= 0) for (int k = 0; k < 2; ++k) recs.push_back({key(r, r), (uint32_t)jr + k, (uint32_t)jr + k});
     if (m >= 0 && r >= 0) {
       for (int k = 0; k < 2; ++k) {
         if (m < r) recs.push_back({key(m, r), (uint32_t)jm + k, (uint32_t)jr + k});
-        else recs.push_back({key(r, m), (uint32_t)jr + k, (uint32_t)jm + k});
+        else if (r < m) recs.push_back({key(r, m), (uint32_t)jr + k, (uint32_t)jm + k});
+        else {  // both sides on the same pose: J = J_m + J_r, the two cross terms
+          recs.push_back({key(m, m), (uint32_t)jm + k, (uint32_t)jr + k});
+          recs.push_back({key(m, m), (uint32_t)jr + k, (uint32_t)jm + k});
+        }
       }
     }
   }
@@ -354,6 +360,11 @@ static int build_structure(Engine* e) {
   UP(linc_ptr, linc_ptr); UP(linc_row, linc_row); UP(linc_pose, linc_pose_lm);
   UP(pair_ptr, pair_ptr); UP(pair_ij, pair_ij); UP(pair_ent, pair_ent);
   UP(prhs_ptr, prhs); UP(prhs_ent, prhs_ent);
+  {
+    std::vector<uint32_t> pose_rows(pslot_ptr);
+    pose_rows.insert(pose_rows.end(), pinc_ptr.begin(), pinc_ptr.end());
+    UP(pose_rows, pose_rows);
+  }
   UP(pose_active, pb.pose_active);
   UP(un_pose, pb.un_pose); UP(un_t, pb.un_t); UP(un_cov_inv, pb.un_cov_inv); UP(un_rot, pb.un_rot);
   UP(bin_p1, pb.bin_p1); UP(bin_p2, pb.bin_p2); UP(bin_t, pb.bin_t); UP(bin_cov_inv, pb.bin_cov_inv);
@@ -536,7 +547,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
   REL(obs_jrow_m); REL(obs_jrow_r); REL(obs_wrow_m); REL(obs_first); REL(lm_wrow_r);
   REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent);
-  REL(prhs_ptr); REL(prhs_ent);
+  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);

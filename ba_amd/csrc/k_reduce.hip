@@ -73,15 +73,83 @@ k_gather_S(uint32_t npairs, const uint32_t* __restrict__ pair_ptr,
     double acc = ((red[w][0][lane] + red[w][1][lane]) + (red[w][2][lane] + red[w][3][lane])) +
                  red[w][4][lane];
     if (i == j) {
-      const uint16_t m = mask_opt[i];
-      if (rr == cc && (m & (1u << rr))) acc = write_fixed ? 1e6 : 0.0;
-      A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] = acc;
+      // only the cross terms of observations whose two sides sit on the same pose come here;
+      // the block itself was written by k_gather_S_diag (stream order), single writer
+      A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] += acc;
     } else {
       A[((size_t)j * D + cc) * ld + (size_t)i * D + rr] = acc;
     }
-  } else if (i == j && lane - 36 < D - 6) {
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Diagonal blocks (i,i): one workgroup per active pose streams the pose's own factor
+// rows — contiguous in the pose-major numbering — instead of walking an entry list:
+//   sum over its J rows of row row^T                       (jt_pr j_pr, diagonal part)
+//   sum over its incidences of (-W V^-1)_k W_k^T           (the Schur term of the pose with itself)
+// A pose of the 1M-residual benchmark owns ~2000 + 2*1000 rows; as list entries of ONE
+// wavefront they were the critical path of the whole gather.  Fixed reduction order
+// (strided rows per thread, xor-butterfly per wave, waves in order): bitwise reproducible.
+// Also writes the fixed entries of the block: 1e6 on masked parameters (shard 0 only).
+template <int LM>
+__global__ void __launch_bounds__(256)
+k_gather_S_diag(const uint32_t* __restrict__ pose_rows, uint32_t npose, uint32_t jbase,
+                const double* __restrict__ frow, int D, uint32_t ld,
+                const uint16_t* __restrict__ mask_opt, int write_fixed, double* __restrict__ A) {
+  __shared__ double red[4][36];
+  const uint32_t i = blockIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  {
+    const uint32_t r0 = jbase + 2 * pose_rows[i], r1 = jbase + 2 * pose_rows[i + 1];
+    for (uint32_t row = r0 + tid; row < r1; row += 256) {
+      const double* v = frow + (size_t)row * kRow;
+      const double v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4], v5 = v[5];
+      const double vv[6] = {v0, v1, v2, v3, v4, v5};
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) acc[a * 6 + b] += vv[a] * vv[b];
+    }
+  }
+  if (LM > 0) {
+    const uint32_t* pinc = pose_rows + (npose + 1);
+    const uint32_t q0 = pinc[i], q1 = pinc[i + 1];
+    const int lm = LM > 0 ? LM : 1;
+    for (uint32_t q = q0 + tid; q < q1; q += 256) {
+      const double* base = frow + (size_t)q * 2 * lm * kRow;
+#pragma unroll
+      for (int k = 0; k < lm; ++k) {
+        const double* a = base + (size_t)(lm + k) * kRow;  // (-W V^-1) row k
+        const double* b = base + (size_t)k * kRow;         // W row k
+        const double av[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
+        const double bv[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};
+#pragma unroll
+        for (int x = 0; x < 6; ++x)
+#pragma unroll
+          for (int y = 0; y < 6; ++y) acc[x * 6 + y] += av[x] * bv[y];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[w][k] = v;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int rr = tid / 6, cc = tid - 6 * rr;
+    double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     const uint16_t m = mask_opt[i];
-    const int k = 6 + (lane - 36);
+    if (rr == cc && (m & (1u << rr))) v = write_fixed ? 1e6 : 0.0;
+    A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] = v;
+  } else if ((int)tid - 36 < D - 6) {
+    const uint16_t m = mask_opt[i];
+    const int k = 6 + (tid - 36);
     if ((m & (1u << k)) && write_fixed) A[((size_t)i * D + k) * ld + (size_t)i * D + k] = 1e6;
   }
 }
@@ -92,41 +160,52 @@ __global__ void k_pad_diag(uint32_t n, uint32_t n_pad, uint32_t ld, double* __re
   if (k < n_pad) A[(size_t)k * ld + k] = 1.0;
 }
 
-// One wavefront per active pose: rhs_p[i] = sum F[row] * scal[idx] over the pose's
+// One workgroup per active pose: rhs_p[i] = sum F[row] * scal[idx] over the pose's
 // observation rows (jt_pr * r_pr, BundleAdjuster.cpp:348-353), then minus W V^-1 rhs_l
-// over its incidences (:480-484).  Lanes = 10 entry slots x 6 components; slots are
-// combined in a fixed order.
+// over its incidences (:480-484).  The factor rows of a pose are contiguous (pose-major),
+// so consecutive threads read consecutive 48-byte rows; the scalars are 8-byte gathers.
+// Fixed reduction order (strided entries per thread, xor-butterfly, waves in order).
 __global__ void __launch_bounds__(256)
 k_gather_rhs(uint32_t npose, const uint32_t* __restrict__ prhs_ptr,
              const uint32_t* __restrict__ prhs_mid, const uint2* __restrict__ prhs_ent,
              const double* __restrict__ frow, const double* __restrict__ scal, int D,
              double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
-  __shared__ double red[4][2][64];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t i = blockIdx.x * 4 + w;
-  const bool valid = i < npose;
-  double accA = 0.0, accB = 0.0;
-  if (valid && lane < 60) {
-    const int slot = lane / 6, c = lane - 6 * slot;
-    const uint32_t e0 = prhs_ptr[i], em = prhs_mid[i], e1 = prhs_ptr[i + 1];
-    for (uint32_t e = e0 + slot; e < em; e += 10) {
-      const uint2 p = prhs_ent[e];
-      accA += frow[(size_t)p.x * kRow + c] * scal[p.y];
-    }
-    for (uint32_t e = em + slot; e < e1; e += 10) {
-      const uint2 p = prhs_ent[e];
-      accB += frow[(size_t)p.x * kRow + c] * scal[p.y];
-    }
+  __shared__ double red[4][12];
+  const uint32_t i = blockIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const uint32_t e0 = prhs_ptr[i], em = prhs_mid[i], e1 = prhs_ptr[i + 1];
+  double acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+  for (uint32_t e = e0 + tid; e < em; e += 256) {
+    const uint2 p = prhs_ent[e];
+    const double* v = frow + (size_t)p.x * kRow;
+    const double sc = scal[p.y];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] += v[c] * sc;
   }
-  red[w][0][lane] = accA;
-  red[w][1][lane] = accB;
+  for (uint32_t e = em + tid; e < e1; e += 256) {
+    const uint2 p = prhs_ent[e];
+    const double* v = frow + (size_t)p.x * kRow;
+    const double sc = scal[p.y];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[6 + c] += v[c] * sc;
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[w][k] = v;
+  }
   __syncthreads();
-  if (valid && lane < 6) {
-    double sa = 0.0, sb = 0.0;
-    for (int s = 0; s < 10; ++s) { sa += red[w][0][s * 6 + lane]; sb += red[w][1][s * 6 + lane]; }
-    rhs_p[(size_t)i * D + lane] = sa;
-    rhs_sc[(size_t)i * D + lane] = sa + sb;
+  if (tid < 6) {
+    const double sa = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    const double sb = (red[0][6 + tid] + red[1][6 + tid]) + (red[2][6 + tid] + red[3][6 + tid]);
+    rhs_p[(size_t)i * D + tid] = sa;
+    rhs_sc[(size_t)i * D + tid] = sa + sb;
   }
+  (void)npose;
 }
 
 int launch_gather_S(Engine* e) {
@@ -144,6 +223,16 @@ int launch_gather_S(Engine* e) {
   }
   BAE_HIP(hipMemsetAsync(e->rhs_p.p, 0, e->rhs_p.bytes(), e->stream));
   BAE_HIP(hipMemsetAsync(e->rhs_sc.p, 0, e->rhs_sc.bytes(), e->stream));
+  if (st.Pact > 0) {
+    const uint16_t* masks = e->pose_mask.p + st.P;  // masks by opt id live after the by-id masks
+#define BAE_DIAG(LMV)                                                                              \
+  hipLaunchKernelGGL(k_gather_S_diag<LMV>, dim3(st.Pact), dim3(256), 0, e->stream,                 \
+                     (const uint32_t*)e->pose_rows.p, st.Pact, st.jbase, (const double*)e->frow.p, \
+                     e->pose_dim, ld, masks, write_fixed, e->A.p)
+    if (e->lm_dim == 0) BAE_DIAG(0); else if (e->lm_dim == 1) BAE_DIAG(1); else BAE_DIAG(3);
+#undef BAE_DIAG
+    BAE_HIP(hipGetLastError());
+  }
   if (st.n_pairs > 0) {
     e->prof_begin(e->ev_gather);
     hipLaunchKernelGGL(k_gather_S, dim3((st.n_pairs + 3) / 4), dim3(256), 0, e->stream, st.n_pairs,
@@ -154,7 +243,7 @@ int launch_gather_S(Engine* e) {
     BAE_HIP(hipGetLastError());
   }
   if (st.Pact > 0 && st.O > 0) {
-    hipLaunchKernelGGL(k_gather_rhs, dim3((st.Pact + 3) / 4), dim3(256), 0, e->stream, st.Pact,
+    hipLaunchKernelGGL(k_gather_rhs, dim3(st.Pact), dim3(256), 0, e->stream, st.Pact,
                        e->prhs_ptr.p, e->prhs_ptr.p + (st.Pact + 1), e->prhs_ent.p, e->frow.p,
                        e->scal.p, e->pose_dim, e->rhs_p.p, e->rhs_sc.p);
     BAE_HIP(hipGetLastError());
