@@ -46,136 +46,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // ---------------------------------------------------------------------------------
-// 64x64 Cholesky of the diagonal tile k by ONE wavefront.  Lane r keeps row r in
-// registers.  Step j: the pivot is broadcast by v_readlane, 1/sqrt(pivot) comes from
-// v_rsq_f64 refined by two Newton steps (no division on the serial chain), every lane
-// scales its column-j entry and publishes it to an LDS column buffer, then updates its
-// columns right of j with the column entries read back as wave-uniform (broadcast) LDS
-// reads.  Fully unrolled: every register index is static; no barriers (single wave, LDS
-// operations of one wave execute in order).
-// Also stores 1/L[j][j] for the triangular solves.
-__global__ void __launch_bounds__(64)
-k_potrf64(double* __restrict__ A, uint32_t ld, uint32_t k, double* __restrict__ dinv_out,
-          double* __restrict__ dsgn_out, int* __restrict__ status) {
-  __shared__ double T[NB][LDP];
-  __shared__ double colbuf[2][NB];
-  const int lane = threadIdx.x;
-  double* Akk = A + ((size_t)k * NB) * ld + (size_t)k * NB;
-  {
-    double tmp[NB];  // all 64 row loads in flight before the first use
-#pragma unroll
-    for (int r = 0; r < NB; ++r) tmp[r] = Akk[(size_t)r * ld + lane];  // coalesced rows
-#pragma unroll
-    for (int r = 0; r < NB; ++r) T[r][lane] = tmp[r];
-  }
-  __syncthreads();
-  double a[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) a[c] = (c <= lane) ? T[lane][c] : 0.0;
-  int bad = 0;
-  double my_dinv = 0.0, my_sgn = 1.0;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const double d = readlane_f64(a[j], j);
-    const double ad = fabs(d);
-    if (!(ad > 0.0) || !(ad < 1e300)) bad = 1;  // zero / NaN / Inf pivot
-    const double sgn = d < 0.0 ? -1.0 : 1.0;
-    const double dd = (ad > 0.0 && ad < 1e300) ? ad : 1.0;
-    // y ~ 1/sqrt(dd): hardware estimate + 2 Newton-Raphson steps y <- y (1.5 - 0.5 dd y^2)
-    double y = __builtin_amdgcn_rsq(dd);
-    y = y * fma(-0.5 * dd * y, y, 1.5);
-    y = y * fma(-0.5 * dd * y, y, 1.5);
-    if (lane == j) { my_dinv = y; my_sgn = sgn; }
-    a[j] *= y * sgn;  // lanes below: L[r][j] = d_j A[r][j] / sqrt|d|
-    if (lane == j) a[j] = fabs(a[j]);  // L[j][j] = sqrt|d|
-    colbuf[j & 1][lane] = a[j];
-    const double sa = sgn * a[j];
-#pragma unroll
-    for (int c = j + 1; c < NB; ++c) a[c] -= sa * colbuf[j & 1][c];  // d_j L[r][j] L[c][j]
-  }
-#pragma unroll
-  for (int c = 0; c < NB; ++c) T[lane][c] = a[c];
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < NB; ++r)
-    if (lane <= r) Akk[(size_t)r * ld + lane] = T[r][lane];
-  dinv_out[(size_t)k * NB + lane] = my_dinv;
-  dsgn_out[(size_t)k * NB + lane] = my_sgn;
-  if (lane == 0 && bad) atomicExch(status, 1);
-}
-
-// ---------------------------------------------------------------------------------
-// Rows below the diagonal tile: X L_kk^T = A_ik, one thread per row, column-oriented
-// (right-looking) forward substitution: once x_p is known every remaining entry of the
-// row is updated independently, s_j -= x_p L[j][p], so the 2016 FMAs per row have no
-// serial dependence beyond one FMA per step.  L_kk is staged TRANSPOSED in LDS so that
-// the entries needed at step p (L[p+1..63][p]) are contiguous: wave-uniform 16-byte LDS
-// reads (broadcast).  One wavefront per 64-row block; the last block is the rhs row.
-__global__ void __launch_bounds__(64)
-k_trsm64(const double* __restrict__ Lkk, const double* __restrict__ dinv,
-         const double* __restrict__ dsgn, double* __restrict__ Apanel, uint32_t ld,
-         uint32_t nrowblk, int inverse_mode) {
-  __shared__ double Xs[NB][LDP];
-  __shared__ __attribute__((aligned(16))) double LsT[NB][LDT];  // LsT[p][j] = L[j][p] / L[j][j]
-  __shared__ double dv[NB];
-  const int lane = threadIdx.x;
-  const int rows = (blockIdx.x + 1 == nrowblk) ? 1 : NB;  // the last block is the rhs row
-  // inverse_mode: block b inverts diagonal tile b — the "panel" is the identity and the
-  // result X = L_bb^-T goes to a dense 64x64 slot (used by the backward substitution)
-  const size_t tile = (size_t)blockIdx.x * NB;
-  if (inverse_mode) { Lkk += tile * ld + tile; dinv += tile; dsgn += tile; }
-  double* Aik = inverse_mode ? Apanel + tile * NB : Apanel + tile * ld;
-  const uint32_t ldo = inverse_mode ? NB : ld;
-  {
-    double ta[NB], tl[NB];  // all loads in flight before the first use
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      ta[r] = inverse_mode ? (r == lane ? 1.0 : 0.0) : ((r < rows) ? Aik[(size_t)r * ld + lane] : 0.0);
-      tl[r] = (lane <= r) ? Lkk[(size_t)r * ld + lane] : 0.0;
-    }
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      Xs[r][lane] = ta[r];
-      // row r of L, element (r, lane), pre-scaled by 1/L[r][r]: with t_j = s_j / L[j][j]
-      // the substitution needs no multiply on its serial chain (x_p = t_p)
-      // (column sign d_lane, row scale d_r / L[r][r]:  x_j = d_j (a_j - sum x_p d_p L[j][p]) / L[j][j])
-      // inverse_mode solves X L^T = I (no D): plain L^-T for the backward substitution
-      LsT[lane][r] = tl[r] * dinv[r] * (inverse_mode ? 1.0 : dsgn[r] * dsgn[lane]);
-    }
-  }
-  dv[lane] = dinv[lane] * (inverse_mode ? 1.0 : dsgn[lane]);
-  __syncthreads();
-  double s[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) s[j] = Xs[lane][j] * dv[j];
-  // software pipeline: the L entries of step p+1 are fetched (wave-uniform LDS reads)
-  // while step p computes; sched_barrier keeps the compiler from sinking the loads
-  double cur[NB], nxt[NB];
-#pragma unroll
-  for (int j = 1; j < NB; ++j) cur[j] = LsT[0][j];
-#pragma unroll
-  for (int p = 0; p < NB; ++p) {
-    if (p + 1 < NB) {
-#pragma unroll
-      for (int j = p + 2; j < NB; ++j) nxt[j] = LsT[p + 1][j];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const double x = s[p];
-#pragma unroll
-    for (int j = p + 1; j < NB; ++j) s[j] -= x * cur[j];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = p + 2; j < NB; ++j) cur[j] = nxt[j];
-  }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) Xs[lane][j] = s[j];
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < NB; ++r)
-    if (r < rows) Aik[(size_t)r * ldo + lane] = Xs[r][lane];
-}
-
-// ---------------------------------------------------------------------------------
 // One 64-column step of the panel factorisation in ONE kernel (the serial chain of the
 // solver: 94 of these at n = 6000):
 //   block 0            factorises the diagonal tile jj, stores the pivot signs and
@@ -449,100 +319,6 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
 }
 
 // ---------------------------------------------------------------------------------
-// C(64x64) += X(64x64) * Y(64x64)^T on the FP64 matrix cores; X, Y in LDS (stride LDT).
-// 4 waves: wave w owns rows [32*(w>>1), +32) x cols [32*(w&1), +32) as 2x2 MFMA tiles.
-// Fragment maps of v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4],
-// B[k = lane>>4][j = lane&15]; C/D: col = lane&15, row = (lane>>4) + 4*reg.
-__device__ __forceinline__ void tile_mma(const double (*X)[LDT], const double (*Y)[LDT],
-                                         int wave, int lane, double4_t acc[2][2]) {
-  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
-  const int li = lane & 15, lk = lane >> 4;
-#pragma unroll 4
-  for (int k0 = 0; k0 < NB; k0 += 4) {
-    const double a0 = X[rb + li][k0 + lk];
-    const double a1 = X[rb + 16 + li][k0 + lk];
-    const double b0 = Y[cb + li][k0 + lk];
-    const double b1 = Y[cb + 16 + li][k0 + lk];
-    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-  }
-}
-
-// load a 64-row x 64-col tile (rows beyond `rows` are zero) into LDS
-__device__ __forceinline__ void load_tile(double (*T)[LDT], const double* __restrict__ src,
-                                          uint32_t ld, int rows, int tid) {
-  for (int idx = tid; idx < NB * (NB / 2); idx += 256) {
-    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
-    double2 v = make_double2(0.0, 0.0);
-    if (r < rows) v = *reinterpret_cast<const double2*>(src + (size_t)r * ld + c2);
-    T[r][c2] = v.x;
-    T[r][c2 + 1] = v.y;
-  }
-}
-
-// same, columns scaled by the pivot signs d_k = +-1 (C -= X D Y^T)
-__device__ __forceinline__ void load_tile_signed(double (*T)[LDT], const double* __restrict__ src,
-                                                 uint32_t ld, const double* __restrict__ sg, int tid) {
-  for (int idx = tid; idx < NB * (NB / 2); idx += 256) {
-    const int r = idx / (NB / 2), c2 = (idx % (NB / 2)) * 2;
-    const double2 v = *reinterpret_cast<const double2*>(src + (size_t)r * ld + c2);
-    T[r][c2] = v.x * sg[c2];
-    T[r][c2 + 1] = v.y * sg[c2 + 1];
-  }
-}
-
-// Update of the tiles (i, c), c in [c0, c0 + gridDim.y), i in [c, nblk] (i == nblk: the
-// rhs row) with the tile columns [kb0, kb1):
-//     A_ic -= sum_kb A_i,kb * A_c,kb^T
-// grid = (nblk - c0 + 1, number of tile columns); blockIdx.x counts rows from c.
-// LDSPAD > 0 inflates the LDS footprint so that only ONE workgroup fits per CU: the bulk
-// updates running beside the serial panel factorisation then always leave LDS, wave slots
-// and issue bandwidth for the critical-path kernels on every CU.
-template <int LDSPAD>
-__global__ void __launch_bounds__(256)
-k_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
-         uint32_t kb1, const double* __restrict__ dsgn) {
-  __shared__ double X[NB][LDT];
-  __shared__ double Y[NB][LDT];
-  __shared__ double pad_[LDSPAD > 0 ? LDSPAD : 1];
-  if (LDSPAD > 0 && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the array allocated
-  const uint32_t c = c0 + blockIdx.y;
-  const uint32_t i = c + blockIdx.x;
-  if (i > nblk) return;
-  const int rows = (i == nblk) ? 1 : NB;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double4_t acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  for (uint32_t kb = kb0; kb < kb1; ++kb) {
-    const double* Aik = A + ((size_t)i * NB) * ld + (size_t)kb * NB;
-    const double* Ack = A + ((size_t)c * NB) * ld + (size_t)kb * NB;
-    if (kb != kb0) __syncthreads();
-    load_tile(X, Aik, ld, rows, tid);
-    load_tile_signed(Y, Ack, ld, dsgn + (size_t)kb * NB, tid);
-    __syncthreads();
-    tile_mma(X, Y, wave, lane, acc);
-  }
-  double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
-  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
-  const bool diag = (i == c);
-#pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = rb + 16 * ti + (lane >> 4) + 4 * reg;
-        const int cc = cb + 16 * tj + (lane & 15);
-        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] -= acc[ti][tj][reg];
-      }
-}
-
-// ---------------------------------------------------------------------------------
 // The same update, software-pipelined (the default):
 //   * the C tile is fetched into the accumulators at kernel start, so its latency hides
 //     under the K loop and the epilogue is a plain store (acc = C - X D Y^T, the sign and
@@ -645,98 +421,335 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 }
 
 // ---------------------------------------------------------------------------------
-// Trailing update with 128x128 output tiles (the bulk of the n^3/3 flops):
-//     A[R, C] -= sum_{k in [kb0*64, kb1*64)} A[R, k] d_k A[C, k]^T
-// for the lower-triangular region right of a panel: block columns >= c0 (c0 even), block
-// rows >= column, the rhs row included.  4 waves, each owns a 64x64 quadrant as 4x4 MFMA
-// tiles (v_mfma_f64_16x16x4_f64); K is consumed in chunks of 32 staged through LDS, the
-// next chunk's global loads are issued before the current chunk's MFMAs (register double
-// buffering), so HBM/L2 latency overlaps the matrix pipe.  Versus 64x64 tiles this halves
-// the operand traffic per flop (16 flop per operand byte at K = 32).
-static const int KC = 32;
-static const int LDK = KC + 2;
+// Pipelined panel step (the default).  k_panel64 keeps the pivot chain of tile d + 1
+// strictly AFTER the update launch of step d; here the chain runs INSIDE that launch:
+//
+//   k_step_update  = the k_update2 tile update, except that workgroup (0,0) — the diagonal
+//                    tile (c0,c0), dispatched first — keeps its updated tile in LDS,
+//                    factorises it (the k_panel64 wave-0 chain), and publishes the
+//                    "factor packet" of step c0: the 40 A-operand vectors of the blocked
+//                    substitution (signed, in fragment order: plain coalesced loads for the
+//                    consumer), the pivot signs and L^-T.  The chain (~12 us) overlaps the
+//                    other tiles' updates of the same launch instead of following them.
+//   k_trsm_op      = rows below the diagonal tile: X = A L^-T D from the factor packet —
+//                    no LDS, no barrier: 16 + 40 loads, 40 MFMAs, 16 stores per wave.
+//
+// Serial path per 64 columns: k_trsm_op (~5 us) + the diagonal workgroup (~15 us), against
+// k_panel64 (~18 us) + update launch (~10 us).
+static const int NOPV = 40;  // operand vectors per factor packet
 
-__global__ void __launch_bounds__(256)
-k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
-            uint32_t kb1, const double* __restrict__ dsgn) {
-  __shared__ double X[128][LDK];
-  __shared__ double Y[128][LDK];
-  const uint32_t trows = (nblk + 1 - c0 + 1) / 2;   // 128-row tiles incl. the rhs row
-  const uint32_t ty = blockIdx.y, tx = blockIdx.x + ty;
-  if (tx >= trows) return;
-  const uint32_t n_pad = nblk * NB;
-  const uint32_t row0 = (c0 + 2 * tx) * NB, col0 = (c0 + 2 * ty) * NB;  // global indices
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+struct TileLds {
+  double T[NB][LDT];        // the diagonal tile: A_dd -> L_dd (upper part zero)
+  double Md[4][16][LDM];    // M_cc = L_cc^-1, c = 0..3
+  double dv[NB];            // 1 / L[j][j]
+  double sg[NB];            // pivot signs d_j
+  __attribute__((aligned(16))) double colbuf[2][NB];  // column j of L, for broadcast reads
+  int bad;
+};
+
+// wave 0: factorise sh.T in place (see k_panel64 for the commentary of the chain), then the
+// four 16x16 diagonal inverses
+__device__ __forceinline__ void factor_tile_wave0(TileLds& sh, int lane) {
   const int li = lane & 15, lk = lane >> 4;
-  const int rb = 64 * (wave >> 1), cb = 64 * (wave & 1);
-  double4_t acc[4][4];
+  unsigned long long negmask = 0;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int pb = 0; pb < 4; ++pb) {
+    const int c0 = 16 * pb;
+    double p[16];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  // staging: thread t moves 8 double2 of X and 8 of Y per chunk: row = (t + 256 u) / 16
-  const int sr = tid >> 4, sc = (tid & 15) * 2;
-  double2 px[8], py[8];
-  const uint32_t k_begin = kb0 * NB, k_end = kb1 * NB;
-  auto gload = [&](uint32_t k0) {
+    for (int c = 0; c < 16; ++c) p[c] = (c0 + c <= lane) ? sh.T[lane][c0 + c] : 0.0;
+    double sa_prev = 0.0;
+    double lb[16];
+    double d = readlane_f64(p[0], c0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const uint32_t r = sr + 16 * u;
-      const uint32_t gr = row0 + r, gc = col0 + r;  // X row / Y row (a column block row)
-      px[u] = (gr <= n_pad) ? *reinterpret_cast<const double2*>(A + (size_t)gr * ld + k0 + sc)
-                            : make_double2(0.0, 0.0);
-      py[u] = (gc < n_pad) ? *reinterpret_cast<const double2*>(A + (size_t)gc * ld + k0 + sc)
-                           : make_double2(0.0, 0.0);
+    for (int j = 0; j < 16; ++j) {
+      const int J = c0 + j;
+      const int dhi = __double2hiint(d);
+      const int sbit = dhi & (int)0x80000000;
+      negmask |= (unsigned long long)((unsigned)dhi >> 31) << J;
+      const double ad = fabs(d);
+#define BAE_UPD(n)                                      \
+  {                                                     \
+    const int c_ = j + 1 + (n);                         \
+    if (j > 0 && c_ < 16) p[c_] -= sa_prev * lb[c_];    \
+  }
+#define BAE_SB __builtin_amdgcn_sched_barrier(0)
+      double y = __builtin_amdgcn_rsq(ad);
+      BAE_SB;
+      double t = ad * y;
+      BAE_SB;
+      double h = fma(-t, y, 1.0);
+      BAE_UPD(0) BAE_SB;
+      double q = fma(0.375, h, 0.5);
+      double yh = y * h;
+      BAE_UPD(1) BAE_UPD(2) BAE_UPD(3) BAE_SB;
+      y = fma(yh, q, y);
+      BAE_UPD(4) BAE_UPD(5) BAE_UPD(6) BAE_UPD(7) BAE_UPD(8) BAE_SB;
+      const double sa = p[j] * y;
+      BAE_UPD(9) BAE_UPD(10) BAE_SB;
+      const double l = __hiloint2double(__double2hiint(sa) ^ sbit, __double2loint(sa));
+      sh.colbuf[j & 1][lane] = l;
+      p[j] = l;
+      BAE_UPD(11) BAE_UPD(12) BAE_UPD(13) BAE_UPD(14) BAE_SB;
+#pragma unroll
+      for (int c = j + 2; c < 16; ++c) lb[c] = sh.colbuf[j & 1][c0 + c];
+      BAE_SB;
+      if (j < 15) {
+        p[j + 1] -= sa * readlane_f64(l, J + 1);
+        d = readlane_f64(p[j + 1], J + 1);
+      }
+      BAE_SB;
+#undef BAE_UPD
+#undef BAE_SB
+      sa_prev = sa;
     }
-  };
-  auto sstore = [&](uint32_t k0) {
-    const double s0 = dsgn[k0 + sc], s1 = dsgn[k0 + sc + 1];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int r = sr + 16 * u;
-      X[r][sc] = px[u].x; X[r][sc + 1] = px[u].y;
-      Y[r][sc] = py[u].x * s0; Y[r][sc + 1] = py[u].y * s1;
-    }
-  };
-  gload(k_begin);
-  sstore(k_begin);
-  __syncthreads();
-  for (uint32_t k0 = k_begin; k0 < k_end; k0 += KC) {
-    const bool more = k0 + KC < k_end;
-    if (more) gload(k0 + KC);
+    for (int c = 0; c < 16; ++c) sh.T[lane][c0 + c] = (c0 + c <= lane) ? p[c] : 0.0;
+    sh.sg[lane] = ((negmask >> lane) & 1ull) ? -1.0 : 1.0;
+    if (pb < 3) {
+      double la[4][3], nb[4][3];
 #pragma unroll
-    for (int kk = 0; kk < KC; kk += 4) {
-      double a[4], b[4];
+      for (int ks = 0; ks < 4; ++ks) {
+        const int k = c0 + 4 * ks + lk;
+        const double sk = -sh.sg[k];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        a[t] = X[rb + 16 * t + li][kk + lk];
-        b[t] = Y[cb + 16 * t + li][kk + lk];
+        for (int b = pb + 1; b < 4; ++b) {
+          la[ks][b - 1] = sh.T[16 * b + li][k];
+          nb[ks][b - 1] = sk * la[ks][b - 1];
+        }
       }
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti)
+      for (int rbk = pb + 1; rbk < 4; ++rbk)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-          acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+        for (int cbk = pb + 1; cbk <= rbk; ++cbk) {
+          double4_t acc;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[reg] = sh.T[16 * rbk + lk + 4 * reg][16 * cbk + li];
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks][rbk - 1], nb[ks][cbk - 1], acc, 0, 0, 0);
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) sh.T[16 * rbk + lk + 4 * reg][16 * cbk + li] = acc[reg];
+        }
     }
+  }
+  {
+    const double q = sh.T[lane][lane];
+    if (!(q > 0.0 && q < 1e150)) sh.bad = 1;  // zero, NaN or Inf pivot
+    sh.dv[lane] = 1.0 / q;
+  }
+  {
+    const int base = 16 * lk, c = li;
+    double sacc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double xk = sacc[k] * sh.dv[base + k];
+      sacc[k] = xk;
+#pragma unroll
+      for (int r = k + 1; r < 16; ++r) sacc[r] -= sh.T[base + r][base + k] * xk;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sh.Md[lk][r][c] = sacc[r];
+  }
+}
+
+// operand vector v of the blocked substitution for this lane (see k_panel64):
+//   v < 16:  aM[c][ks] =  d_(16c+li) M_cc[li][4ks+lk]           c = v / 4, ks = v % 4
+//   v >= 16: aL[c][k][ks] = -d_kk L[16c+li][kk], kk = 16k+4ks+lk, (c,k) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+// `sgn` false: all signs +1 (the inverse L^-T)
+__device__ __forceinline__ double subst_operand(const TileLds& sh, int v, int li, int lk, bool sgn) {
+  if (v < 16) {
+    const int c = v >> 2, ks = v & 3;
+    return (sgn ? sh.sg[16 * c + li] : 1.0) * sh.Md[c][li][4 * ks + lk];
+  }
+  const int pi = (v - 16) >> 2, ks = v & 3;
+  const int c = pi == 0 ? 1 : (pi < 3 ? 2 : 3);
+  const int k = pi == 0 ? 0 : (pi < 3 ? pi - 1 : pi - 3);
+  const int kk = 16 * k + 4 * ks + lk;
+  return -(sgn ? sh.sg[kk] : 1.0) * sh.T[16 * c + li][kk];
+}
+
+// R[c] (c = 0..3) holds A^T fragments of 16 rows; on return X^T.  op[v]: operand vectors.
+__device__ __forceinline__ void subst_rows(double4_t R[4], const double op[NOPV]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double4_t Zc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Zc = __builtin_amdgcn_mfma_f64_16x16x4f64(op[4 * c + ks], R[c][ks], Zc, 0, 0, 0);
+#pragma unroll
+    for (int c2 = c + 1; c2 < 4; ++c2) {
+      const int pi = (c2 == 1 ? 0 : (c2 == 2 ? 1 : 3)) + c;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        R[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[16 + 4 * pi + ks], Zc[ks], R[c2], 0, 0, 0);
+    }
+    R[c] = Zc;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
+              uint32_t kb1, double* __restrict__ dsgn, double* __restrict__ opbuf,
+              double* __restrict__ linvT_out, int* __restrict__ status) {
+  struct UpdLds { double X[2][NB][LDK2]; double Y[2][NB][LDK2]; };
+  constexpr size_t kLds = sizeof(TileLds) > sizeof(UpdLds) ? sizeof(TileLds) : sizeof(UpdLds);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
+  UpdLds& u = *reinterpret_cast<UpdLds*>(smem);
+  TileLds& sh = *reinterpret_cast<TileLds*>(smem);
+  __builtin_amdgcn_s_setprio(2);
+  const uint32_t c = c0 + blockIdx.y;
+  const uint32_t i = c + blockIdx.x;
+  if (i > nblk) return;
+  const bool special = (blockIdx.x == 0 && blockIdx.y == 0);  // the diagonal tile (c0,c0)
+  const int rows = (i == nblk) ? 1 : NB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
+  double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        acc[ti][tj][reg] = Aic[(size_t)(r < rows ? r : 0) * ld + cb + 16 * tj + li];
+      }
+  const uint32_t k_begin = kb0 * NB, k_end = kb1 * NB;
+  const int nchunk = (int)((k_end - k_begin) / KC2);
+  if (nchunk > 0) {
+    const int sr = tid >> 3, sc = (tid & 7) * 2;
+    const double* Xg0 = A + ((size_t)i * NB + (sr < rows ? sr : 0)) * ld + sc;
+    const double* Xg1 = A + ((size_t)i * NB + (sr + 32 < rows ? sr + 32 : 0)) * ld + sc;
+    const double* Yg0 = A + ((size_t)c * NB + sr) * ld + sc;
+    const double* Yg1 = Yg0 + (size_t)32 * ld;
+    const double xm0 = sr < rows ? 1.0 : 0.0, xm1 = sr + 32 < rows ? 1.0 : 0.0;
+    double2 px0, px1, py0, py1, ps;
+    auto gload = [&](uint32_t k0) {
+      px0 = *reinterpret_cast<const double2*>(Xg0 + k0);
+      px1 = *reinterpret_cast<const double2*>(Xg1 + k0);
+      py0 = *reinterpret_cast<const double2*>(Yg0 + k0);
+      py1 = *reinterpret_cast<const double2*>(Yg1 + k0);
+      ps = *reinterpret_cast<const double2*>(dsgn + k0 + sc);
+    };
+    auto sstore = [&](int b) {
+      u.X[b][sr][sc] = px0.x * xm0; u.X[b][sr][sc + 1] = px0.y * xm0;
+      u.X[b][sr + 32][sc] = px1.x * xm1; u.X[b][sr + 32][sc + 1] = px1.y * xm1;
+      u.Y[b][sr][sc] = -ps.x * py0.x; u.Y[b][sr][sc + 1] = -ps.y * py0.y;
+      u.Y[b][sr + 32][sc] = -ps.x * py1.x; u.Y[b][sr + 32][sc + 1] = -ps.y * py1.y;
+    };
+    gload(k_begin);
+    sstore(0);
+    if (nchunk > 1) gload(k_begin + KC2);
     __syncthreads();
-    if (more) {
-      sstore(k0 + KC);
+    for (int kc = 0; kc < nchunk; ++kc) {
+      const int b = kc & 1;
+      if (kc + 1 < nchunk) sstore(b ^ 1);
+      if (kc + 2 < nchunk) gload(k_begin + (uint32_t)(kc + 2) * KC2);
+#pragma unroll
+      for (int ks = 0; ks < KC2 / 4; ++ks) {
+        const double a0 = u.X[b][rb + li][4 * ks + lk];
+        const double a1 = u.X[b][rb + 16 + li][4 * ks + lk];
+        const double b0 = u.Y[b][cb + li][4 * ks + lk];
+        const double b1 = u.Y[b][cb + 16 + li][4 * ks + lk];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
       __syncthreads();
     }
   }
-  // epilogue: lower-triangular part only (64-block granularity, then element-wise on the
-  // diagonal blocks), rows up to the rhs row, columns inside the matrix
+  if (!special) {
+    const bool diag = (i == c);
 #pragma unroll
-  for (int ti = 0; ti < 4; ++ti)
+    for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int r = rb + 16 * ti + lk + 4 * reg;
+          const int cc = cb + 16 * tj + li;
+          if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = acc[ti][tj][reg];
+        }
+    return;
+  }
+  // ---- the diagonal tile: factorise, publish the factor packet of step c0 -------------
+  __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const uint32_t gr = row0 + rb + 16 * ti + (lane >> 4) + 4 * reg;
-        const uint32_t gc = col0 + cb + 16 * tj + (lane & 15);
-        if (gr <= n_pad && gc < n_pad && (gc <= gr || gr == n_pad))
-          A[(size_t)gr * ld + gc] -= acc[ti][tj][reg];
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        const int cc = cb + 16 * tj + li;
+        sh.T[r][cc] = (cc <= r) ? acc[ti][tj][reg] : 0.0;
       }
+  if (tid == 0) sh.bad = 0;
+  __syncthreads();
+  if (wave == 0) factor_tile_wave0(sh, lane);
+  __syncthreads();
+  {
+    double* ob = opbuf + (size_t)c0 * NOPV * 64;
+#pragma unroll
+    for (int q = 0; q < NOPV / 4; ++q) {
+      const int v = wave * (NOPV / 4) + q;
+      ob[(size_t)v * 64 + lane] = subst_operand(sh, v, li, lk, true);
+    }
+    if (tid < NB) dsgn[(size_t)c0 * NB + tid] = sh.sg[tid];
+    if (tid == 0 && sh.bad) atomicExch(status, 1);
+  }
+  {
+    // L^-T for the backward substitution: the same substitution on the identity, no signs
+    double op[NOPV];
+#pragma unroll
+    for (int v = 0; v < NOPV; ++v) op[v] = subst_operand(sh, v, li, lk, false);
+    const int myrow = 16 * wave + li;
+    double4_t R[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) R[cc][reg] = (16 * cc + lk + 4 * reg == myrow) ? 1.0 : 0.0;
+    subst_rows(R, op);
+    double* Xrow = linvT_out + (size_t)c0 * NB * NB + (size_t)myrow * NB;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Xrow[16 * cc + lk + 4 * reg] = R[cc][reg];
+  }
+}
+
+// rows below the diagonal tile d (row tiles d+1 .., the last block is the rhs row)
+__global__ void __launch_bounds__(256)
+k_trsm_op(double* __restrict__ A, uint32_t ld, uint32_t d, uint32_t nblk,
+          const double* __restrict__ opbuf) {
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const uint32_t i = d + 1 + blockIdx.x;
+  const int rows = (i == nblk) ? 1 : NB;
+  const int myrow = 16 * wave + li;
+  double* Xrow = A + ((size_t)i * NB + (myrow < rows ? myrow : 0)) * ld + (size_t)d * NB;
+  double4_t R[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) R[c][reg] = Xrow[16 * c + lk + 4 * reg];
+  double op[NOPV];
+  const double* ob = opbuf + (size_t)d * NOPV * 64 + lane;
+#pragma unroll
+  for (int v = 0; v < NOPV; ++v) op[v] = ob[(size_t)v * 64];
+  subst_rows(R, op);
+  if (myrow < rows) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = R[c][reg];
+  }
 }
 
 // Backward substitution, block row i (from the last to the first):
@@ -781,15 +794,13 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status) {
   (void)n;
   const uint32_t nblk = ld / NB;
-  BAE_HIP(e->invdiag.alloc((size_t)2 * nblk * NB + (size_t)nblk * NB * NB));
-  double* dsgn = e->invdiag.p + (size_t)nblk * NB;            // pivot signs
-  double* linvT = e->invdiag.p + (size_t)2 * nblk * NB;       // inverse-transposed diagonal tiles
+  BAE_HIP(e->invdiag.alloc((size_t)nblk * NB + (size_t)nblk * NB * NB + (size_t)nblk * NOPV * 64));
+  double* dsgn = e->invdiag.p;                                  // pivot signs
+  double* linvT = dsgn + (size_t)nblk * NB;                     // inverse-transposed diagonal tiles
+  double* opbuf = linvT + (size_t)nblk * NB * NB;               // factor packets (k_step_update)
   static const bool no_lookahead = getenv("BA_HIP_NO_LOOKAHEAD") != nullptr;  // A/B switches
-  static const bool use64 = getenv("BA_HIP_UPDATE128") == nullptr;  // 64x64 tiles measured faster (r01)
   static const bool bulk_full = getenv("BA_HIP_BULK_FULL") != nullptr;
-  static const bool upd_v1 = getenv("BA_HIP_UPDATE_V1") != nullptr;
-  static const bool old_panel = getenv("BA_HIP_OLD_PANEL") != nullptr;
-  static const bool one_per_cu = getenv("BA_HIP_BULK_ONE_PER_CU") != nullptr;
+  static const bool panel64 = getenv("BA_HIP_PANEL64") != nullptr;
   hipStream_t s0 = e->stream, s1 = no_lookahead ? e->stream : e->stream2;
   const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
   while (e->ev_panel.size() < npanels) {
@@ -800,6 +811,19 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     e->ev_bulk.push_back(b);
   }
   BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), s0));
+  // update of the tile columns [c0, c0 + ncols) with the tile columns [kb0, kb1) on the
+  // critical-path stream; in the pipelined scheme the launch also factorises tile (c0,c0)
+  auto step_update = [&](uint32_t c0, uint32_t ncols, uint32_t kb0, uint32_t kb1) {
+    if (panel64)
+      hipLaunchKernelGGL(k_update2<false>, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
+                         kb0, kb1, (const double*)dsgn);
+    else
+      hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
+                         kb0, kb1, dsgn, opbuf, linvT, e->flags.p);
+  };
+  if (!panel64)  // factor packet of tile 0 (nothing to update: one workgroup)
+    hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
+                       linvT, e->flags.p);
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
   // overlapping the serial factorisation of the next panel.
@@ -808,67 +832,31 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
     const uint32_t Jend = J + KOUT < nblk ? J + KOUT : nblk;
     for (uint32_t jj = J; jj < Jend; ++jj) {
-      if (old_panel) {
-        hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(64), 0, s0, dA, ld, jj, e->invdiag.p, dsgn,
-                           e->flags.p);
-        hipLaunchKernelGGL(k_trsm64, dim3(nblk - jj), dim3(64), 0, s0,
-                           (const double*)(dA + ((size_t)jj * NB) * ld + (size_t)jj * NB),
-                           (const double*)(e->invdiag.p + (size_t)jj * NB),
-                           (const double*)(dsgn + (size_t)jj * NB),
-                           dA + ((size_t)(jj + 1) * NB) * ld + (size_t)jj * NB, ld, nblk - jj, 0);
-      } else {
+      if (panel64)
         hipLaunchKernelGGL(k_panel64, dim3(nblk - jj + 1), dim3(256), 0, s0, dA, ld, jj, nblk, dsgn,
                            linvT, e->flags.p);
-      }
-      if (jj + 1 < Jend) {
-        // in-panel update of the panel's remaining tile columns with tile column jj
-        if (upd_v1)
-          hipLaunchKernelGGL(k_update<0>, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
-                             dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
-        else
-          hipLaunchKernelGGL(k_update2<false>, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0,
-                             dA, ld, nblk, jj + 1, jj, jj + 1, (const double*)dsgn);
-      }
+      else
+        hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk,
+                           (const double*)opbuf);
+      // in-panel update of the panel's remaining tile columns with tile column jj
+      if (jj + 1 < Jend) step_update(jj + 1, Jend - (jj + 1), jj, jj + 1);
     }
     if (Jend >= nblk) break;
     BAE_HIP(hipEventRecord(e->ev_panel[pj], s0));
     const uint32_t a_end = Jend + KOUT < nblk ? Jend + KOUT : nblk;  // columns of the next panel
     // (a) next panel's columns: needs every earlier bulk update of those columns
     if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
-    if (use64) {
-      if (upd_v1)
-        hipLaunchKernelGGL(k_update<0>, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld,
-                           nblk, Jend, J, Jend, (const double*)dsgn);
-      else
-        hipLaunchKernelGGL(k_update2<false>, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld,
-                           nblk, Jend, J, Jend, (const double*)dsgn);
-    } else {
-      const uint32_t trows = (nblk + 1 - Jend + 1) / 2, tcols = (a_end - Jend + 1) / 2;
-      hipLaunchKernelGGL(k_update128, dim3(trows, tcols), dim3(256), 0, s0, dA, ld, nblk, Jend, J,
-                         Jend, (const double*)dsgn);
-    }
+    step_update(Jend, a_end - Jend, J, Jend);
     // (b) the rest, concurrently with the next panel's factorisation
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
       e->prof_begin(e->ev_syrk, s1);
-      if (use64) {
-        if (one_per_cu)
-          hipLaunchKernelGGL(k_update<2048>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
-                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
-        else if (upd_v1)
-          hipLaunchKernelGGL(k_update<0>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
-                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
-        else if (no_lookahead || bulk_full)
-          hipLaunchKernelGGL(k_update2<false>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
-                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
-        else
-          hipLaunchKernelGGL(k_update2<true>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
-                             ld, nblk, a_end, J, Jend, (const double*)dsgn);
-      } else {
-        const uint32_t trows = (nblk + 1 - a_end + 1) / 2, tcols = (nblk - a_end + 1) / 2;
-        hipLaunchKernelGGL(k_update128, dim3(trows, tcols), dim3(256), 0, s1, dA, ld, nblk, a_end, J,
-                           Jend, (const double*)dsgn);
-      }
+      if (no_lookahead || bulk_full)
+        hipLaunchKernelGGL(k_update2<false>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
+                           ld, nblk, a_end, J, Jend, (const double*)dsgn);
+      else
+        hipLaunchKernelGGL(k_update2<true>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
+                           ld, nblk, a_end, J, Jend, (const double*)dsgn);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
@@ -879,10 +867,6 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     }
   }
   BAE_HIP(hipGetLastError());
-  // inverse-transposed diagonal tiles (all in parallel): X L_ii^T = I  ->  X = L_ii^-T
-  if (old_panel)
-    hipLaunchKernelGGL(k_trsm64, dim3(nblk), dim3(64), 0, s0, (const double*)dA,
-                       (const double*)e->invdiag.p, (const double*)dsgn, linvT, ld, nblk + 1, 1);
   for (uint32_t ii = nblk; ii-- > 0;) {
     const uint32_t cols = ii * NB;
     const uint32_t grid = cols == 0 ? 1 : (cols + 255) / 256;
