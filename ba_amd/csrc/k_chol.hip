@@ -34,7 +34,6 @@ namespace bae {
 static const int NB = 64;        // tile size
 static const int KOUT = 4;       // tiles per outer panel
 static const int LDT = NB + 2;   // LDS row stride (doubles): conflict-free MFMA operand reads
-static const int LDP = NB + 1;   // LDS row stride for row-per-lane access
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -592,7 +591,7 @@ __device__ __forceinline__ void subst_rows(double4_t R[4], const double op[NOPV]
 __global__ void __launch_bounds__(256, 2)
 k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
               uint32_t kb1, double* __restrict__ dsgn, double* __restrict__ opbuf,
-              double* __restrict__ linvT_out, int* __restrict__ status) {
+              int* __restrict__ status) {
   struct UpdLds { double X[2][NB][LDK2]; double Y[2][NB][LDK2]; };
   constexpr size_t kLds = sizeof(TileLds) > sizeof(UpdLds) ? sizeof(TileLds) : sizeof(UpdLds);
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
@@ -703,24 +702,6 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
     if (tid < NB) dsgn[(size_t)c0 * NB + tid] = sh.sg[tid];
     if (tid == 0 && sh.bad) atomicExch(status, 1);
   }
-  {
-    // L^-T for the backward substitution: the same substitution on the identity, no signs
-    double op[NOPV];
-#pragma unroll
-    for (int v = 0; v < NOPV; ++v) op[v] = subst_operand(sh, v, li, lk, false);
-    const int myrow = 16 * wave + li;
-    double4_t R[4];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) R[cc][reg] = (16 * cc + lk + 4 * reg == myrow) ? 1.0 : 0.0;
-    subst_rows(R, op);
-    double* Xrow = linvT_out + (size_t)c0 * NB * NB + (size_t)myrow * NB;
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Xrow[16 * cc + lk + 4 * reg] = R[cc][reg];
-  }
 }
 
 // rows below the diagonal tile d (row tiles d+1 .., the last block is the rhs row)
@@ -750,6 +731,43 @@ k_trsm_op(double* __restrict__ A, uint32_t ld, uint32_t d, uint32_t nblk,
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = R[c][reg];
   }
+}
+
+// L_dd^-T of every diagonal tile, for the backward substitution: the blocked substitution on
+// the identity with the signs taken back out of the factor packets (d = +-1).  One launch
+// for all tiles after the factorisation — off the serial chain.
+__global__ void __launch_bounds__(256)
+k_linvT(const double* __restrict__ opbuf, const double* __restrict__ dsgn, double* __restrict__ linvT) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const uint32_t d = blockIdx.x;
+  const double* sg = dsgn + (size_t)d * NB;
+  const double* ob = opbuf + (size_t)d * NOPV * 64 + lane;
+  double op[NOPV];
+#pragma unroll
+  for (int v = 0; v < NOPV; ++v) {
+    double s;
+    if (v < 16) {
+      s = sg[16 * (v >> 2) + li];
+    } else {
+      const int pi = (v - 16) >> 2;
+      const int k = pi == 0 ? 0 : (pi < 3 ? pi - 1 : pi - 3);
+      s = sg[16 * k + 4 * (v & 3) + lk];
+    }
+    op[v] = ob[(size_t)v * 64] * s;
+  }
+  const int myrow = 16 * wave + li;
+  double4_t R[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) R[c][reg] = (16 * c + lk + 4 * reg == myrow) ? 1.0 : 0.0;
+  subst_rows(R, op);
+  double* Xrow = linvT + (size_t)d * NB * NB + (size_t)myrow * NB;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = R[c][reg];
 }
 
 // Backward substitution, block row i (from the last to the first):
@@ -801,6 +819,8 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   static const bool no_lookahead = getenv("BA_HIP_NO_LOOKAHEAD") != nullptr;  // A/B switches
   static const bool bulk_full = getenv("BA_HIP_BULK_FULL") != nullptr;
   static const bool panel64 = getenv("BA_HIP_PANEL64") != nullptr;
+  static const uint32_t bulk_full_m =
+      getenv("BA_HIP_BULK_FULL_M") ? (uint32_t)atoi(getenv("BA_HIP_BULK_FULL_M")) : 0xffffffffu;
   hipStream_t s0 = e->stream, s1 = no_lookahead ? e->stream : e->stream2;
   const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
   while (e->ev_panel.size() < npanels) {
@@ -819,11 +839,11 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
                          kb0, kb1, (const double*)dsgn);
     else
       hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, dsgn, opbuf, linvT, e->flags.p);
+                         kb0, kb1, dsgn, opbuf, e->flags.p);
   };
   if (!panel64)  // factor packet of tile 0 (nothing to update: one workgroup)
     hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
-                       linvT, e->flags.p);
+                       e->flags.p);
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
   // overlapping the serial factorisation of the next panel.
@@ -851,7 +871,10 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
       e->prof_begin(e->ev_syrk, s1);
-      if (no_lookahead || bulk_full)
+      // early panels: the bulk update outweighs the serial chain it overlaps — run it at full
+      // occupancy; later the chain is the bottleneck and the capped variant leaves it room
+      const bool bulk_heavy = (nblk - a_end) >= bulk_full_m;
+      if (no_lookahead || bulk_full || bulk_heavy)
         hipLaunchKernelGGL(k_update2<false>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
                            ld, nblk, a_end, J, Jend, (const double*)dsgn);
       else
@@ -867,6 +890,9 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     }
   }
   BAE_HIP(hipGetLastError());
+  if (!panel64)
+    hipLaunchKernelGGL(k_linvT, dim3(nblk), dim3(256), 0, s0, (const double*)opbuf, (const double*)dsgn,
+                       linvT);
   for (uint32_t ii = nblk; ii-- > 0;) {
     const uint32_t cols = ii * NB;
     const uint32_t grid = cols == 0 ? 1 : (cols + 255) / 256;
