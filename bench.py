@@ -162,7 +162,8 @@ def main():
         n = eng.num_pose_params()
         O = L * K
         ms = 1e3 * elapsed / args.steps
-        # dominant kernel: the trailing update of the dense Cholesky (FP64 MFMA)
+        # dominant kernel: the trailing update of the dense LDL^T factorisation (FP64 MFMA);
+        # timed with HIP events on the stream it is launched on (the engine's second stream)
         syrk_tf = ks.syrk_flops / (ks.syrk_ms * 1e-3) / 1e12 if ks.syrk_ms > 0 else 0.0
         # HBM-bound kernels, algorithmic bytes per launch (DESIGN.md §Roofline accounting)
         ell = lm_dim
@@ -170,6 +171,15 @@ def main():
         b_gather = 8.0 * n * (n + 1) / 2 + 8 * n
         lm_gbs = b_landmarks * ks.landmarks_launches / (ks.landmarks_ms * 1e-3) / 1e9 if ks.landmarks_ms > 0 else 0.0
         ga_gbs = b_gather * ks.gather_launches / (ks.gather_ms * 1e-3) / 1e9 if ks.gather_ms > 0 else 0.0
+        # HBM-side traffic of the dominant kernel: not measurable live; taken from the committed
+        # rocprofv3 --pmc passes of this same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
+        # per launch), null if the summary is absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"]["bae::k_update2<true>"]["traffic_bytes_per_launch_corrected"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Gauss-Newton iterations/sec",
             "value": args.steps / elapsed,
@@ -188,9 +198,11 @@ def main():
                                    "2 anchor poses inactive" % (P, L, O, lm_dim),
                        "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
                        "parallelism": "landmark-sharded x%d, all-reduce of S" % world if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_syrk (dense Cholesky trailing update, v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": "k_update2 (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)",
                          "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                         "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, bytes per launch)",
+                         "flops_per_launch": ks.syrk_flops / max(ks.syrk_launches, 1),
                          "launches": ks.syrk_launches,
                          "avg_launch_us": 1e3 * ks.syrk_ms / max(ks.syrk_launches, 1)},
             "hbm_kernels": {
