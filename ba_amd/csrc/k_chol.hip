@@ -337,15 +337,34 @@ static const int LDK2 = KC2 + 2;
 template <bool BULK>
 __global__ void __launch_bounds__(256)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
-          uint32_t kb1, const double* __restrict__ dsgn) {
+          uint32_t kb1, const double* __restrict__ dsgn, int swz) {
   __shared__ double X[2][NB][LDK2];
   __shared__ double Y[2][NB][LDK2];
   __shared__ double pad_[BULK ? 2432 : 1];
   if (BULK && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the padding allocated
   if (!BULK) __builtin_amdgcn_s_setprio(2);  // critical-path launches outrank the bulk waves
-  const uint32_t c = c0 + blockIdx.y;
-  const uint32_t i = c + blockIdx.x;
-  if (i > nblk) return;
+  uint32_t c, i;
+  if (swz) {
+    // XCD-aware 1-D launch (the big trailing updates): workgroups whose ids agree mod 8 share
+    // an XCD and its L2, so each XCD walks its own 8x8 super-blocks of output tiles — the
+    // 8 + 8 operand slices of a super-block (2 MB at K = 256) stay L2-resident instead of
+    // being re-fetched for every tile.  Super-blocks enumerate the lower triangle row by row.
+    const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+    const uint32_t t = (slot >> 6) * 8u + xcd, within = slot & 63u;
+    uint32_t sr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)(sr + 1) * (sr + 2) / 2 <= t) ++sr;
+    while ((uint64_t)sr * (sr + 1) / 2 > t) --sr;
+    const uint32_t sc = t - (uint32_t)((uint64_t)sr * (sr + 1) / 2);
+    const uint32_t R = sr * 8u + (within >> 3), C = sc * 8u + (within & 7u);
+    if (C > R) return;
+    c = c0 + C;
+    i = c0 + R;
+    if (i > nblk || c >= nblk) return;
+  } else {
+    c = c0 + blockIdx.y;
+    i = c + blockIdx.x;
+    if (i > nblk) return;
+  }
   const int rows = (i == nblk) ? 1 : NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -820,7 +839,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   static const bool bulk_full = getenv("BA_HIP_BULK_FULL") != nullptr;
   static const bool panel64 = getenv("BA_HIP_PANEL64") != nullptr;
   static const uint32_t bulk_full_m =
-      getenv("BA_HIP_BULK_FULL_M") ? (uint32_t)atoi(getenv("BA_HIP_BULK_FULL_M")) : 0xffffffffu;
+      getenv("BA_HIP_BULK_FULL_M") ? (uint32_t)atoi(getenv("BA_HIP_BULK_FULL_M")) : 128u;
   hipStream_t s0 = e->stream, s1 = no_lookahead ? e->stream : e->stream2;
   const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
   while (e->ev_panel.size() < npanels) {
@@ -836,7 +855,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   auto step_update = [&](uint32_t c0, uint32_t ncols, uint32_t kb0, uint32_t kb1) {
     if (panel64)
       hipLaunchKernelGGL(k_update2<false>, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, (const double*)dsgn);
+                         kb0, kb1, (const double*)dsgn, 0);
     else
       hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
                          kb0, kb1, dsgn, opbuf, e->flags.p);
@@ -871,15 +890,20 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
       e->prof_begin(e->ev_syrk, s1);
-      // early panels: the bulk update outweighs the serial chain it overlaps — run it at full
-      // occupancy; later the chain is the bottleneck and the capped variant leaves it room
-      const bool bulk_heavy = (nblk - a_end) >= bulk_full_m;
+      // 1-D XCD-aware launch over the 8x8 super-blocks of the (m + 1) x m lower-triangular
+      // tile region.  Large trailing matrices (the serial chain is negligible beside them):
+      // full occupancy; otherwise the capped variant leaves the chain room.
+      const uint32_t m = nblk - a_end;
+      const uint32_t nsr = (m + 1 + 7) / 8;
+      const uint32_t nsb = nsr * (nsr + 1) / 2;
+      const uint32_t grid1 = ((nsb + 7) / 8) * 8 * 64;
+      const bool bulk_heavy = m >= bulk_full_m;
       if (no_lookahead || bulk_full || bulk_heavy)
-        hipLaunchKernelGGL(k_update2<false>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
-                           ld, nblk, a_end, J, Jend, (const double*)dsgn);
+        hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
+                           (const double*)dsgn, 1);
       else
-        hipLaunchKernelGGL(k_update2<true>, dim3(nblk - a_end + 1, nblk - a_end), dim3(256), 0, s1, dA,
-                           ld, nblk, a_end, J, Jend, (const double*)dsgn);
+        hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
+                           (const double*)dsgn, 1);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
