@@ -112,6 +112,7 @@ struct Engine {
   DBuf<uint32_t> pair_ptr;               // [n_pairs+1] (64-bit offsets split? entries < 2^32 assumed)
   DBuf<uint2> pair_ij;
   DBuf<uint2> pair_ent;                  // (rowA, rowB)
+  DBuf<double> packed;                   // packed lower triangle + rhs row (all-reduce staging)
   DBuf<uint32_t> pose_rows;              // [2*(Pact+1)]: pose-major J-slot ptr | incidence ptr
   DBuf<uint32_t> prhs_ptr;               // [Pact+1]
   DBuf<uint2> prhs_ent;                  // (row, scalar index)
@@ -183,7 +184,9 @@ int launch_begin_solve(Engine* e);                     // x_s from x_w
 int launch_end_solve(Engine* e);                       // x_w from x_s
 int launch_residuals(Engine* e, int mode);             // mode 0: errors for the median; 1: EvaluateResiduals
 int launch_landmarks(Engine* e, double c_huber, int use_robust);  // Jacobians, V, W, rows
-int launch_gather_S(Engine* e);                        // pair gather -> A, rhs row, masks
+int launch_gather_S(Engine* e);
+int launch_pack_lower(Engine* e, int unpack);
+size_t packed_lower_count(uint32_t n_pad);                        // pair gather -> A, rhs row, masks
 int launch_backsub(Engine* e);                         // delta_l
 int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norms2_host);
 int launch_apply_step(Engine* e);                      // state[cur] -> state[1-cur]

@@ -547,7 +547,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
   REL(obs_jrow_m); REL(obs_jrow_r); REL(obs_wrow_m); REL(obs_first); REL(lm_wrow_r);
   REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent);
-  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows);
+  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
@@ -768,9 +768,14 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   if (e->allreduce && e->nranks > 1) {
     // S (lower storage) with its rhs row, and the unreduced rhs_p, are sums over the
     // landmark shards: one all-reduce each over xGMI.
+    // The message is the packed lower triangle + rhs row (half of the square storage).
+    const size_t cnt = packed_lower_count(st.ld);
+    BAE_HIP(e->packed.alloc(cnt));
+    if ((rc = launch_pack_lower(e, 0))) return rc;
     BAE_HIP(hipStreamSynchronize(e->stream));
-    if (e->allreduce(e->allreduce_ctx, e->A.p, (size_t)(st.ld + 1) * st.ld, 0) != 0)
+    if (e->allreduce(e->allreduce_ctx, e->packed.p, cnt, 0) != 0)
       return e->fail_msg("allreduce hook failed");
+    if ((rc = launch_pack_lower(e, 1))) return rc;
     if (e->allreduce(e->allreduce_ctx, e->rhs_p.p, st.ld, 0) != 0)
       return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpyAsync(e->rhs_sc.p, e->A.p + (size_t)st.ld * st.ld, (size_t)st.n * sizeof(double),

@@ -208,6 +208,43 @@ k_gather_rhs(uint32_t npose, const uint32_t* __restrict__ prhs_ptr,
   (void)npose;
 }
 
+// Lower storage of S at 64-tile granularity (row r: columns 0 .. 64 (r/64 + 1) - 1, i.e. the
+// diagonal tiles in full — the 6x6 diagonal blocks are stored with both triangles) + the rhs
+// row  <->  packed array: halves the all-reduce message of the landmark-sharded path.
+// Row r of tile row t = r / 64 sits at 64^2 t (t+1) / 2 + (r % 64) 64 (t+1); the rhs row
+// (r == n_pad) behind the matrix.  grid = (column chunks of 1024, n_pad + 1 rows).
+__global__ void __launch_bounds__(256)
+k_pack_lower(double* __restrict__ A, uint32_t ld, uint32_t n_pad, double* __restrict__ packed, int unpack) {
+  const uint32_t r = blockIdx.y;
+  const uint32_t t = r >> 6;
+  const uint32_t len = (r == n_pad) ? n_pad : 64u * (t + 1);
+  const uint32_t c0 = blockIdx.x * 1024u;
+  if (c0 >= len) return;
+  double* row = A + (size_t)r * ld;
+  double* prow = packed + (size_t)4096 * ((size_t)t * (t + 1) / 2) + (size_t)(r & 63u) * 64u * (t + 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t c = c0 + k * 256u + threadIdx.x;
+    if (c < len) {
+      if (unpack) row[c] = prow[c];
+      else prow[c] = row[c];
+    }
+  }
+}
+
+size_t packed_lower_count(uint32_t n_pad) {
+  const size_t nblk = n_pad / 64;
+  return (size_t)4096 * (nblk * (nblk + 1) / 2) + n_pad;
+}
+
+int launch_pack_lower(Engine* e, int unpack) {
+  const uint32_t n_pad = e->st.ld;
+  hipLaunchKernelGGL(k_pack_lower, dim3((n_pad + 1023) / 1024, n_pad + 1), dim3(256), 0, e->stream, e->A.p,
+                     e->st.ld, n_pad, e->packed.p, unpack);
+  BAE_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_gather_S(Engine* e) {
   const Structure& st = e->st;
   const uint32_t n = st.n, ld = st.ld, n_pad = ld;

@@ -9,11 +9,14 @@ HBM: linearise (residuals, Huber median, Jacobians, V/W, gather S and rhs) -> de
 Cholesky solve -> landmark back-substitution -> EvaluateResiduals -> ApplyUpdate ->
 EvaluateResiduals -> accept / roll back.  Exit tests are disabled (fixed step count).
 
-Workload at N = 1: BASELINE.json configs[1] — 1k poses / 100k landmarks / 1M reprojection
-residuals, pinhole camera, inverse-depth landmarks (LmSize = 1).  For N > 1 the SAME scene
-is sharded by landmark across the ranks (every rank holds all poses); the reduced pose
-system S, its right-hand side and a few scalars/histograms are summed with RCCL
-all-reduces over xGMI through the engine's all-reduce hook ("scaling": "strong").
+Workload (default, `--config 3`): the scene BASELINE.json's metric is quoted on — configs[3],
+10k poses / 1M landmarks / 10M reprojection residuals, pinhole camera, inverse-depth landmarks
+(LmSize = 1), n = 59 988 reduced unknowns; it fits one MI355X (S is 28.8 GB of the 288 GB).
+`--config 1` selects configs[1] (1k poses / 100k landmarks / 1M residuals).  For N > 1 the SAME
+scene is sharded by landmark across the ranks (every rank holds all poses); the reduced pose
+system S (packed lower triangle), its right-hand side and a few scalars/histograms are
+summed with RCCL all-reduces over xGMI through the engine's all-reduce hook
+("scaling": "strong").
 
 Rank 0 prints one JSON line with the driver's contract keys plus `roofline` (dominant
 kernel, measured live with HIP events on the engine's stream) and `cpu_baseline` (the
@@ -76,7 +79,7 @@ def gn_step(eng):
 
 def cpu_baseline(sc, lm_dim):
     """The oracle (CPU restatement of the reference, 1 thread as the reference runs its
-    projection loop serially, BundleAdjuster.cpp:1345-1347) on ONE iteration of the scene."""
+    projection loop serially, BundleAdjuster.cpp:1345-1347) on ONE iteration of the scene `sc`."""
     from oracle import pyoracle as po
     po.build()
     ba = po.OracleBundleAdjuster(lm_dim, 6)
@@ -102,14 +105,26 @@ def cpu_baseline(sc, lm_dim):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--poses", type=int, default=1000)
-    ap.add_argument("--landmarks", type=int, default=100000)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=3, choices=[1, 3],
+                    help="BASELINE.json configs index: 3 = 10k poses / 1M landmarks / 10M residuals "
+                         "(the metric's scene, default), 1 = 1k / 100k / 1M")
+    ap.add_argument("--poses", type=int, default=None)
+    ap.add_argument("--landmarks", type=int, default=None)
     ap.add_argument("--obs-per-landmark", type=int, default=10)
     ap.add_argument("--lm-dim", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    preset = {1: (1000, 100000, 20, 3), 3: (10000, 1000000, 5, 1)}[args.config]
+    if args.poses is None:
+        args.poses = preset[0]
+    if args.landmarks is None:
+        args.landmarks = preset[1]
+    if args.steps is None:
+        args.steps = preset[2]
+    if args.warmup is None:
+        args.warmup = preset[3]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,7 +191,7 @@ def main():
         # per launch), null if the summary is absent
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg%d.json" % args.config)) as f:
                 traffic = json.load(f)["kernels"]["bae::k_update2<true>"]["traffic_bytes_per_launch_corrected"]
         except (OSError, KeyError, ValueError):
             pass
@@ -193,15 +208,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: %d poses / %d landmarks / %d reprojection "
+            "config": {"workload": "BASELINE.json configs[%d]: %d poses / %d landmarks / %d reprojection "
                                    "residuals, pinhole, LmSize=%d, PoseSize=6, Gauss-Newton (no dogleg), "
-                                   "2 anchor poses inactive" % (P, L, O, lm_dim),
+                                   "2 anchor poses inactive" % (args.config, P, L, O, lm_dim),
                        "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
                        "parallelism": "landmark-sharded x%d, all-reduce of S" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_update2 (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)",
                          "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc, bytes per launch)",
+                         "traffic_source": "profiles/r01_pmc_traffic_cfg%d.json (rocprofv3 --pmc, bytes per launch)" % args.config,
                          "flops_per_launch": ks.syrk_flops / max(ks.syrk_launches, 1),
                          "launches": ks.syrk_launches,
                          "avg_launch_us": 1e3 * ks.syrk_ms / max(ks.syrk_launches, 1)},
@@ -217,7 +232,27 @@ def main():
             "final_error": err,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sc, lm_dim)
+            if P <= 1000:
+                out["cpu_baseline"] = cpu_baseline(sc, lm_dim)
+            else:
+                # One oracle iteration of THIS scene needs a dense n = 60k LDL^T on one core
+                # (~72 TFLOP: over an hour).  Bounded sample: one oracle iteration of the
+                # 10x smaller configs[1] scene (same generator, same densities); its O(N)
+                # phases are scaled by the residual count, its dense solve by n^3.
+                small = scene.make_scene(1000, 100000, K, lm_dim=lm_dim, seed=2)
+                cb = cpu_baseline(small, lm_dim)
+                ph = cb["phases_s"]
+                lin = ph["total"] - ph["solve"]
+                f_lin = float(O) / (100000 * K)
+                f_sol = (float(n) / (6.0 * 998)) ** 3
+                est = lin * f_lin + ph["solve"] * f_sol
+                cb["sample"] = ("1 Gauss-Newton iteration of the configs[1] scene (1k poses / 100k landmarks / "
+                                "1M residuals, %.1f s measured), extrapolated to this scene: linear phases "
+                                "x%.0f (residual count), dense LDL^T x%.0f (n^3) -> %.0f s per iteration"
+                                % (ph["total"], f_lin, f_sol, est))
+                cb["measured_sample_iterations_per_sec"] = cb["value"]
+                cb["value"] = 1.0 / est
+                out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
