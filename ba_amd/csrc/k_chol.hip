@@ -32,7 +32,6 @@
 namespace bae {
 
 static const int NB = 64;        // tile size
-static const int KOUT = 4;       // tiles per outer panel
 static const int LDT = NB + 2;   // LDS row stride (doubles): conflict-free MFMA operand reads
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -841,6 +840,11 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   static const uint32_t bulk_full_m =
       getenv("BA_HIP_BULK_FULL_M") ? (uint32_t)atoi(getenv("BA_HIP_BULK_FULL_M")) : 128u;
   hipStream_t s0 = e->stream, s1 = no_lookahead ? e->stream : e->stream2;
+  // Tiles per outer panel: every panel costs one read-modify-write pass over the trailing
+  // matrix (8 n^3 / (3 * 64 KOUT) bytes in total), the serial chain inside a panel grows with
+  // KOUT.  Small systems are chain-bound (KOUT = 4), large ones HBM-bound on the C tiles.
+  static const uint32_t kout_env = getenv("BA_HIP_KOUT") ? (uint32_t)atoi(getenv("BA_HIP_KOUT")) : 0;
+  const uint32_t KOUT = kout_env ? kout_env : (nblk >= 256 ? 8u : 4u);
   const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
   while (e->ev_panel.size() < npanels) {
     hipEvent_t a, b;

@@ -53,7 +53,10 @@ def torch_allreduce_hook(dist, device="cuda"):
         try:
             if device == "cuda":
                 t = torch.as_tensor(_DevArray(ptr, count, "<f8" if dtype == 0 else "<i8"), device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                # S of the 10k-pose scene is a 14 GB message: hand it to RCCL in 4 GB pieces
+                step = 1 << 29
+                for lo in range(0, count, step):
+                    dist.all_reduce(t[lo:lo + step], op=dist.ReduceOp.SUM)
                 torch.cuda.synchronize()
             else:
                 a = _host_view(ptr, count, dtype)
