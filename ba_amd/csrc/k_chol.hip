@@ -334,7 +334,7 @@ static const int LDK2 = KC2 + 2;
 // two such workgroups fit on a CU, which always leaves the 44 KB + one wave per SIMD that a
 // k_panel64 block of the concurrent serial chain needs.
 template <bool BULK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BULK ? 2 : 4)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
           uint32_t kb1, const double* __restrict__ dsgn, int swz) {
   __shared__ double X[2][NB][LDK2];
@@ -369,17 +369,15 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   const int li = lane & 15, lk = lane >> 4;
   const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
   double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
-  // C tile -> accumulators (rows past `rows` read row 0: never stored)
+  // The accumulators start at zero and the C tile is fetched after the K loop: no MFMA of the
+  // loop depends on a global load (a wait for the C tile, needed by the first MFMA, would be
+  // re-executed in every iteration and serialise the operand prefetch), and the registers go
+  // to a second prefetch set instead.
   double4_t acc[2][2];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = rb + 16 * ti + lk + 4 * reg;
-        acc[ti][tj][reg] = Aic[(size_t)(r < rows ? r : 0) * ld + cb + 16 * tj + li];
-      }
+    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (double4_t){0.0, 0.0, 0.0, 0.0};
   // staging: thread t moves rows sr and sr + 32, columns sc, sc + 1 of a 64 x 16 chunk
   const int sr = tid >> 3, sc = (tid & 7) * 2;
   const double* Xg0 = A + ((size_t)i * NB + (sr < rows ? sr : 0)) * ld + sc;
@@ -388,53 +386,75 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   const double* Yg1 = Yg0 + (size_t)32 * ld;
   const double xm0 = sr < rows ? 1.0 : 0.0, xm1 = sr + 32 < rows ? 1.0 : 0.0;
   const uint32_t k_begin = kb0 * NB, k_end = kb1 * NB;
-  const int nchunk = (int)((k_end - k_begin) / KC2);
-  double2 px0, px1, py0, py1, ps;
-  auto gload = [&](uint32_t k0) {
-    px0 = *reinterpret_cast<const double2*>(Xg0 + k0);
-    px1 = *reinterpret_cast<const double2*>(Xg1 + k0);
-    py0 = *reinterpret_cast<const double2*>(Yg0 + k0);
-    py1 = *reinterpret_cast<const double2*>(Yg1 + k0);
-    ps = *reinterpret_cast<const double2*>(dsgn + k0 + sc);
-  };
-  auto sstore = [&](int b) {
-    X[b][sr][sc] = px0.x * xm0; X[b][sr][sc + 1] = px0.y * xm0;
-    X[b][sr + 32][sc] = px1.x * xm1; X[b][sr + 32][sc + 1] = px1.y * xm1;
-    Y[b][sr][sc] = -ps.x * py0.x; Y[b][sr][sc + 1] = -ps.y * py0.y;
-    Y[b][sr + 32][sc] = -ps.x * py1.x; Y[b][sr + 32][sc + 1] = -ps.y * py1.y;
-  };
-  gload(k_begin);
-  sstore(0);
-  if (nchunk > 1) gload(k_begin + KC2);
+  const int nchunk = (int)((k_end - k_begin) / KC2);  // a multiple of 4 (K is a multiple of 64)
+  // two register sets: a chunk is loaded two iterations (~2 x 4096 MFMA-pipe cycles at four
+  // waves per SIMD) before it is written to LDS
+  double2 px0[2], px1[2], py0[2], py1[2], ps[2];
+#define BAE_GLOAD(S, CH)                                                          \
+  {                                                                               \
+    const uint32_t k0_ = k_begin + (uint32_t)(CH) * KC2;                          \
+    px0[S] = *reinterpret_cast<const double2*>(Xg0 + k0_);                        \
+    px1[S] = *reinterpret_cast<const double2*>(Xg1 + k0_);                        \
+    py0[S] = *reinterpret_cast<const double2*>(Yg0 + k0_);                        \
+    py1[S] = *reinterpret_cast<const double2*>(Yg1 + k0_);                        \
+    ps[S] = *reinterpret_cast<const double2*>(dsgn + k0_ + sc);                   \
+  }
+#define BAE_SSTORE(B, S)                                                          \
+  {                                                                               \
+    X[B][sr][sc] = px0[S].x * xm0; X[B][sr][sc + 1] = px0[S].y * xm0;             \
+    X[B][sr + 32][sc] = px1[S].x * xm1; X[B][sr + 32][sc + 1] = px1[S].y * xm1;   \
+    Y[B][sr][sc] = -ps[S].x * py0[S].x; Y[B][sr][sc + 1] = -ps[S].y * py0[S].y;   \
+    Y[B][sr + 32][sc] = -ps[S].x * py1[S].x; Y[B][sr + 32][sc + 1] = -ps[S].y * py1[S].y; \
+  }
+#define BAE_MMA(B)                                                                \
+  _Pragma("unroll") for (int ks = 0; ks < KC2 / 4; ++ks) {                        \
+    const double a0 = X[B][rb + li][4 * ks + lk];                                 \
+    const double a1 = X[B][rb + 16 + li][4 * ks + lk];                            \
+    const double b0 = Y[B][cb + li][4 * ks + lk];                                 \
+    const double b1 = Y[B][cb + 16 + li][4 * ks + lk];                            \
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0); \
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0); \
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0); \
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0); \
+  }
+  BAE_GLOAD(0, 0);
+  BAE_GLOAD(1, 1);
+  BAE_SSTORE(0, 0);
+  BAE_GLOAD(0, 2);
   __syncthreads();
-  for (int kc = 0; kc < nchunk; ++kc) {
-    const int b = kc & 1;
-    if (kc + 1 < nchunk) sstore(b ^ 1);
-    if (kc + 2 < nchunk) gload(k_begin + (uint32_t)(kc + 2) * KC2);
-#pragma unroll
-    for (int ks = 0; ks < KC2 / 4; ++ks) {
-      const double a0 = X[b][rb + li][4 * ks + lk];
-      const double a1 = X[b][rb + 16 + li][4 * ks + lk];
-      const double b0 = Y[b][cb + li][4 * ks + lk];
-      const double b1 = Y[b][cb + 16 + li][4 * ks + lk];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
+  for (int kc = 0; kc < nchunk; kc += 2) {
+    // LDS stage 0 holds chunk kc, set 1 chunk kc + 1, set 0 (in flight) chunk kc + 2
+    BAE_SSTORE(1, 1);
+    if (kc + 3 < nchunk) BAE_GLOAD(1, kc + 3);
+    BAE_MMA(0);
+    __syncthreads();
+    if (kc + 2 < nchunk) BAE_SSTORE(0, 0);
+    if (kc + 4 < nchunk) BAE_GLOAD(0, kc + 4);
+    BAE_MMA(1);
     __syncthreads();
   }
+#undef BAE_GLOAD
+#undef BAE_SSTORE
+#undef BAE_MMA
+  // epilogue: C - X D Y^T  (rows past `rows` are not touched)
   const bool diag = (i == c);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
+    for (int tj = 0; tj < 2; ++tj) {
+      double cv[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        cv[reg] = Aic[(size_t)(r < rows ? r : 0) * ld + cb + 16 * tj + li];
+      }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = rb + 16 * ti + lk + 4 * reg;
         const int cc = cb + 16 * tj + li;
-        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = acc[ti][tj][reg];
+        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = cv[reg] + acc[ti][tj][reg];
       }
+    }
 }
 
 // ---------------------------------------------------------------------------------
