@@ -78,7 +78,9 @@ __device__ long long g_clk[16];
 
 __global__ void __launch_bounds__(256, 2)
 k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
-          double* __restrict__ dsgn_out, double* __restrict__ linvT_out, int* __restrict__ status) {
+          double* __restrict__ dsgn_out, double* __restrict__ linvT_out, int* __restrict__ colneg,
+          int* __restrict__ status) {
+  __shared__ int neg_s;
   __shared__ double T[NB][LDT];        // the diagonal tile: A_jj -> L_jj (upper part zero)
   __shared__ double Md[4][16][LDM];    // M_cc = L_cc^-1, c = 0..3
   __shared__ double dv[NB];            // 1 / L[j][j]
@@ -233,6 +235,7 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
       }
       PCLK(2 + pb);
     }
+    if (lane == 0) neg_s = negmask != 0 ? 1 : 0;
     {
       // 1 / L[j][j]; a zero, negative-zero, NaN or Inf pivot shows up on the diagonal
       const double q = T[lane][lane];
@@ -311,6 +314,7 @@ k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
   }
   if (invert) {
     if (tid < NB) dsgn_out[(size_t)jj * NB + tid] = sg[tid];
+    if (tid == 0) colneg[jj] = neg_s;
     if (tid == 0 && bad_s) atomicExch(status, 1);
   }
   PCLK(9);
@@ -336,7 +340,7 @@ static const int LDK2 = KC2 + 2;
 template <bool BULK>
 __global__ void __launch_bounds__(256, BULK ? 2 : 4)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
-          uint32_t kb1, const double* __restrict__ dsgn, int swz) {
+          uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, int swz) {
   __shared__ double X[2][NB][LDK2];
   __shared__ double Y[2][NB][LDK2];
   __shared__ double pad_[BULK ? 2432 : 1];
@@ -390,6 +394,11 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   // two register sets: a chunk is loaded two iterations (~2 x 4096 MFMA-pipe cycles at four
   // waves per SIMD) before it is written to LDS
   double2 px0[2], px1[2], py0[2], py1[2], ps[2];
+  // `plain`: a full tile and no negative pivot in the K range (every SPD system) — the staged
+  // operands are then plain copies, no per-element multiplies in the loop.  The accumulators
+  // collect +X D Y^T; the epilogue subtracts.
+  bool plain = rows == NB;
+  for (uint32_t kb = kb0; kb < kb1; ++kb) plain = plain && (colneg[kb] == 0);
 #define BAE_GLOAD(S, CH)                                                          \
   {                                                                               \
     const uint32_t k0_ = k_begin + (uint32_t)(CH) * KC2;                          \
@@ -400,11 +409,16 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
     ps[S] = *reinterpret_cast<const double2*>(dsgn + k0_ + sc);                   \
   }
 #define BAE_SSTORE(B, S)                                                          \
-  {                                                                               \
+  if (plain) {                                                                    \
+    X[B][sr][sc] = px0[S].x; X[B][sr][sc + 1] = px0[S].y;                         \
+    X[B][sr + 32][sc] = px1[S].x; X[B][sr + 32][sc + 1] = px1[S].y;               \
+    Y[B][sr][sc] = py0[S].x; Y[B][sr][sc + 1] = py0[S].y;                         \
+    Y[B][sr + 32][sc] = py1[S].x; Y[B][sr + 32][sc + 1] = py1[S].y;               \
+  } else {                                                                        \
     X[B][sr][sc] = px0[S].x * xm0; X[B][sr][sc + 1] = px0[S].y * xm0;             \
     X[B][sr + 32][sc] = px1[S].x * xm1; X[B][sr + 32][sc + 1] = px1[S].y * xm1;   \
-    Y[B][sr][sc] = -ps[S].x * py0[S].x; Y[B][sr][sc + 1] = -ps[S].y * py0[S].y;   \
-    Y[B][sr + 32][sc] = -ps[S].x * py1[S].x; Y[B][sr + 32][sc + 1] = -ps[S].y * py1[S].y; \
+    Y[B][sr][sc] = ps[S].x * py0[S].x; Y[B][sr][sc + 1] = ps[S].y * py0[S].y;     \
+    Y[B][sr + 32][sc] = ps[S].x * py1[S].x; Y[B][sr + 32][sc + 1] = ps[S].y * py1[S].y; \
   }
 #define BAE_MMA(B)                                                                \
   _Pragma("unroll") for (int ks = 0; ks < KC2 / 4; ++ks) {                        \
@@ -428,7 +442,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
     if (kc + 3 < nchunk) BAE_GLOAD(1, kc + 3);
     BAE_MMA(0);
     __syncthreads();
-    if (kc + 2 < nchunk) BAE_SSTORE(0, 0);
+    if (kc + 2 < nchunk) { BAE_SSTORE(0, 0); }
     if (kc + 4 < nchunk) BAE_GLOAD(0, kc + 4);
     BAE_MMA(1);
     __syncthreads();
@@ -452,7 +466,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
       for (int reg = 0; reg < 4; ++reg) {
         const int r = rb + 16 * ti + lk + 4 * reg;
         const int cc = cb + 16 * tj + li;
-        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = cv[reg] + acc[ti][tj][reg];
+        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = cv[reg] - acc[ti][tj][reg];
       }
     }
 }
@@ -482,6 +496,7 @@ struct TileLds {
   double sg[NB];            // pivot signs d_j
   __attribute__((aligned(16))) double colbuf[2][NB];  // column j of L, for broadcast reads
   int bad;
+  int neg;                  // any negative pivot in this tile
 };
 
 // wave 0: factorise sh.T in place (see k_panel64 for the commentary of the chain), then the
@@ -570,6 +585,7 @@ __device__ __forceinline__ void factor_tile_wave0(TileLds& sh, int lane) {
         }
     }
   }
+  if (lane == 0) sh.neg = negmask != 0 ? 1 : 0;
   {
     const double q = sh.T[lane][lane];
     if (!(q > 0.0 && q < 1e150)) sh.bad = 1;  // zero, NaN or Inf pivot
@@ -629,7 +645,7 @@ __device__ __forceinline__ void subst_rows(double4_t R[4], const double op[NOPV]
 __global__ void __launch_bounds__(256, 2)
 k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
               uint32_t kb1, double* __restrict__ dsgn, double* __restrict__ opbuf,
-              int* __restrict__ status) {
+              int* __restrict__ colneg, int* __restrict__ status) {
   struct UpdLds { double X[2][NB][LDK2]; double Y[2][NB][LDK2]; };
   constexpr size_t kLds = sizeof(TileLds) > sizeof(UpdLds) ? sizeof(TileLds) : sizeof(UpdLds);
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
@@ -738,6 +754,7 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
       ob[(size_t)v * 64 + lane] = subst_operand(sh, v, li, lk, true);
     }
     if (tid < NB) dsgn[(size_t)c0 * NB + tid] = sh.sg[tid];
+    if (tid == 0) colneg[c0] = sh.neg;
     if (tid == 0 && sh.bad) atomicExch(status, 1);
   }
 }
@@ -850,10 +867,12 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status) {
   (void)n;
   const uint32_t nblk = ld / NB;
-  BAE_HIP(e->invdiag.alloc((size_t)nblk * NB + (size_t)nblk * NB * NB + (size_t)nblk * NOPV * 64));
+  BAE_HIP(e->invdiag.alloc((size_t)nblk * NB + (size_t)nblk * NB * NB + (size_t)nblk * NOPV * 64 +
+                           (nblk + 1) / 2));
   double* dsgn = e->invdiag.p;                                  // pivot signs
   double* linvT = dsgn + (size_t)nblk * NB;                     // inverse-transposed diagonal tiles
   double* opbuf = linvT + (size_t)nblk * NB * NB;               // factor packets (k_step_update)
+  int* colneg = reinterpret_cast<int*>(opbuf + (size_t)nblk * NOPV * 64);  // per tile column: any d_k < 0
   static const bool no_lookahead = getenv("BA_HIP_NO_LOOKAHEAD") != nullptr;  // A/B switches
   static const bool bulk_full = getenv("BA_HIP_BULK_FULL") != nullptr;
   static const bool panel64 = getenv("BA_HIP_PANEL64") != nullptr;
@@ -879,14 +898,14 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   auto step_update = [&](uint32_t c0, uint32_t ncols, uint32_t kb0, uint32_t kb1) {
     if (panel64)
       hipLaunchKernelGGL(k_update2<false>, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, (const double*)dsgn, 0);
+                         kb0, kb1, (const double*)dsgn, (const int*)colneg, 0);
     else
       hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, dsgn, opbuf, e->flags.p);
+                         kb0, kb1, dsgn, opbuf, colneg, e->flags.p);
   };
   if (!panel64)  // factor packet of tile 0 (nothing to update: one workgroup)
     hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
-                       e->flags.p);
+                       colneg, e->flags.p);
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
   // overlapping the serial factorisation of the next panel.
@@ -897,7 +916,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     for (uint32_t jj = J; jj < Jend; ++jj) {
       if (panel64)
         hipLaunchKernelGGL(k_panel64, dim3(nblk - jj + 1), dim3(256), 0, s0, dA, ld, jj, nblk, dsgn,
-                           linvT, e->flags.p);
+                           linvT, colneg, e->flags.p);
       else
         hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk,
                            (const double*)opbuf);
@@ -924,10 +943,10 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
       const bool bulk_heavy = m >= bulk_full_m;
       if (no_lookahead || bulk_full || bulk_heavy)
         hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, 1);
+                           (const double*)dsgn, (const int*)colneg, 1);
       else
         hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, 1);
+                           (const double*)dsgn, (const int*)colneg, 1);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
