@@ -54,7 +54,8 @@ struct Impl : Iface {
     opt.enable_auto_regularization = o->enable_auto_regularization != 0;
     opt.use_robust_norm_for_proj_residuals = o->use_robust_norm_for_proj_residuals != 0;
     opt.use_robust_norm_for_inertial_residuals = o->use_robust_norm_for_inertial_residuals != 0;
-    opt.write_reduced_camera_matrix = o->write_reduced_camera_matrix != 0;
+    opt.write_reduced_camera_matrix = o->write_reduced_camera_matrix >= 2;
+    opt.keep_reduced_system = o->write_reduced_camera_matrix != 0;
     opt.device = o->device;
     ba.Init(opt);
   }
@@ -162,7 +163,7 @@ void ba_default_options(ba_options* o) {
   o->enable_auto_regularization = d.enable_auto_regularization;
   o->use_robust_norm_for_proj_residuals = d.use_robust_norm_for_proj_residuals;
   o->use_robust_norm_for_inertial_residuals = d.use_robust_norm_for_inertial_residuals;
-  o->write_reduced_camera_matrix = d.write_reduced_camera_matrix;
+  o->write_reduced_camera_matrix = d.write_reduced_camera_matrix ? 2 : (d.keep_reduced_system ? 1 : 0);
   o->device = d.device;
 }
 ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim) {

@@ -73,6 +73,7 @@ struct Options {  // reference BundleAdjuster.h:72-107, same names and defaults
   bool use_triangular_matrices = true;
   bool use_sparse_solver = true;  // accepted; the engine always factorises densely
   bool write_reduced_camera_matrix = false;
+  bool keep_reduced_system = false;  // extension: keep S readable (GetReducedSystem taps) without writing files
   bool calculate_calibration_marginals = false;
   bool use_per_pose_cam_params = false;
   bool regularize_biases_in_batch = true;
@@ -385,6 +386,7 @@ class BundleAdjuster {
   }
   bool UploadProblem();
   void ComputeMasks(std::vector<uint16_t>& masks);
+  void WriteReducedCameraMatrix();
   bool SolveInternal(const Scalar gn_damping, const bool error_increase_allowed, const bool use_dogleg);
   bool DownloadState();
 
@@ -445,7 +447,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   o.use_robust_norm_for_proj_residuals = options_.use_robust_norm_for_proj_residuals;
   o.use_robust_norm_for_inertial_residuals = options_.use_robust_norm_for_inertial_residuals;
   o.use_triangular_matrices = options_.use_triangular_matrices;
-  o.keep_reduced_system = options_.write_reduced_camera_matrix;  // debug tap (reference :600-627)
+  o.keep_reduced_system = options_.write_reduced_camera_matrix || options_.keep_reduced_system;  // debug tap (reference :600-627)
   o.gyro_sigma = options_.gyro_sigma; o.accel_sigma = options_.accel_sigma;
   o.gyro_bias_sigma = options_.gyro_bias_sigma; o.accel_bias_sigma = options_.accel_bias_sigma;
   if (!Check(ba_hip_set_options(engine_, &o), "ba_hip_set_options")) return false;
@@ -496,6 +498,34 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
 }
 
 // Parameter masks (gauge handling), reference BundleAdjuster.cpp:1237-1330.
+// The reference's interchange dump (BundleAdjuster.cpp:600-606, Utils.h:66): the reduced
+// camera matrix s_ and the reduced right-hand side as CSV in Eigen's FullPrecision format
+// (", " between coefficients, one row per line) into s.txt and rhs.txt of the working
+// directory, so that a build of the original can be diffed against this one.  (The Jacobian
+// dumps j_pr.txt / j_l.txt / r_pr.txt of :608-616 are not produced: the Jacobians are never
+// materialised as matrices on the device.)
+template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
+void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::WriteReducedCameraMatrix() {
+  const uint32_t n = ba_hip_num_pose_params(engine_);
+  if (n == 0) return;
+  std::cerr << "Writing reduced camera matrix for " << n << " pose parameters and " << kCalibDim
+            << " calib  parameters " << std::endl;
+  std::vector<double> sm((size_t)n * n), rhs(n);
+  if (!Check(ba_hip_get_S(engine_, sm.data()), "ba_hip_get_S")) return;
+  if (!Check(ba_hip_get_rhs(engine_, rhs.data(), nullptr, nullptr), "ba_hip_get_rhs")) return;
+  if (FILE* f = std::fopen("s.txt", "w")) {
+    for (uint32_t r = 0; r < n; ++r) {
+      for (uint32_t c = 0; c < n; ++c) std::fprintf(f, c ? ", %.16g" : "%.16g", sm[(size_t)r * n + c]);
+      std::fputc('\n', f);
+    }
+    std::fclose(f);
+  }
+  if (FILE* f = std::fopen("rhs.txt", "w")) {
+    for (uint32_t r = 0; r < n; ++r) std::fprintf(f, "%.16g\n", rhs[r]);
+    std::fclose(f);
+  }
+}
+
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
 void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::ComputeMasks(std::vector<uint16_t>& masks) {
   // :1240-1259 — note the loop stops at the first inactive pose
@@ -689,6 +719,7 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     if (!Check(ba_hip_linearize(engine_, &built), "ba_hip_linearize")) return;  // BuildProblem .. Schur
     proj_error_ = built.proj_error; binary_error_ = built.binary_error;
     unary_error_ = built.unary_error; inertial_error_ = built.inertial_error;
+    if (options_.write_reduced_camera_matrix) WriteReducedCameraMatrix();  // :600-606
     iterations_run_++;
     const bool ok = SolveInternal(gn_damping, error_increase_allowed, options_.use_dogleg);
     ba_hip_get_timers(engine_, &last_timers_);

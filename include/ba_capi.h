@@ -25,7 +25,8 @@ typedef struct { /* ba::Options<double>, reference BundleAdjuster.h:72-107 */
   int32_t apply_results, use_dogleg, use_triangular_matrices, use_sparse_solver;
   int32_t regularize_biases_in_batch, enable_auto_regularization;
   int32_t use_robust_norm_for_proj_residuals, use_robust_norm_for_inertial_residuals;
-  int32_t write_reduced_camera_matrix; /* keeps S readable through ba_hip_get_S */
+  int32_t write_reduced_camera_matrix; /* 1: keep S readable through the taps; 2: also write s.txt / rhs.txt
+                                          (the reference's dump, BundleAdjuster.cpp:600-606) */
   int32_t device;
 } ba_options;
 

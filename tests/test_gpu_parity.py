@@ -454,6 +454,23 @@ def test_two_shards_equal_one(lm_dim):
     assert rel_err(lms, single.get_landmarks(L)) < 1e-9
 
 
+def test_reduced_camera_matrix_dump(tmp_path, monkeypatch):
+    """write_reduced_camera_matrix (BundleAdjuster.cpp:600-606): s.txt / rhs.txt in the
+    reference's CSV format reproduce the tapped S and rhs to the printed precision."""
+    sc = scene.make_scene(12, 40, 4, lm_dim=1, seed=11)
+    monkeypatch.chdir(tmp_path)
+    h = adjuster.BundleAdjuster(1, 6)
+    h.Init(hip_options(write_reduced_camera_matrix=2))
+    fill(h, sc)
+    h.Solve(1)
+    s = np.loadtxt(tmp_path / "s.txt", delimiter=",")
+    rhs = np.loadtxt(tmp_path / "rhs.txt", delimiter=",")
+    assert s.shape == h.S().shape and rel_err(s, h.S()) < 1e-15
+    assert rel_err(rhs, h.rhs()) < 1e-15
+    first = (tmp_path / "s.txt").read_text().splitlines()[0]
+    assert ", " in first and ";" not in first  # Utils.h:66 kLongCsvFmt
+
+
 # ---- full-size properties (BASELINE.json configs[1]) ---------------------------------------
 def test_config2_size_properties():
     """1k poses / 100k landmarks / 1M residuals: size-independent properties —
