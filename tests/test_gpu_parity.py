@@ -374,6 +374,19 @@ def test_cpp_application_runs_on_the_engine():
     assert "proj error" in r.stdout
 
 
+def test_pose_graph_application_with_interpolation_buffer():
+    """applications/unary_binary_imu_test: the shape of the reference's application of the same
+    name (BundleAdjuster<double,0,9,0>; odometry -> binary, position fixes -> unary, IMU via
+    InterpolationBufferT::GetRange -> AddImuResidual; Solve; GetPose) on synthetic streams."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ba_amd", "lib", "unary_binary_imu_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mean position error" in r.stdout
+
+
 # ---- landmark sharding (SURVEY.md §8e) on one device ------------------------------------------
 def _run_engine_steps(eng, iters, out, key):
     try:
