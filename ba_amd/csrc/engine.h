@@ -71,6 +71,9 @@ struct Structure {
   uint32_t n_pp_entries = 0;  // (pose, residual side) entries of the pose-pose scatter
   std::vector<int32_t> pose_opt, lm_opt;
   std::vector<uint32_t> obs_perm;  // sorted position -> residual id
+  // 64x64-tile pattern of S of THIS shard (nt x nt bytes, symmetric, nt = ld / 64): which tiles
+  // the gather lists and the pose-pose residuals can touch
+  std::vector<uint8_t> tile_nz;
 };
 
 struct Engine {
@@ -112,6 +115,9 @@ struct Engine {
   DBuf<uint32_t> pair_ptr;               // [n_pairs+1] (64-bit offsets split? entries < 2^32 assumed)
   DBuf<uint2> pair_ij;
   DBuf<uint2> pair_ent;                  // (rowA, rowB)
+  DBuf<uint8_t> nzL;                     // tile pattern of the factor L (nt x nt bytes, lower), see k_chol.hip
+  bool nzL_valid = false;
+  std::vector<uint8_t> nzL_host;         // host copy (flop accounting of the profiled launches)
   DBuf<double> packed;                   // packed lower triangle + rhs row (all-reduce staging)
   DBuf<uint32_t> pose_rows;              // [2*(Pact+1)]: pose-major J-slot ptr | incidence ptr
   DBuf<uint32_t> prhs_ptr;               // [Pact+1]
@@ -196,6 +202,8 @@ int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, b
 int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs);
 int launch_posepose_eval(Engine* e, ba_hip_errors* errs);
 int launch_posepose_jrhs(Engine* e, double* out);
-int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status);
+int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status,
+                   const uint8_t* nz_tiles);
+int factor_tile_pattern(Engine* e);
 
 }  // namespace bae

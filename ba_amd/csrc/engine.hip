@@ -348,6 +348,27 @@ static int build_structure(Engine* e) {
     }
   }
 
+  // ---- 64x64-tile pattern of S (for the tile-sparse factorisation) ---------------------------
+  {
+    const uint32_t nt = st.ld / 64, D = (uint32_t)e->pose_dim;
+    st.tile_nz.assign((size_t)nt * nt, 0);
+    auto mark = [&](uint32_t pi, uint32_t pj) {  // all tiles the D x D block (pi, pj) overlaps
+      const uint32_t r0 = pi * D / 64, r1 = (pi * D + D - 1) / 64;
+      const uint32_t c0 = pj * D / 64, c1 = (pj * D + D - 1) / 64;
+      for (uint32_t r = r0; r <= r1; ++r)
+        for (uint32_t c = c0; c <= c1; ++c) { st.tile_nz[(size_t)r * nt + c] = 1; st.tile_nz[(size_t)c * nt + r] = 1; }
+    };
+    for (uint32_t p = 0; p < st.Pact; ++p) mark(p, p);
+    for (const uint2& ij : pair_ij) mark(ij.x, ij.y);
+    for (uint32_t s = 0; s < nres; ++s) {
+      const int32_t o1 = st.pose_opt[res_p1[s]];
+      const int32_t o2 = res_p2[s] != 0xffffffffu ? st.pose_opt[res_p2[s]] : -1;
+      if (o1 >= 0 && o2 >= 0) mark((uint32_t)o1, (uint32_t)o2);
+    }
+    for (uint32_t t = 0; t < nt; ++t) st.tile_nz[(size_t)t * nt + t] = 1;  // padding identity
+    e->nzL_valid = false;
+  }
+
   // ---- upload ------------------------------------------------------------------------------
   int rc;
 #define UP(buf, vec) if ((rc = upload(e, e->buf, vec))) return rc
@@ -547,7 +568,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
   REL(obs_jrow_m); REL(obs_jrow_r); REL(obs_wrow_m); REL(obs_first); REL(lm_wrow_r);
   REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent);
-  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed);
+  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed); REL(nzL);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
@@ -805,7 +826,8 @@ int ba_hip_solve_gn(ba_hip_engine* h) {
       BAE_HIP(hipMemcpyAsync(e->A_keep.p, e->A.p, (size_t)st.ld * st.ld * sizeof(double),
                              hipMemcpyDeviceToDevice, e->stream));
     }
-    if ((rc = cholesky_solve(e, e->A.p, st.n, st.ld, e->gn_p.p, &status))) return rc;
+    if (!e->nzL_valid && (rc = factor_tile_pattern(e))) return rc;
+    if ((rc = cholesky_solve(e, e->A.p, st.n, st.ld, e->gn_p.p, &status, e->nzL.p))) return rc;
     e->factored = true;
   }
   e->timers.solve = t.stop_ms();
@@ -1053,6 +1075,7 @@ int ba_hip_device_buffer(ba_hip_engine* h, int which, void** dev_ptr, size_t* nu
 int ba_hip_set_allreduce(ba_hip_engine* h, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) {
   ENG(h);
   e->allreduce = fn; e->allreduce_ctx = ctx; e->rank = rank; e->nranks = nranks < 1 ? 1 : nranks;
+  e->nzL_valid = false;  // the tile pattern of S is the union over the shards
   return 0;
 }
 
@@ -1071,7 +1094,7 @@ int ba_hip_dense_solve(ba_hip_engine* h, uint32_t n, const double* a_lower, cons
   BAE_HIP(e->flags.alloc(16));
   BAE_HIP(hipMemcpy(dA.p, A.data(), A.size() * 8, hipMemcpyHostToDevice));
   int status = 0;
-  int rc = cholesky_solve(e, dA.p, n, ld, dx.p, &status);
+  int rc = cholesky_solve(e, dA.p, n, ld, dx.p, &status, nullptr);  // arbitrary matrix: dense
   if (rc == 0) {
     std::vector<double> xx(ld);
     hipError_t err = hipMemcpy(xx.data(), dx.p, (size_t)ld * 8, hipMemcpyDeviceToHost);

@@ -28,6 +28,8 @@
 // BundleAdjuster.cpp:756-759).
 #include "engine.h"
 #include <cstdlib>
+#include <algorithm>
+#include <vector>
 
 namespace bae {
 
@@ -340,9 +342,11 @@ static const int LDK2 = KC2 + 2;
 template <bool BULK>
 __global__ void __launch_bounds__(256, BULK ? 2 : 4)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
-          uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, int swz) {
+          uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, int swz,
+          const uint8_t* __restrict__ nz) {
   __shared__ double X[2][NB][LDK2];
   __shared__ double Y[2][NB][LDK2];
+  __shared__ uint32_t klist[32];  // the tile columns of [kb0, kb1) with a structurally nonzero product
   __shared__ double pad_[BULK ? 2432 : 1];
   if (BULK && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the padding allocated
   if (!BULK) __builtin_amdgcn_s_setprio(2);  // critical-path launches outrank the bulk waves
@@ -389,8 +393,19 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   const double* Yg0 = A + ((size_t)c * NB + sr) * ld + sc;
   const double* Yg1 = Yg0 + (size_t)32 * ld;
   const double xm0 = sr < rows ? 1.0 : 0.0, xm1 = sr + 32 < rows ? 1.0 : 0.0;
-  const uint32_t k_begin = kb0 * NB, k_end = kb1 * NB;
-  const int nchunk = (int)((k_end - k_begin) / KC2);  // a multiple of 4 (K is a multiple of 64)
+  // tile-sparse factor: column kb contributes only where both operand tiles are structurally
+  // nonzero (nz = tile pattern of L, nblk x nblk bytes; the rhs row is dense)
+  uint32_t nact = 0;
+  for (uint32_t kb = kb0; kb < kb1; ++kb) {
+    const bool on = !nz || ((i == nblk || nz[(size_t)i * nblk + kb]) && nz[(size_t)c * nblk + kb]);
+    if (on) {
+      if (threadIdx.x == 0) klist[nact] = kb * NB;
+      ++nact;
+    }
+  }
+  if (nact == 0) return;  // nothing to subtract from this tile
+  __syncthreads();
+  const int nchunk = (int)nact * (NB / KC2);  // a multiple of 4
   // two register sets: a chunk is loaded two iterations (~2 x 4096 MFMA-pipe cycles at four
   // waves per SIMD) before it is written to LDS
   double2 px0[2], px1[2], py0[2], py1[2], ps[2];
@@ -401,7 +416,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   for (uint32_t kb = kb0; kb < kb1; ++kb) plain = plain && (colneg[kb] == 0);
 #define BAE_GLOAD(S, CH)                                                          \
   {                                                                               \
-    const uint32_t k0_ = k_begin + (uint32_t)(CH) * KC2;                          \
+    const uint32_t k0_ = klist[(CH) >> 2] + (uint32_t)((CH) & 3) * KC2;           \
     px0[S] = *reinterpret_cast<const double2*>(Xg0 + k0_);                        \
     px1[S] = *reinterpret_cast<const double2*>(Xg1 + k0_);                        \
     py0[S] = *reinterpret_cast<const double2*>(Yg0 + k0_);                        \
@@ -645,8 +660,9 @@ __device__ __forceinline__ void subst_rows(double4_t R[4], const double op[NOPV]
 __global__ void __launch_bounds__(256, 2)
 k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
               uint32_t kb1, double* __restrict__ dsgn, double* __restrict__ opbuf,
-              int* __restrict__ colneg, int* __restrict__ status) {
+              int* __restrict__ colneg, int* __restrict__ status, const uint8_t* __restrict__ nz) {
   struct UpdLds { double X[2][NB][LDK2]; double Y[2][NB][LDK2]; };
+  __shared__ uint32_t klist[32];  // active tile columns (tile-sparse factor, see k_update2)
   constexpr size_t kLds = sizeof(TileLds) > sizeof(UpdLds) ? sizeof(TileLds) : sizeof(UpdLds);
   __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
   UpdLds& u = *reinterpret_cast<UpdLds*>(smem);
@@ -660,6 +676,16 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
+  uint32_t nact = 0;
+  for (uint32_t kb = kb0; kb < kb1; ++kb) {
+    const bool on = !nz || ((i == nblk || nz[(size_t)i * nblk + kb]) && nz[(size_t)c * nblk + kb]);
+    if (on) {
+      if (tid == 0) klist[nact] = kb * NB;
+      ++nact;
+    }
+  }
+  if (nact == 0 && !special) return;  // nothing to subtract from this tile
+  __syncthreads();
   double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
   double4_t acc[2][2];
 #pragma unroll
@@ -671,8 +697,7 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
         const int r = rb + 16 * ti + lk + 4 * reg;
         acc[ti][tj][reg] = Aic[(size_t)(r < rows ? r : 0) * ld + cb + 16 * tj + li];
       }
-  const uint32_t k_begin = kb0 * NB, k_end = kb1 * NB;
-  const int nchunk = (int)((k_end - k_begin) / KC2);
+  const int nchunk = (int)nact * (NB / KC2);
   if (nchunk > 0) {
     const int sr = tid >> 3, sc = (tid & 7) * 2;
     const double* Xg0 = A + ((size_t)i * NB + (sr < rows ? sr : 0)) * ld + sc;
@@ -694,14 +719,15 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
       u.Y[b][sr][sc] = -ps.x * py0.x; u.Y[b][sr][sc + 1] = -ps.y * py0.y;
       u.Y[b][sr + 32][sc] = -ps.x * py1.x; u.Y[b][sr + 32][sc + 1] = -ps.y * py1.y;
     };
-    gload(k_begin);
+    auto kof = [&](int ch) { return klist[ch >> 2] + (uint32_t)(ch & 3) * KC2; };
+    gload(kof(0));
     sstore(0);
-    if (nchunk > 1) gload(k_begin + KC2);
+    if (nchunk > 1) gload(kof(1));
     __syncthreads();
     for (int kc = 0; kc < nchunk; ++kc) {
       const int b = kc & 1;
       if (kc + 1 < nchunk) sstore(b ^ 1);
-      if (kc + 2 < nchunk) gload(k_begin + (uint32_t)(kc + 2) * KC2);
+      if (kc + 2 < nchunk) gload(kof(kc + 2));
 #pragma unroll
       for (int ks = 0; ks < KC2 / 4; ++ks) {
         const double a0 = u.X[b][rb + li][4 * ks + lk];
@@ -762,11 +788,12 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
 // rows below the diagonal tile d (row tiles d+1 .., the last block is the rhs row)
 __global__ void __launch_bounds__(256)
 k_trsm_op(double* __restrict__ A, uint32_t ld, uint32_t d, uint32_t nblk,
-          const double* __restrict__ opbuf) {
+          const double* __restrict__ opbuf, const uint8_t* __restrict__ nz) {
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const uint32_t i = d + 1 + blockIdx.x;
+  if (nz && i < nblk && !nz[(size_t)i * nblk + d]) return;  // structurally zero tile: stays zero
   const int rows = (i == nblk) ? 1 : NB;
   const int myrow = 16 * wave + li;
   double* Xrow = A + ((size_t)i * NB + (myrow < rows ? myrow : 0)) * ld + (size_t)d * NB;
@@ -862,9 +889,57 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
   }
 }
 
+// Tile pattern of the factor L: the union of the shards' S patterns (all-reduce of the tile
+// map), then symbolic elimination in natural order at 64x64-tile granularity:
+// L(i,j) becomes nonzero when L(i,k) and L(j,k) are, k < j <= i.  The trailing updates,
+// triangular solves and the look-ahead skip every tile product with a structurally zero
+// operand — the reference reaches the same saving through Eigen::SimplicialLDLT on
+// s_.sparseView() (BundleAdjuster.cpp:792-799).  BA_HIP_DENSE=1 keeps everything dense.
+int factor_tile_pattern(Engine* e) {
+  const Structure& st = e->st;
+  const uint32_t nt = st.ld / 64;
+  std::vector<uint8_t> nz(st.tile_nz);
+  if (nz.size() != (size_t)nt * nt) nz.assign((size_t)nt * nt, 1);
+  static const bool dense = getenv("BA_HIP_DENSE") != nullptr;
+  if (dense) std::fill(nz.begin(), nz.end(), 1);
+  if (e->allreduce && e->nranks > 1 && !dense) {
+    std::vector<double> cnt(nz.begin(), nz.end());
+    DBuf<double> d;
+    BAE_HIP(d.alloc(cnt.size()));
+    BAE_HIP(hipMemcpy(d.p, cnt.data(), cnt.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (e->allreduce(e->allreduce_ctx, d.p, cnt.size(), 0) != 0) { d.release(); return e->fail_msg("allreduce hook failed"); }
+    BAE_HIP(hipMemcpy(cnt.data(), d.p, cnt.size() * sizeof(double), hipMemcpyDeviceToHost));
+    d.release();
+    for (size_t i = 0; i < nz.size(); ++i) nz[i] = cnt[i] > 0.5 ? 1 : 0;
+  }
+  // symbolic right-looking elimination on the lower triangle; the working copy is column-major
+  // (c[k * nt + i] = L(i,k)) so that both the scan of column k and the fill of column j are
+  // contiguous
+  std::vector<uint8_t> c(nz);  // symmetric on input
+  std::vector<uint32_t> rows;
+  for (uint32_t k = 0; k < nt; ++k) {
+    rows.clear();
+    const uint8_t* ck = &c[(size_t)k * nt];
+    for (uint32_t i = k + 1; i < nt; ++i)
+      if (ck[i]) rows.push_back(i);
+    for (size_t a = 0; a < rows.size(); ++a) {
+      uint8_t* cj = &c[(size_t)rows[a] * nt];
+      for (size_t b = a; b < rows.size(); ++b) cj[rows[b]] = 1;
+    }
+  }
+  for (uint32_t i = 0; i < nt; ++i)
+    for (uint32_t k = 0; k < nt; ++k) nz[(size_t)i * nt + k] = (k <= i) ? c[(size_t)k * nt + i] : 0;
+  BAE_HIP(e->nzL.alloc(nz.size()));
+  BAE_HIP(hipMemcpy(e->nzL.p, nz.data(), nz.size(), hipMemcpyHostToDevice));
+  e->nzL_host = nz;
+  e->nzL_valid = true;
+  return 0;
+}
+
 // Solve on the padded lower storage dA ((n_pad + 1) x ld, n_pad = ld multiple of 64; the
 // rhs is row n_pad).  dx receives n_pad doubles (the first n are the solution).
-int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status) {
+int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status,
+                   const uint8_t* nz) {
   (void)n;
   const uint32_t nblk = ld / NB;
   BAE_HIP(e->invdiag.alloc((size_t)nblk * NB + (size_t)nblk * NB * NB + (size_t)nblk * NOPV * 64 +
@@ -898,14 +973,14 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   auto step_update = [&](uint32_t c0, uint32_t ncols, uint32_t kb0, uint32_t kb1) {
     if (panel64)
       hipLaunchKernelGGL(k_update2<false>, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, (const double*)dsgn, (const int*)colneg, 0);
+                         kb0, kb1, (const double*)dsgn, (const int*)colneg, 0, nz);
     else
       hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, dsgn, opbuf, colneg, e->flags.p);
+                         kb0, kb1, dsgn, opbuf, colneg, e->flags.p, nz);
   };
   if (!panel64)  // factor packet of tile 0 (nothing to update: one workgroup)
     hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
-                       colneg, e->flags.p);
+                       colneg, e->flags.p, nz);
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
   // overlapping the serial factorisation of the next panel.
@@ -919,7 +994,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
                            linvT, colneg, e->flags.p);
       else
         hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk,
-                           (const double*)opbuf);
+                           (const double*)opbuf, nz);
       // in-panel update of the panel's remaining tile columns with tile column jj
       if (jj + 1 < Jend) step_update(jj + 1, Jend - (jj + 1), jj, jj + 1);
     }
@@ -943,16 +1018,26 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
       const bool bulk_heavy = m >= bulk_full_m;
       if (no_lookahead || bulk_full || bulk_heavy)
         hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, 1);
+                           (const double*)dsgn, (const int*)colneg, 1, nz);
       else
         hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, 1);
+                           (const double*)dsgn, (const int*)colneg, 1, nz);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
       if (e->profiling) {
-        const double m = (double)(nblk - a_end);
-        e->kstats.syrk_flops += (m * (m + 1) / 2 + m) * 2.0 * NB * NB * NB * (Jend - J);
+        // algorithmic flops of this launch: per panel column kb the tiles (i, c), i >= c >= a_end,
+        // whose two operand tiles are structurally nonzero, plus the rhs row
+        double tiles = 0.0;
+        for (uint32_t kb = J; kb < Jend; ++kb) {
+          double mk = (double)(nblk - a_end);
+          if (nz && e->nzL_host.size() == (size_t)nblk * nblk) {
+            mk = 0.0;
+            for (uint32_t r = a_end; r < nblk; ++r) mk += e->nzL_host[(size_t)r * nblk + kb];
+          }
+          tiles += mk * (mk + 1) / 2 + mk;
+        }
+        e->kstats.syrk_flops += tiles * 2.0 * NB * NB * NB;
       }
     }
   }
