@@ -467,6 +467,35 @@ def test_two_shards_equal_one(lm_dim):
     assert rel_err(lms, single.get_landmarks(L)) < 1e-9
 
 
+def test_tile_sparse_factorisation_matches_oracle(oracle_lib):
+    """300 poses (n = 1788, 28 tiles of 64): poses far apart on the loop share no landmark, so S
+    has structurally zero 64x64 tiles and the factorisation skips tile products (symbolic
+    pattern, k_chol.hip).  The step must still agree with the oracle's dense LDL^T, and with
+    the engine's own dense path (BA_HIP_DENSE is read once per process, so the dense reference
+    here is the stand-alone dense solver on the tapped S)."""
+    po = oracle_lib
+    sc = scene.make_scene(300, 6000, 6, lm_dim=1, seed=23)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    o, h = both(po, sc, 1, active=pa, apply_results=0, use_triangular_matrices=0)
+    o.Solve(1)
+    h.Solve(1)
+    s = h.S()
+    n = s.shape[0]
+    nt = (n + 63) // 64
+    tiles = np.zeros((nt, nt), dtype=bool)
+    for a in range(nt):
+        for b in range(nt):
+            tiles[a, b] = np.any(s[64 * a:64 * a + 64, 64 * b:64 * b + 64] != 0.0)
+    assert tiles.mean() < 0.8, "the scene is supposed to have structurally zero tiles"
+    assert rel_err(s, o.S()) < 1e-12
+    assert rel_err(h.delta_p(), o.delta_p()) < 1e-8
+    assert rel_err(h.delta_l(), o.delta_l()) < 1e-8
+    eng = hipapi.Engine(1, 6)
+    x, rc = eng.dense_solve(s, h.rhs())
+    assert rc == 0 and rel_err(h.delta_p(), x) < 1e-9
+
+
 def test_reduced_camera_matrix_dump(tmp_path, monkeypatch):
     """write_reduced_camera_matrix (BundleAdjuster.cpp:600-606): s.txt / rhs.txt in the
     reference's CSV format reproduce the tapped S and rhs to the printed precision."""
