@@ -93,6 +93,8 @@ struct Engine {
   ba_hip_timers timers;
   ba_hip_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
+  ba_hip_collective_fn coll = nullptr;   // broadcast / reduce-scatter: distributed reduced solve
+  void* coll_ctx = nullptr;
   int rank = 0, nranks = 1;
 
   // ---- device: static problem data
@@ -118,6 +120,7 @@ struct Engine {
   DBuf<uint8_t> nzL;                     // tile pattern of the factor L (nt x nt bytes, lower), see k_chol.hip
   bool nzL_valid = false;
   std::vector<uint8_t> nzL_host;         // host copy (flop accounting of the profiled launches)
+  DBuf<double> dist_msg;                 // panel broadcast message (distributed solve)
   DBuf<double> packed;                   // packed lower triangle + rhs row (all-reduce staging)
   DBuf<uint32_t> pose_rows;              // [2*(Pact+1)]: pose-major J-slot ptr | incidence ptr
   DBuf<uint32_t> prhs_ptr;               // [Pact+1]
@@ -205,5 +208,9 @@ int launch_posepose_jrhs(Engine* e, double* out);
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status,
                    const uint8_t* nz_tiles);
 int factor_tile_pattern(Engine* e);
+uint32_t choose_kout(uint32_t nblk);
+bool dist_solve_enabled(const Engine* e);
+int dist_reduce_scatter_S(Engine* e);
+int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz);
 
 }  // namespace bae

@@ -568,7 +568,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
   REL(obs_jrow_m); REL(obs_jrow_r); REL(obs_wrow_m); REL(obs_first); REL(lm_wrow_r);
   REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent);
-  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed); REL(nzL);
+  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed); REL(nzL); REL(dist_msg);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
@@ -789,6 +789,16 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   if (e->allreduce && e->nranks > 1) {
     // S (lower storage) with its rhs row, and the unreduced rhs_p, are sums over the
     // landmark shards: one all-reduce each over xGMI.
+    if (dist_solve_enabled(e)) {
+      // distributed reduced solve: every rank only needs the sum of the column panels it owns
+      // (reduce-scatter); the reduced rhs (one row) and rhs_p are summed everywhere
+      BAE_HIP(hipStreamSynchronize(e->stream));
+      if (e->allreduce(e->allreduce_ctx, e->rhs_sc.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
+      if (e->allreduce(e->allreduce_ctx, e->rhs_p.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
+      if ((rc = dist_reduce_scatter_S(e))) return rc;
+      BAE_HIP(hipMemcpyAsync(e->A.p + (size_t)st.ld * st.ld, e->rhs_sc.p, (size_t)st.n * sizeof(double),
+                             hipMemcpyDeviceToDevice, e->stream));
+    } else {
     // The message is the packed lower triangle + rhs row (half of the square storage).
     const size_t cnt = packed_lower_count(st.ld);
     BAE_HIP(e->packed.alloc(cnt));
@@ -801,6 +811,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
       return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpyAsync(e->rhs_sc.p, e->A.p + (size_t)st.ld * st.ld, (size_t)st.n * sizeof(double),
                            hipMemcpyDeviceToDevice, e->stream));
+    }
   }
   e->timers.jtj_schur = t_s.stop_ms();
   // proj_error_ of BuildProblem (BundleAdjuster.cpp:1386) = EvaluateResiduals at the same
@@ -827,7 +838,9 @@ int ba_hip_solve_gn(ba_hip_engine* h) {
                              hipMemcpyDeviceToDevice, e->stream));
     }
     if (!e->nzL_valid && (rc = factor_tile_pattern(e))) return rc;
-    if ((rc = cholesky_solve(e, e->A.p, st.n, st.ld, e->gn_p.p, &status, e->nzL.p))) return rc;
+    if (dist_solve_enabled(e)) {
+      if ((rc = cholesky_solve_dist(e, e->A.p, st.ld, e->gn_p.p, &status, e->nzL.p))) return rc;
+    } else if ((rc = cholesky_solve(e, e->A.p, st.n, st.ld, e->gn_p.p, &status, e->nzL.p))) return rc;
     e->factored = true;
   }
   e->timers.solve = t.stop_ms();
@@ -1070,6 +1083,17 @@ int ba_hip_device_buffer(ba_hip_engine* h, int which, void** dev_ptr, size_t* nu
   if (which == 0) { *dev_ptr = e->A.p; *num_doubles = (size_t)(e->st.ld + 1) * e->st.ld; return 0; }
   if (which == 1) { *dev_ptr = e->scalars_out.p; *num_doubles = e->scalars_out.n; return 0; }
   return e->fail_msg("unknown buffer id");
+}
+
+int ba_hip_solve_is_distributed(ba_hip_engine* h) {
+  if (!h) return 0;
+  return dist_solve_enabled(reinterpret_cast<Engine*>(h)) ? 1 : 0;
+}
+
+int ba_hip_set_collectives(ba_hip_engine* h, ba_hip_collective_fn fn, void* ctx) {
+  ENG(h);
+  e->coll = fn; e->coll_ctx = ctx;
+  return 0;
 }
 
 int ba_hip_set_allreduce(ba_hip_engine* h, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) {

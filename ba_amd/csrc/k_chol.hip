@@ -343,7 +343,7 @@ template <bool BULK>
 __global__ void __launch_bounds__(256, BULK ? 2 : 4)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
           uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, int swz,
-          const uint8_t* __restrict__ nz) {
+          const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
   __shared__ double X[2][NB][LDK2];
   __shared__ double Y[2][NB][LDK2];
   __shared__ uint32_t klist[32];  // the tile columns of [kb0, kb1) with a structurally nonzero product
@@ -372,6 +372,8 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
     i = c + blockIdx.x;
     if (i > nblk) return;
   }
+  // distributed solve: a rank only updates the column panels it owns (panel p -> rank p mod N)
+  if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
   const int rows = (i == nblk) ? 1 : NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -936,6 +938,190 @@ int factor_tile_pattern(Engine* e) {
   return 0;
 }
 
+uint32_t choose_kout(uint32_t nblk) {
+  static const uint32_t kout_env = getenv("BA_HIP_KOUT") ? (uint32_t)atoi(getenv("BA_HIP_KOUT")) : 0;
+  return kout_env ? kout_env : (nblk >= 256 ? 8u : 4u);
+}
+
+// ---------------------------------------------------------------------------------
+// Distributed reduced solve.  Column panels of KOUT tiles
+// are dealt to the ranks round-robin (panel p -> rank p mod N).  Per iteration:
+//   * reduce-scatter: the partial S of every landmark shard is summed onto the owners of its
+//     panels (dist_reduce_scatter_S), instead of an all-reduce of the whole matrix;
+//   * panel J: its owner runs the serial chain (k_trsm_op / k_step_update) on its columns,
+//     packs the factor columns (rows from the panel's first row down to the rhs row), the pivot
+//     signs and the factor packets into one message and BROADCASTS it; everybody else unpacks;
+//   * trailing update with panel J: the owner of panel J+1 applies it to that panel (and
+//     factorises its first diagonal tile in the same launch), every rank applies it to the
+//     panels it owns further right (k_update2's ownership filter) on its second stream,
+//     overlapping the next panel's chain and broadcast;
+//   * the backward substitution is replicated (every rank holds all of L after the broadcasts).
+// Enabled when the caller installed the collectives hook (ba_hip_set_collectives), more than
+// one rank takes part, and the reduced system need not stay readable (keep_reduced_system).
+bool dist_solve_enabled(const Engine* e) {
+  static const bool off = getenv("BA_HIP_NO_DIST_SOLVE") != nullptr;
+  return e->coll && e->allreduce && e->nranks > 1 && !e->opt.keep_reduced_system && !off;
+}
+
+// rows [r0, r0 + nrows) x columns [c0, c0 + w) of A  <->  dense row-major block in buf
+__global__ void __launch_bounds__(256)
+k_copy_panel(double* __restrict__ A, uint32_t ld, uint32_t r0, uint32_t c0, uint32_t w,
+             double* __restrict__ buf, int unpack) {
+  const uint32_t r = blockIdx.x;
+  double* row = A + (size_t)(r0 + r) * ld + c0;
+  double* brow = buf + (size_t)r * w;
+  for (uint32_t cc = threadIdx.x; cc < w; cc += 256) {
+    if (unpack) row[cc] = brow[cc];
+    else brow[cc] = row[cc];
+  }
+}
+
+struct DistLayout {
+  uint32_t kout, npanels;
+  std::vector<size_t> off;  // offset of panel p inside its owner's chunk
+  size_t chunk;             // padded chunk size (doubles)
+};
+
+static DistLayout dist_layout(uint32_t nblk, uint32_t nranks) {
+  DistLayout d;
+  d.kout = choose_kout(nblk);
+  d.npanels = (nblk + d.kout - 1) / d.kout;
+  d.off.assign(d.npanels, 0);
+  std::vector<size_t> used(nranks, 0);
+  for (uint32_t p = 0; p < d.npanels; ++p) {
+    const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
+    const size_t rows = (size_t)(nblk - J) * NB, w = (size_t)(Jend - J) * NB;
+    d.off[p] = used[p % nranks];
+    used[p % nranks] += rows * w;
+  }
+  d.chunk = 0;
+  for (size_t u : used) d.chunk = std::max(d.chunk, u);
+  d.chunk = (d.chunk + 63) / 64 * 64;
+  return d;
+}
+
+int dist_reduce_scatter_S(Engine* e) {
+  const uint32_t ld = e->st.ld, nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
+  const DistLayout d = dist_layout(nblk, N);
+  BAE_HIP(e->packed.alloc(d.chunk * N));
+  for (uint32_t p = 0; p < d.npanels; ++p) {
+    const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
+    hipLaunchKernelGGL(k_copy_panel, dim3((nblk - J) * NB), dim3(256), 0, e->stream, e->A.p, ld, J * NB, J * NB,
+                       (Jend - J) * NB, e->packed.p + (size_t)(p % N) * d.chunk + d.off[p], 0);
+  }
+  BAE_HIP(hipGetLastError());
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  if (e->coll(e->coll_ctx, 2, e->packed.p, d.chunk, 0) != 0) return e->fail_msg("reduce-scatter hook failed");
+  for (uint32_t p = rank; p < d.npanels; p += N) {
+    const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
+    hipLaunchKernelGGL(k_copy_panel, dim3((nblk - J) * NB), dim3(256), 0, e->stream, e->A.p, ld, J * NB, J * NB,
+                       (Jend - J) * NB, e->packed.p + (size_t)rank * d.chunk + d.off[p], 1);
+  }
+  BAE_HIP(hipGetLastError());
+  return 0;
+}
+
+int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz) {
+  const uint32_t nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
+  const uint32_t KOUT = choose_kout(nblk);
+  BAE_HIP(e->invdiag.alloc((size_t)nblk * NB + (size_t)nblk * NB * NB + (size_t)nblk * NOPV * 64 +
+                           (nblk + 1) / 2));
+  double* dsgn = e->invdiag.p;
+  double* linvT = dsgn + (size_t)nblk * NB;
+  double* opbuf = linvT + (size_t)nblk * NB * NB;
+  int* colneg = reinterpret_cast<int*>(opbuf + (size_t)nblk * NOPV * 64);
+  // broadcast message of a panel: factor columns | pivot signs | colneg (ints) | factor packets
+  const size_t wmax = (size_t)KOUT * NB;
+  const size_t msg_cap = (size_t)(ld + 1) * wmax + wmax + KOUT + (size_t)KOUT * NOPV * 64;
+  BAE_HIP(e->dist_msg.alloc(msg_cap));
+  double* msg = e->dist_msg.p;
+  hipStream_t s0 = e->stream, s1 = e->stream2;
+  const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
+  while (e->ev_panel.size() < npanels) {
+    hipEvent_t a, b;
+    BAE_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    BAE_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    e->ev_panel.push_back(a);
+    e->ev_bulk.push_back(b);
+  }
+  BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), s0));
+  if (rank == 0)  // factor packet of tile 0
+    hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
+                       colneg, e->flags.p, nz);
+  int prev_bulk = -1;
+  uint32_t pj = 0;
+  for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
+    const uint32_t Jend = std::min(J + KOUT, nblk), owner = pj % N;
+    const uint32_t w = (Jend - J) * NB, nrows = (nblk - J) * NB + 1;  // incl. the rhs row
+    const size_t n_cols = (size_t)nrows * w;
+    double* m_sgn = msg + n_cols;
+    double* m_neg = m_sgn + w;
+    double* m_op = m_neg + KOUT;
+    const size_t msg_len = n_cols + w + KOUT + (size_t)(Jend - J) * NOPV * 64;
+    if (rank == owner) {
+      for (uint32_t jj = J; jj < Jend; ++jj) {
+        hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk, (const double*)opbuf, nz);
+        if (jj + 1 < Jend)
+          hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0, dA, ld,
+                             nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, e->flags.p, nz);
+      }
+      hipLaunchKernelGGL(k_copy_panel, dim3(nrows), dim3(256), 0, s0, dA, ld, J * NB, J * NB, w, msg, 0);
+      BAE_HIP(hipMemcpyAsync(m_sgn, dsgn + (size_t)J * NB, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(m_neg, colneg + J, (Jend - J) * sizeof(int), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(m_op, opbuf + (size_t)J * NOPV * 64, (size_t)(Jend - J) * NOPV * 64 * sizeof(double),
+                             hipMemcpyDeviceToDevice, s0));
+    }
+    BAE_HIP(hipGetLastError());
+    BAE_HIP(hipStreamSynchronize(s0));  // message complete / previous unpack done
+    if (e->coll(e->coll_ctx, 1, msg, msg_len, (int)owner) != 0) return e->fail_msg("broadcast hook failed");
+    if (rank != owner) {
+      hipLaunchKernelGGL(k_copy_panel, dim3(nrows), dim3(256), 0, s0, dA, ld, J * NB, J * NB, w, msg, 1);
+      BAE_HIP(hipMemcpyAsync(dsgn + (size_t)J * NB, m_sgn, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(colneg + J, m_neg, (Jend - J) * sizeof(int), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(opbuf + (size_t)J * NOPV * 64, m_op, (size_t)(Jend - J) * NOPV * 64 * sizeof(double),
+                             hipMemcpyDeviceToDevice, s0));
+    }
+    if (Jend >= nblk) break;
+    BAE_HIP(hipEventRecord(e->ev_panel[pj], s0));
+    const uint32_t a_end = std::min(Jend + KOUT, nblk);
+    if (rank == (pj + 1) % N) {
+      // next panel's columns (owned here): update + factor packet of its first diagonal tile
+      if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
+      hipLaunchKernelGGL(k_step_update, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld, nblk, Jend,
+                         J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
+    }
+    if (a_end < nblk) {
+      BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
+      const uint32_t m = nblk - a_end;
+      const uint32_t nsr = (m + 1 + 7) / 8, nsb = nsr * (nsr + 1) / 2;
+      const uint32_t grid1 = ((nsb + 7) / 8) * 8 * 64;
+      hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
+                         (const double*)dsgn, (const int*)colneg, 1, nz, rank, N, KOUT);
+      BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
+      prev_bulk = (int)pj;
+    }
+  }
+  BAE_HIP(hipGetLastError());
+  BAE_HIP(hipStreamSynchronize(s1));
+  hipLaunchKernelGGL(k_linvT, dim3(nblk), dim3(256), 0, s0, (const double*)opbuf, (const double*)dsgn, linvT);
+  for (uint32_t ii = nblk; ii-- > 0;) {
+    const uint32_t cols = ii * NB;
+    const uint32_t grid = cols == 0 ? 1 : (cols + 255) / 256;
+    hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, s0, dA, ld, ii, nblk, (const double*)linvT, dx);
+  }
+  BAE_HIP(hipGetLastError());
+  // the pivot status of every owner
+  int st = 0;
+  BAE_HIP(hipMemcpyAsync(&st, e->flags.p, sizeof(int), hipMemcpyDeviceToHost, s0));
+  BAE_HIP(hipStreamSynchronize(s0));
+  double sd = (double)st;
+  BAE_HIP(hipMemcpy(e->scalars_out.p, &sd, sizeof(double), hipMemcpyHostToDevice));
+  if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
+  BAE_HIP(hipMemcpy(&sd, e->scalars_out.p, sizeof(double), hipMemcpyDeviceToHost));
+  *status = sd > 0.5 ? 1 : 0;
+  return 0;
+}
+
 // Solve on the padded lower storage dA ((n_pad + 1) x ld, n_pad = ld multiple of 64; the
 // rhs is row n_pad).  dx receives n_pad doubles (the first n are the solution).
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status,
@@ -957,8 +1143,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   // Tiles per outer panel: every panel costs one read-modify-write pass over the trailing
   // matrix (8 n^3 / (3 * 64 KOUT) bytes in total), the serial chain inside a panel grows with
   // KOUT.  Small systems are chain-bound (KOUT = 4), large ones HBM-bound on the C tiles.
-  static const uint32_t kout_env = getenv("BA_HIP_KOUT") ? (uint32_t)atoi(getenv("BA_HIP_KOUT")) : 0;
-  const uint32_t KOUT = kout_env ? kout_env : (nblk >= 256 ? 8u : 4u);
+  const uint32_t KOUT = choose_kout(nblk);
   const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
   while (e->ev_panel.size() < npanels) {
     hipEvent_t a, b;
@@ -973,7 +1158,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   auto step_update = [&](uint32_t c0, uint32_t ncols, uint32_t kb0, uint32_t kb1) {
     if (panel64)
       hipLaunchKernelGGL(k_update2<false>, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, (const double*)dsgn, (const int*)colneg, 0, nz);
+                         kb0, kb1, (const double*)dsgn, (const int*)colneg, 0, nz, 0u, 1u, 1u);
     else
       hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
                          kb0, kb1, dsgn, opbuf, colneg, e->flags.p, nz);
@@ -1018,10 +1203,10 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
       const bool bulk_heavy = m >= bulk_full_m;
       if (no_lookahead || bulk_full || bulk_heavy)
         hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, 1, nz);
+                           (const double*)dsgn, (const int*)colneg, 1, nz, 0u, 1u, 1u);
       else
         hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, 1, nz);
+                           (const double*)dsgn, (const int*)colneg, 1, nz, 0u, 1u, 1u);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;

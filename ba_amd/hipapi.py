@@ -58,6 +58,7 @@ class KernelStats(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int)
 
 # every entry point include/ba_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -71,7 +72,7 @@ SYMBOLS = [
     "ba_hip_get_landmarks", "ba_hip_get_landmark_flags", "ba_hip_num_pose_params",
     "ba_hip_num_lm_params", "ba_hip_get_S", "ba_hip_get_rhs", "ba_hip_get_delta_gn",
     "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_timers", "ba_hip_get_unary_scales", "ba_hip_device_buffer",
-    "ba_hip_set_allreduce", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
+    "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
     "ba_hip_get_kernel_stats",
 ]
 
@@ -305,6 +306,20 @@ class Engine:
             return
         self._cb = ALLREDUCE_FN(lambda ctx, ptr, count, dtype: int(fn(ptr, count, dtype)))
         self._chk(self.L.ba_hip_set_allreduce(self.h, self._cb, None, int(rank), int(nranks)))
+
+    def set_collectives(self, fn):
+        """fn(op:int, dev_ptr:int, count:int, root:int) -> int (0 = ok); op 1 = broadcast from
+        root, op 2 = in-place reduce-scatter of nranks chunks of `count` doubles.  Switches the
+        reduced solve from replicated to distributed (ba_hip.h: ba_hip_set_collectives)."""
+        if fn is None:
+            self._cb2 = None
+            self._chk(self.L.ba_hip_set_collectives(self.h, None, None))
+            return
+        self._cb2 = COLLECTIVE_FN(lambda ctx, op, ptr, count, root: int(fn(op, ptr, count, root)))
+        self._chk(self.L.ba_hip_set_collectives(self.h, self._cb2, None))
+
+    def solve_is_distributed(self):
+        return bool(self.L.ba_hip_solve_is_distributed(self.h))
 
     def dense_solve(self, a_lower, b):
         a, b = _d(a_lower), _d(b)

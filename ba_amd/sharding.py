@@ -70,6 +70,36 @@ def torch_allreduce_hook(dist, device="cuda"):
     return fn
 
 
+def torch_collectives_hook(dist, device="cuda"):
+    """Hook (op, ptr, count, root) -> 0 for ba_hip_set_collectives over the torch.distributed
+    default group (RCCL): op 1 = broadcast `count` doubles from `root`; op 2 = reduce-scatter
+    (sum) of world_size chunks of `count` doubles, the result lands in this rank's chunk."""
+    import torch
+
+    def fn(op, ptr, count, root):
+        try:
+            world, rank = dist.get_world_size(), dist.get_rank()
+            if op == 1:
+                t = torch.as_tensor(_DevArray(ptr, count, "<f8"), device=device)
+                dist.broadcast(t, src=root)
+            elif op == 2:
+                t = torch.as_tensor(_DevArray(ptr, count * world, "<f8"), device=device)
+                out = torch.empty(count, dtype=torch.float64, device=device)
+                dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM)
+                t[rank * count:(rank + 1) * count].copy_(out)
+                del out
+            else:
+                raise ValueError("unknown collective op %d" % op)
+            if device == "cuda":
+                torch.cuda.synchronize()
+            return 0
+        except Exception as exc:  # the engine reports the failure
+            import sys
+            print("collectives hook:", exc, file=sys.stderr)
+            return 1
+    return fn
+
+
 class ThreadAllReduce:
     """Sums buffers of `nranks` engines that live in one process and are driven by one
     thread each (shards emulated on a single GPU)."""
@@ -104,6 +134,42 @@ class ThreadAllReduce:
             except Exception as exc:
                 import sys
                 print("ThreadAllReduce:", exc, file=sys.stderr)
+                self.failed = True
+                try:
+                    self.barrier.abort()
+                except Exception:
+                    pass
+                return 1
+        return fn
+
+    def collectives(self, rank):
+        """Broadcast / reduce-scatter among the engines of this process (see hook())."""
+        torch = self.torch
+
+        def fn(op, ptr, count, root):
+            try:
+                n = count if op == 1 else count * self.n
+                t = torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
+                self.slots[rank] = t
+                self.barrier.wait()
+                if op == 1:
+                    if rank != root:
+                        t.copy_(self.slots[root])
+                elif op == 2:
+                    mine = self.slots[0][rank * count:(rank + 1) * count].clone()
+                    for r in range(1, self.n):  # fixed rank order
+                        mine += self.slots[r][rank * count:(rank + 1) * count]
+                    torch.cuda.synchronize()
+                    self.barrier.wait()  # everybody has read the inputs before anybody overwrites
+                    t[rank * count:(rank + 1) * count].copy_(mine)
+                else:
+                    raise ValueError("unknown collective op %d" % op)
+                torch.cuda.synchronize()
+                self.barrier.wait()
+                return 0
+            except Exception as exc:
+                import sys
+                print("ThreadAllReduce.collectives:", exc, file=sys.stderr)
                 self.failed = True
                 try:
                     self.barrier.abort()

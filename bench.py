@@ -13,10 +13,11 @@ Workload (default, `--config 3`): the scene BASELINE.json's metric is quoted on 
 10k poses / 1M landmarks / 10M reprojection residuals, pinhole camera, inverse-depth landmarks
 (LmSize = 1), n = 59 988 reduced unknowns; it fits one MI355X (S is 28.8 GB of the 288 GB).
 `--config 1` selects configs[1] (1k poses / 100k landmarks / 1M residuals).  For N > 1 the SAME
-scene is sharded by landmark across the ranks (every rank holds all poses); the reduced pose
-system S (packed lower triangle), its right-hand side and a few scalars/histograms are
-summed with RCCL all-reduces over xGMI through the engine's all-reduce hook
-("scaling": "strong").
+scene is sharded by landmark across the ranks (every rank holds all poses); the partial
+reduced pose systems are reduce-scattered (RCCL over xGMI) onto the owners of S's column
+panels, every panel is factorised by its owner and broadcast, and each rank applies the
+trailing updates to the panels it owns; the right-hand side and a few scalars/histograms
+are all-reduced ("scaling": "strong").
 
 Rank 0 prints one JSON line with the driver's contract keys plus `roofline` (dominant
 kernel, measured live with HIP events on the engine's stream) and `cpu_baseline` (the
@@ -146,6 +147,10 @@ def main():
     eng, n_obs_local = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
     if world > 1:
         eng.set_allreduce(sharding.torch_allreduce_hook(dist, "cuda"), rank, world)
+        # distributed reduced solve: reduce-scatter of S to the panel owners, per-panel
+        # factorisation + broadcast (BA_BENCH_REPLICATED_SOLVE=1 keeps the replicated solve)
+        if not os.environ.get("BA_BENCH_REPLICATED_SOLVE"):
+            eng.set_collectives(sharding.torch_collectives_hook(dist, "cuda"))
 
     def barrier():
         if world > 1:
@@ -221,7 +226,8 @@ def main():
                                    "residuals, pinhole, LmSize=%d, PoseSize=6, Gauss-Newton (no dogleg), "
                                    "2 anchor poses inactive" % (args.config, P, L, O, lm_dim),
                        "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
-                       "parallelism": "landmark-sharded x%d, all-reduce of S" % world if world > 1 else "single GPU"},
+                       "parallelism": ("landmark-sharded x%d, reduce-scatter of S to panel owners, distributed LDL^T "
+                                       "(panel broadcast)" % world) if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_update2 (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)",
                          "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": traffic,

@@ -190,6 +190,19 @@ int ba_hip_device_buffer(ba_hip_engine* e, int which, void** dev_ptr, size_t* nu
  * dtype: 0 = f64, 1 = u64.  Must return 0 on success.  NULL = single shard. */
 typedef int (*ba_hip_allreduce_fn)(void* ctx, void* dev_ptr, size_t count, int dtype);
 int ba_hip_set_allreduce(ba_hip_engine* e, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);
+/* Collectives hook (optional, on top of the all-reduce hook): with it the dense reduced solve
+ * is DISTRIBUTED over the shards instead of replicated:
+ * the partial S of every shard is reduce-scattered to the owners of its 256/512-column panels
+ * (panel p belongs to rank p mod nranks), every panel is factorised by its owner and broadcast,
+ * and each rank applies the trailing updates to the panels it owns.
+ *   op 1 = broadcast `count` doubles at dev_ptr from rank `root`;
+ *   op 2 = reduce-scatter (sum), in place: dev_ptr holds nranks chunks of `count` doubles, on
+ *          return chunk `rank` (at dev_ptr + rank * count) holds the sum over ranks of that chunk.
+ * Same calling conventions as the all-reduce hook.  NULL = replicated solve. */
+typedef int (*ba_hip_collective_fn)(void* ctx, int op, void* dev_ptr, size_t count, int root);
+int ba_hip_set_collectives(ba_hip_engine* e, ba_hip_collective_fn fn, void* ctx);
+/* 1 if the next ba_hip_solve_gn will run the distributed solve, 0 if replicated / single. */
+int ba_hip_solve_is_distributed(ba_hip_engine* e);
 
 /* ---- stand-alone kernels exposed for tests and benchmarks ------------------------- */
 /* Dense Cholesky solve of an SPD system given by its LOWER triangle (row-major n x n,
