@@ -79,15 +79,21 @@ def torch_collectives_hook(dist, device="cuda"):
     def fn(op, ptr, count, root):
         try:
             world, rank = dist.get_world_size(), dist.get_rank()
+            n = count if op == 1 else count * world
+            if device == "cuda":
+                t = torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
+            else:  # host buffers (gloo; CPU tests)
+                t = torch.from_numpy(_host_view(ptr, n, 0))
             if op == 1:
-                t = torch.as_tensor(_DevArray(ptr, count, "<f8"), device=device)
                 dist.broadcast(t, src=root)
             elif op == 2:
-                t = torch.as_tensor(_DevArray(ptr, count * world, "<f8"), device=device)
-                out = torch.empty(count, dtype=torch.float64, device=device)
-                dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM)
-                t[rank * count:(rank + 1) * count].copy_(out)
-                del out
+                if device == "cuda":
+                    out = torch.empty(count, dtype=torch.float64, device="cuda")
+                    dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM)
+                    t[rank * count:(rank + 1) * count].copy_(out)
+                    del out
+                else:  # gloo has no reduce-scatter: sum everything, keep the own chunk
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
             else:
                 raise ValueError("unknown collective op %d" % op)
             if device == "cuda":

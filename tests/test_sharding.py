@@ -49,8 +49,15 @@ def _worker(rank, world, port, out):
     lo, hi = sharding.landmark_shards(np.full(1000, 10), world)[rank]
     cnt = np.array([float(hi - lo)])
     hook(cnt.ctypes.data_as(ctypes.c_void_p).value, 1, 0)
+    # the collectives of the distributed solve: broadcast from rank 1, in-place reduce-scatter
+    coll = sharding.torch_collectives_hook(dist, "cpu")
+    msg = np.full(5, 10.0 + rank)
+    rc3 = coll(1, msg.ctypes.data_as(ctypes.c_void_p).value, msg.size, 1)
+    chunks = np.arange(8, dtype=np.float64) + 100.0 * rank      # 2 chunks of 4
+    rc4 = coll(2, chunks.ctypes.data_as(ctypes.c_void_p).value, 4, 0)
+    mine = chunks[4 * rank:4 * rank + 4]
     if rank == 0:
-        np.save(out, np.concatenate([[rc1, rc2], s_part, hist.astype(np.float64), cnt]))
+        np.save(out, np.concatenate([[rc1, rc2], s_part, hist.astype(np.float64), cnt, [rc3, rc4], msg, mine]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,3 +71,6 @@ def test_gloo_allreduce_hook_world_size_2(tmp_path):
     assert np.array_equal(r[2:14], np.arange(12) * 3.0)   # (rank0: x1) + (rank1: x2)
     assert np.array_equal(r[14:17], [1.0, 10.0, 7.0])
     assert r[17] == 1000.0                                  # shards cover all landmarks
+    assert r[18] == 0 and r[19] == 0
+    assert np.array_equal(r[20:25], np.full(5, 11.0))       # broadcast from rank 1
+    assert np.array_equal(r[25:29], 2 * np.arange(4) + 100.0)  # rank 0's chunk, summed over ranks
