@@ -1095,10 +1095,27 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
       const uint32_t m = nblk - a_end;
       const uint32_t nsr = (m + 1 + 7) / 8, nsb = nsr * (nsr + 1) / 2;
       const uint32_t grid1 = ((nsb + 7) / 8) * 8 * 64;
+      e->prof_begin(e->ev_syrk, s1);
       hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
                          (const double*)dsgn, (const int*)colneg, 1, nz, rank, N, KOUT);
+      e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
+      if (e->profiling) {
+        // tile products formed by THIS rank: columns c it owns, rows i >= c (+ the rhs row), both
+        // operand tiles structurally nonzero
+        const bool pat = nz && e->nzL_host.size() == (size_t)nblk * nblk;
+        double tiles = 0.0;
+        std::vector<double> suffix(nblk + 1);
+        for (uint32_t kb = J; kb < Jend; ++kb) {
+          suffix[nblk] = 0.0;
+          for (uint32_t r = nblk; r-- > a_end;)
+            suffix[r] = suffix[r + 1] + (pat ? (double)e->nzL_host[(size_t)r * nblk + kb] : 1.0);
+          for (uint32_t c = a_end; c < nblk; ++c)
+            if ((c / KOUT) % N == rank && (!pat || e->nzL_host[(size_t)c * nblk + kb])) tiles += suffix[c] + 1.0;
+        }
+        e->kstats.syrk_flops += tiles * 2.0 * NB * NB * NB;
+      }
     }
   }
   BAE_HIP(hipGetLastError());

@@ -87,7 +87,7 @@ def torch_collectives_hook(dist, device="cuda"):
             if op == 1:
                 dist.broadcast(t, src=root)
             elif op == 2:
-                if device == "cuda":
+                if device == "cuda" and dist.get_backend() != "gloo":
                     out = torch.empty(count, dtype=torch.float64, device="cuda")
                     dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM)
                     t[rank * count:(rank + 1) * count].copy_(out)

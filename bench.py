@@ -136,8 +136,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # BA_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than
+        # ranks (ranks share devices; gloo stages the device tensors through the host)
+        backend = os.environ.get("BA_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI
+        if backend != "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+        dist.init_process_group(backend=backend)
 
     P, L, K, lm_dim = args.poses, args.landmarks, args.obs_per_landmark, args.lm_dim
     sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=2)
