@@ -605,3 +605,33 @@ def test_config2_size_properties():
     e0 = h.summary().proj_error
     h.Solve(2)
     assert h.summary().proj_error < e0
+
+
+def test_large_system_properties():
+    """3000 poses (n = 17 988, 282 tiles): the regime of BASELINE.json configs[3] in the solver —
+    512-column outer panels, full-occupancy XCD-swizzled bulk updates, tile-sparse skipping —
+    checked through size-independent properties: S delta = rhs, symmetry, bitwise determinism,
+    error decrease."""
+    sc = scene.make_scene(3000, 30000, 10, lm_dim=1, seed=5)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    runs = []
+    for _ in range(2):
+        h = adjuster.BundleAdjuster(1, 6)
+        h.Init(hip_options(apply_results=0, use_triangular_matrices=0))
+        fill(h, sc, active=pa)
+        h.Solve(1)
+        runs.append((h.rhs(), h.delta_p(), h.S() if not runs else None))
+        del h
+    rhs, dp_, s = runs[0]
+    assert np.array_equal(dp_, runs[1][1]) and np.array_equal(rhs, runs[1][0])
+    assert np.abs(s - s.T).max() <= 1e-9 * np.abs(s).max()
+    assert rel_err(s @ dp_, rhs) < 1e-9
+    del s
+    h = adjuster.BundleAdjuster(1, 6)
+    h.Init(hip_options(write_reduced_camera_matrix=0))
+    fill(h, sc, active=pa)
+    h.Solve(1)
+    e0 = h.summary().proj_error
+    h.Solve(2)
+    assert h.summary().proj_error < e0
