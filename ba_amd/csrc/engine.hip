@@ -538,17 +538,9 @@ int ba_hip_create(int lm_dim, int pose_dim, int device, void* stream, ba_hip_eng
   {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // Second stream for the bulk trailing updates of the dense factorisation: lowest
-    // priority, so the serial panel chain on the main stream wins the dispatch.  (CU masks
-    // were measured — r01: every partial mask was slower than none; BA_HIP_BULK_CU_MASK
-    // keeps the experiment reachable.)
-    const char* env = getenv("BA_HIP_BULK_CU_MASK");
-    if (env) {
-      uint32_t mask[8];
-      for (int i = 0; i < 8; ++i) mask[i] = (uint32_t)strtoul(env, nullptr, 16);
-      err = hipExtStreamCreateWithCUMask(&e->stream2, 8, mask);
-      if (err != hipSuccess) { (void)hipGetLastError(); e->stream2 = nullptr; }
-    }
+    // Second stream for the bulk trailing updates of the factorisation: lowest priority, so the
+    // serial panel chain on the main stream wins the dispatch.  (CU masks for it were measured in
+    // round 1 — every mask was slower than none.)
     if (!e->stream2) err = hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, lo);
     if (err != hipSuccess) { delete e; return -(int)err; }
   }

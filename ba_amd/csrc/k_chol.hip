@@ -1,31 +1,31 @@
-// Dense FP64 solve of the reduced camera system S delta = rhs on gfx950.
+// FP64 solve of the reduced camera system S delta = rhs on gfx950.
 //
-// Replaces CalculateGn (BundleAdjuster.cpp:748-833): the reference converts the dense
-// s_ to a sparse view and runs Eigen::SimplicialLDLT<Upper> (or dense LDLT<Upper>).
-// Here: two-level blocked right-looking Cholesky on the LOWER storage (row-major,
-// leading dimension ld, multiple of 64):
+// Replaces CalculateGn (BundleAdjuster.cpp:748-833): the reference converts the dense s_ to
+// a sparse view and runs Eigen::SimplicialLDLT<Upper> (or dense LDLT<Upper>).  Here: two-level
+// blocked right-looking L D L^T, D = diag(+-1), on the LOWER storage (row-major, leading
+// dimension ld, a multiple of 64), tile-sparse at 64x64 granularity, with look-ahead:
 //
-//   for every outer panel J of KOUT = 4 tile columns (256 columns)
-//     for every 64-column tile jj of the panel
-//       k_potrf64   one wavefront factorises the 64x64 diagonal tile in registers
-//                   (row per lane, pivots broadcast with v_readlane: no barriers)
-//       k_trsm64    rows below: X L_jj^T = A, one thread per row (forward substitution,
-//                   L_jj broadcast from LDS)
-//       k_update    in-panel update of the remaining tile columns of the panel (K = 64)
-//     k_update      trailing update of everything right of the panel with K = 256
+//   for every outer panel J of KOUT tile columns (256 columns, 512 for n >= 16k)
+//     for every 64-column tile jj of the panel                                   [stream s0]
+//       k_trsm_op      rows below the diagonal tile: X = A L_jj^-T D (blocked substitution on
+//                      the matrix cores from the "factor packet" of tile jj)
+//       k_step_update  update of the panel's remaining tile columns with column jj (K = 64);
+//                      its workgroup (0,0) also factorises the next diagonal tile in LDS and
+//                      publishes that tile's factor packet
+//     k_step_update    (a) the next panel's columns, K = 64 KOUT, + its first diagonal tile
+//     k_update2        (b) everything right of the next panel, K = 64 KOUT        [stream s1]
+//                      concurrently with the next panel's serial chain
+//   k_linvT, k_backward   L^T x = y, one tile row per launch
 //
-// The products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64 — the one true dense
-// contraction of the path); accumulating 256 columns per pass over the trailing matrix
-// quarters the HBM read-modify-write traffic of the C tiles compared with K = 64.
-// The factorisation is L D L^T with D = diag(+-1) (L carries sqrt|pivot|): for SPD
-// systems it IS the Cholesky factor, and like the reference's un-pivoted LDL^T it does
-// not break down on the indefinite / nearly singular systems that ill-posed gauges
-// produce (BundleAdjuster.cpp:752-761).
-// The right-hand side rides along as one extra row below the matrix, so the forward
-// substitution L y = b is a by-product; k_backward then solves L^T x = y block row by
-// block row.  The system is SPD for well-posed problems (masked parameters carry 1e6 on
-// the diagonal); a non-positive pivot raises the status flag (-> FactorizationError,
-// BundleAdjuster.cpp:756-759).
+// All products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64 — the one true dense
+// contraction of the path).  L carries sqrt|pivot| and D the pivot signs: for SPD systems it
+// IS the Cholesky factor, and like the reference's un-pivoted LDL^T it does not break down on
+// the indefinite / nearly singular systems that ill-posed gauges produce
+// (BundleAdjuster.cpp:752-761).  The right-hand side rides along as one extra row below the
+// matrix, so the forward substitution L y = b is a by-product.  Masked parameters carry 1e6
+// on the diagonal; a zero / NaN / Inf pivot raises the status flag (-> FactorizationError,
+// BundleAdjuster.cpp:756-759).  With the collectives hook the factorisation is distributed
+// over the ranks (cholesky_solve_dist).
 #include "engine.h"
 #include <cstdlib>
 #include <algorithm>
@@ -45,300 +45,23 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-// ---------------------------------------------------------------------------------
-// One 64-column step of the panel factorisation in ONE kernel (the serial chain of the
-// solver: 94 of these at n = 6000):
-//   block 0            factorises the diagonal tile jj, stores the pivot signs and
-//                      L_jj^-T (for the backward substitution);
-//   blocks 1 .. m      row tile jj + b (the last one is the rhs row): X = A L_jj^-T D.
-// EVERY block factorises the (same) diagonal tile itself in LDS — redundant flops instead
-// of a second launch and a trip through HBM on the critical path — while the global loads
-// of its own rows are in flight.  The factorisation works on 16-column panels: the panel
-// is factorised by one wavefront with a row per lane (16 columns in registers, pivots and
-// the in-panel multipliers broadcast by v_readlane; branch-free so that the scheduler can
-// overlap the rank-1 updates of column j with the reciprocal-square-root chain of column
-// j + 1), the rest of the tile is updated on the FP64 matrix cores straight out of LDS.
-// The four 16x16 diagonal inverses M_cc = L_cc^-1 follow (column per lane, four blocks
-// side by side).  The triangular solve of the block's rows is a blocked substitution on
-// the matrix cores, carried out on the TRANSPOSE so that it never leaves registers:
-//     R_c^T = A_c^T - sum_{k<c} (L_ck D_k) Z_k ,   Z_c = X_c^T = (D_c M_cc) R_c^T
-// — the C/D fragment of v_mfma_f64_16x16x4_f64 (row = (lane>>4) + 4 reg, col = lane&15)
-// is exactly its B fragment for k-step `reg`, so Z_k and R_c^T feed the next product
-// directly; only L and M_cc (A operands) come from LDS.  Wave w owns rows 16w .. 16w+15.
-// Block 0 runs the same substitution on the identity without signs: X = L_jj^-T.
-#ifndef BAE_EXP_UPD
-#define BAE_EXP_UPD 1
-#endif
 static const int LDM = 18;  // LDS row stride of the 16x16 diagonal inverses
 
-#ifdef BAE_PANEL_CLOCKS
-__device__ long long g_clk[16];
-#define PCLK(n) do { if (blockIdx.x == 1 && lane == 0 && wave == 0) g_clk[n] = clock64(); } while (0)
-#else
-#define PCLK(n) do { } while (0)
-#endif
-
-__global__ void __launch_bounds__(256, 2)
-k_panel64(double* __restrict__ A, uint32_t ld, uint32_t jj, uint32_t nblk,
-          double* __restrict__ dsgn_out, double* __restrict__ linvT_out, int* __restrict__ colneg,
-          int* __restrict__ status) {
-  __shared__ int neg_s;
-  __shared__ double T[NB][LDT];        // the diagonal tile: A_jj -> L_jj (upper part zero)
-  __shared__ double Md[4][16][LDM];    // M_cc = L_cc^-1, c = 0..3
-  __shared__ double dv[NB];            // 1 / L[j][j]
-  __shared__ double sg[NB];            // pivot signs d_j
-  __shared__ __attribute__((aligned(16))) double colbuf[2][NB];  // column j of L, for broadcast reads
-  __shared__ int bad_s;
-  // the serial chain of the solver: win the issue arbitration against the bulk-update waves
-  // that share the SIMDs during the look-ahead
-  __builtin_amdgcn_s_setprio(3);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, lk = lane >> 4;
-  const uint32_t i = jj + blockIdx.x;          // row tile of this block (jj: the diagonal)
-  const int rows = (i == nblk) ? 1 : NB;
-  const bool invert = blockIdx.x == 0;         // block 0: X = L^-T of the diagonal tile
-  const double* Akk = A + ((size_t)jj * NB) * ld + (size_t)jj * NB;
-  PCLK(0);
-  // the diagonal tile first (it gates the serial chain) ...
-  // (all loads unconditional — masked afterwards — so that they are issued back to back)
-  double2 tl[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int idx = tid + 256 * u;
-    const int r = idx >> 5, c2 = (idx & 31) * 2;
-    tl[u] = *reinterpret_cast<const double2*>(Akk + (size_t)r * ld + c2);
-  }
-  // ... then this wave's rows (16w + li) in the C/B fragment layout; these loads stay in
-  // flight during the factorisation
-  double4_t R[4];
-  const int myrow = 16 * wave + li;
-  double* Xrow = invert ? linvT_out + (size_t)jj * NB * NB + (size_t)myrow * NB
-                        : A + ((size_t)i * NB + myrow) * ld + (size_t)jj * NB;
-  if (invert) {  // block-uniform: the identity
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) R[c][reg] = (16 * c + lk + 4 * reg == myrow) ? 1.0 : 0.0;
-  } else {
-    const double* Lrow = A + ((size_t)i * NB + (myrow < rows ? myrow : 0)) * ld + (size_t)jj * NB;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) R[c][reg] = Lrow[16 * c + lk + 4 * reg];
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int idx = tid + 256 * u;
-    const int r = idx >> 5, c2 = (idx & 31) * 2;
-    T[r][c2] = (c2 <= r) ? tl[u].x : 0.0;
-    T[r][c2 + 1] = (c2 + 1 <= r) ? tl[u].y : 0.0;
-  }
-  if (tid == 0) bad_s = 0;
-  __syncthreads();
-  PCLK(1);
-  if (wave == 0) {
-    unsigned long long negmask = 0;  // bit J: pivot J negative (wave-uniform, lives in SGPRs)
-#pragma unroll
-    for (int pb = 0; pb < 4; ++pb) {
-      const int c0 = 16 * pb;
-      double p[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) p[c] = (c0 + c <= lane) ? T[lane][c0 + c] : 0.0;
-      // Software-pipelined right-looking elimination: iteration j runs the pivot chain of
-      // column j (v_rsq_f64 + two Newton steps, no division) while the rank-1 update of step
-      // j-1 on the columns right of j + 1 — independent of that chain — is issued; only the
-      // update of column j + 1 by step j sits on the serial path.  A single wave issues one
-      // VALU instruction every ~6 cycles, so the loop is kept lean: no pivot tests (a zero /
-      // NaN pivot poisons the diagonal, which is checked once at the end), the pivot sign is
-      // applied with an integer xor and collected in a scalar bit mask, the multipliers of
-      // the deferred updates come back from LDS as wave-uniform broadcast reads.
-      // sched_barrier pins the interleaving (the compiler would otherwise re-serialise the
-      // updates into dot products in front of every pivot).
-      double sa_prev = 0.0;
-      double lb[16];  // multipliers of the previous step: L[c0 + c][J - 1]
-      double d = readlane_f64(p[0], c0);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int J = c0 + j;
-        const int dhi = __double2hiint(d);
-        const int sbit = dhi & (int)0x80000000;
-        negmask |= (unsigned long long)((unsigned)dhi >> 31) << J;
-        const double ad = fabs(d);
-#define BAE_UPD(n)                                                  \
-  {                                                                 \
-    const int c_ = j + 1 + (n);                                     \
-    if (j > 0 && c_ < 16 && BAE_EXP_UPD) p[c_] -= sa_prev * lb[c_]; \
-  }
-#define BAE_SB __builtin_amdgcn_sched_barrier(0)
-        // y ~ 1/sqrt|d|: hardware estimate y0 (rel. error 5e-8, measured) + ONE third-order
-        // step:  h = 1 - |d| y0^2,  y = y0 + y0 h (1/2 + 3/8 h)   (error O(h^3), below 1 ulp)
-        double y = __builtin_amdgcn_rsq(ad);
-        BAE_SB;
-        double t = ad * y;
-        BAE_SB;
-        double h = fma(-t, y, 1.0);
-        BAE_UPD(0) BAE_SB;
-        double q = fma(0.375, h, 0.5);
-        double yh = y * h;
-        BAE_UPD(1) BAE_UPD(2) BAE_UPD(3) BAE_SB;
-        y = fma(yh, q, y);
-        BAE_UPD(4) BAE_UPD(5) BAE_UPD(6) BAE_UPD(7) BAE_UPD(8) BAE_SB;
-        const double sa = p[j] * y;            // d_J L[r][J]
-        BAE_UPD(9) BAE_UPD(10) BAE_SB;
-        // L[r][J] = d_J A[r][J] / sqrt|d| (lane J: sqrt|d| > 0): flip the sign bit if d < 0
-        const double l = __hiloint2double(__double2hiint(sa) ^ sbit, __double2loint(sa));
-        colbuf[j & 1][lane] = l;
-        p[j] = l;
-        BAE_UPD(11) BAE_UPD(12) BAE_UPD(13) BAE_UPD(14) BAE_SB;
-        // the multipliers for the NEXT iteration's deferred updates: issued here, one whole
-        // serial section ahead of their first use, so the LDS round trip is hidden
-#pragma unroll
-        for (int c = j + 2; c < 16; ++c) lb[c] = colbuf[j & 1][c0 + c];
-        BAE_SB;
-        if (j < 15) {
-          p[j + 1] -= sa * readlane_f64(l, J + 1);  // d_J L[r][J] L[J+1][J]
-          d = readlane_f64(p[j + 1], J + 1);
-        }
-        BAE_SB;
-#undef BAE_UPD
-#undef BAE_SB
-        sa_prev = sa;
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) T[lane][c0 + c] = (c0 + c <= lane) ? p[c] : 0.0;
-      sg[lane] = ((negmask >> lane) & 1ull) ? -1.0 : 1.0;  // later panels rewrite their bits
-      // trailing 16x16 blocks (rbk, cbk), pb < cbk <= rbk:  C -= L_rbk,pb D L_cbk,pb^T
-      if (pb < 3) {
-        double la[4][3];  // L[16 b + li][k], k = c0 + 4 ks + lk, b = 1..3 : A operand of row block b
-        double nb[4][3];  // -d_k L[16 b + li][k]                          : B operand of column block b
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int k = c0 + 4 * ks + lk;
-          const double sk = -sg[k];
-#pragma unroll
-          for (int b = pb + 1; b < 4; ++b) {
-            la[ks][b - 1] = T[16 * b + li][k];
-            nb[ks][b - 1] = sk * la[ks][b - 1];
-          }
-        }
-#pragma unroll
-        for (int rbk = pb + 1; rbk < 4; ++rbk)
-#pragma unroll
-          for (int cbk = pb + 1; cbk <= rbk; ++cbk) {
-            double4_t acc;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) acc[reg] = T[16 * rbk + lk + 4 * reg][16 * cbk + li];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[ks][rbk - 1], nb[ks][cbk - 1], acc, 0, 0, 0);
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) T[16 * rbk + lk + 4 * reg][16 * cbk + li] = acc[reg];
-          }
-      }
-      PCLK(2 + pb);
-    }
-    if (lane == 0) neg_s = negmask != 0 ? 1 : 0;
-    {
-      // 1 / L[j][j]; a zero, negative-zero, NaN or Inf pivot shows up on the diagonal
-      const double q = T[lane][lane];
-      if (!(q > 0.0 && q < 1e150)) bad_s = 1;
-      dv[lane] = 1.0 / q;
-    }
-    // diagonal 16x16 inverses, lane = (block b, column c): L_bb x = e_c, column-oriented
-    // (once x_k is known the remaining rows update independently)
-    {
-      const int base = 16 * lk, c = li;
-      double sacc[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double xk = sacc[k] * dv[base + k];
-        sacc[k] = xk;
-#pragma unroll
-        for (int r = k + 1; r < 16; ++r) sacc[r] -= T[base + r][base + k] * xk;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Md[lk][r][c] = sacc[r];  // zero above the diagonal by construction
-    }
-  }
-  PCLK(6);
-  __syncthreads();
-  PCLK(7);
-  // blocked substitution on the transpose, rows 16 wave + li (see the header comment);
-  // right-looking (Z_c updates every later R), all A operands fetched up front.  Rows past
-  // `rows` (rhs-row block) carry row 0's data: MFMA columns are independent, and they are
-  // not stored.
-  {
-    double sgk[3][4], sgc[4];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double v = sg[16 * k + 4 * ks + lk];
-        sgk[k][ks] = invert ? -1.0 : -v;
-      }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const double v = sg[16 * c + li];
-      sgc[c] = invert ? 1.0 : v;
-    }
-    double aM[4][4], aL[4][3][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) aM[c][ks] = sgc[c] * Md[c][li][4 * ks + lk];
-#pragma unroll
-    for (int c = 1; c < 4; ++c)
-#pragma unroll
-      for (int k = 0; k < c; ++k)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) aL[c][k][ks] = sgk[k][ks] * T[16 * c + li][16 * k + 4 * ks + lk];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double4_t Zc = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) Zc = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[c][ks], R[c][ks], Zc, 0, 0, 0);
-#pragma unroll
-      for (int c2 = c + 1; c2 < 4; ++c2)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          R[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aL[c2][c][ks], Zc[ks], R[c2], 0, 0, 0);
-      R[c] = Zc;  // X_c^T
-    }
-  }
-  PCLK(8);
-  if (invert || myrow < rows) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = R[c][reg];
-  }
-  if (invert) {
-    if (tid < NB) dsgn_out[(size_t)jj * NB + tid] = sg[tid];
-    if (tid == 0) colneg[jj] = neg_s;
-    if (tid == 0 && bad_s) atomicExch(status, 1);
-  }
-  PCLK(9);
-}
-
 // ---------------------------------------------------------------------------------
-// The same update, software-pipelined (the default):
-//   * the C tile is fetched into the accumulators at kernel start, so its latency hides
-//     under the K loop and the epilogue is a plain store (acc = C - X D Y^T, the sign and
-//     d_k folded into the staged Y);
+// Trailing update: tile (i, c) -= sum over the panel's tile columns kb of X_i,kb D_kb X_c,kb^T,
+// one 64x64 output tile per workgroup (4 waves x 32x32 = 2x2 MFMA tiles each):
 //   * K is consumed in chunks of 16 through double-buffered LDS stages (stride 18: the
 //     16-lane phases of the operand reads hit distinct banks): while the matrix cores work
-//     on chunk k, chunk k+1 moves registers -> LDS and chunk k+2 global -> registers; one
-//     barrier per chunk;
-//   * 37 KB of LDS per workgroup: three of them share a CU with a k_panel64 block, so
-//     the bulk updates of the look-ahead do not starve the serial chain of LDS.
+//     on chunk k, chunk k+1 moves registers -> LDS and chunks k+2, k+3 global -> registers
+//     (two register sets); one barrier per chunk;
+//   * the accumulators start at zero and the C tile is fetched after the loop;
+//   * 37 KB of LDS per workgroup, four workgroups per CU.
 static const int KC2 = 16;
 static const int LDK2 = KC2 + 2;
 
-// BULK = true (the look-ahead's background updates) pads the LDS footprint to 56 KB: at most
-// two such workgroups fit on a CU, which always leaves the 44 KB + one wave per SIMD that a
-// k_panel64 block of the concurrent serial chain needs.
+// BULK = true (the look-ahead's background updates on small systems) pads the LDS footprint
+// to 56 KB: at most two such workgroups fit on a CU, which always leaves the 45 KB + one wave
+// per SIMD that a k_step_update / k_trsm_op workgroup of the concurrent serial chain needs.
 template <bool BULK>
 __global__ void __launch_bounds__(256, BULK ? 2 : 4)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
@@ -489,12 +212,12 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 }
 
 // ---------------------------------------------------------------------------------
-// Pipelined panel step (the default).  k_panel64 keeps the pivot chain of tile d + 1
-// strictly AFTER the update launch of step d; here the chain runs INSIDE that launch:
+// Pipelined panel step: the pivot chain of tile d + 1 runs INSIDE the update launch of step d
+// instead of after it:
 //
 //   k_step_update  = the k_update2 tile update, except that workgroup (0,0) — the diagonal
 //                    tile (c0,c0), dispatched first — keeps its updated tile in LDS,
-//                    factorises it (the k_panel64 wave-0 chain), and publishes the
+//                    factorises it (factor_tile_wave0), and publishes the
 //                    "factor packet" of step c0: the 40 A-operand vectors of the blocked
 //                    substitution (signed, in fragment order: plain coalesced loads for the
 //                    consumer), the pivot signs and L^-T.  The chain (~12 us) overlaps the
@@ -502,8 +225,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 //   k_trsm_op      = rows below the diagonal tile: X = A L^-T D from the factor packet —
 //                    no LDS, no barrier: 16 + 40 loads, 40 MFMAs, 16 stores per wave.
 //
-// Serial path per 64 columns: k_trsm_op (~5 us) + the diagonal workgroup (~15 us), against
-// k_panel64 (~18 us) + update launch (~10 us).
+// Serial path per 64 columns: k_trsm_op (~8 us) + the diagonal workgroup (~17 us).
 static const int NOPV = 40;  // operand vectors per factor packet
 
 struct TileLds {
@@ -516,8 +238,19 @@ struct TileLds {
   int neg;                  // any negative pivot in this tile
 };
 
-// wave 0: factorise sh.T in place (see k_panel64 for the commentary of the chain), then the
-// four 16x16 diagonal inverses
+// Wave 0 factorises sh.T in place, then forms the four 16x16 diagonal inverses.
+// 16-column panels: a row per lane (16 columns in registers); software-pipelined right-looking
+// elimination — iteration j runs the pivot chain of column j (v_rsq_f64 + one third-order
+// correction, 1.4e-16 measured; no division) while the rank-1 update of step j-1 on the columns
+// right of j + 1, independent of that chain, is issued; only the update of column j + 1 by step
+// j sits on the serial path.  A lone wave issues one VALU instruction every ~6 cycles, so the
+// loop is kept lean: no pivot tests (a zero / NaN pivot poisons the diagonal, which is checked
+// once at the end), the pivot sign is applied with an integer xor and collected in a scalar
+// bit mask, the multipliers of the deferred updates come back from LDS as wave-uniform broadcast
+// reads issued one serial section ahead of their use.  sched_barrier pins the interleaving (the
+// compiler would otherwise re-serialise the updates into dot products in front of every
+// pivot).  The rest of the tile is updated on the matrix cores straight out of LDS.
+// Diagonal inverses: lane = (block, column), column-oriented forward substitution.
 __device__ __forceinline__ void factor_tile_wave0(TileLds& sh, int lane) {
   const int li = lane & 15, lk = lane >> 4;
   unsigned long long negmask = 0;
@@ -625,7 +358,11 @@ __device__ __forceinline__ void factor_tile_wave0(TileLds& sh, int lane) {
   }
 }
 
-// operand vector v of the blocked substitution for this lane (see k_panel64):
+// Blocked substitution X = A L^-T D on the TRANSPOSE, never leaving registers:
+//     R_c^T = A_c^T - sum_{k<c} (L_ck D_k) Z_k ,   Z_c = X_c^T = (D_c M_cc) R_c^T
+// — the C/D fragment of v_mfma_f64_16x16x4_f64 (row = (lane>>4) + 4 reg, col = lane&15) is
+// exactly its B fragment for k-step `reg`, so Z_k and R_c^T feed the next product directly;
+// only L and M_cc (A operands) come from memory.  Operand vector v for this lane:
 //   v < 16:  aM[c][ks] =  d_(16c+li) M_cc[li][4ks+lk]           c = v / 4, ks = v % 4
 //   v >= 16: aL[c][k][ks] = -d_kk L[16c+li][kk], kk = 16k+4ks+lk, (c,k) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
 // `sgn` false: all signs +1 (the inverse L^-T)
@@ -1153,7 +890,6 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   int* colneg = reinterpret_cast<int*>(opbuf + (size_t)nblk * NOPV * 64);  // per tile column: any d_k < 0
   static const bool no_lookahead = getenv("BA_HIP_NO_LOOKAHEAD") != nullptr;  // A/B switches
   static const bool bulk_full = getenv("BA_HIP_BULK_FULL") != nullptr;
-  static const bool panel64 = getenv("BA_HIP_PANEL64") != nullptr;
   static const uint32_t bulk_full_m =
       getenv("BA_HIP_BULK_FULL_M") ? (uint32_t)atoi(getenv("BA_HIP_BULK_FULL_M")) : 128u;
   hipStream_t s0 = e->stream, s1 = no_lookahead ? e->stream : e->stream2;
@@ -1173,15 +909,11 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   // update of the tile columns [c0, c0 + ncols) with the tile columns [kb0, kb1) on the
   // critical-path stream; in the pipelined scheme the launch also factorises tile (c0,c0)
   auto step_update = [&](uint32_t c0, uint32_t ncols, uint32_t kb0, uint32_t kb1) {
-    if (panel64)
-      hipLaunchKernelGGL(k_update2<false>, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, (const double*)dsgn, (const int*)colneg, 0, nz, 0u, 1u, 1u);
-    else
-      hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
+    hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
                          kb0, kb1, dsgn, opbuf, colneg, e->flags.p, nz);
   };
-  if (!panel64)  // factor packet of tile 0 (nothing to update: one workgroup)
-    hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
+  // factor packet of tile 0 (nothing to update: one workgroup)
+  hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
                        colneg, e->flags.p, nz);
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
@@ -1191,11 +923,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
     const uint32_t Jend = J + KOUT < nblk ? J + KOUT : nblk;
     for (uint32_t jj = J; jj < Jend; ++jj) {
-      if (panel64)
-        hipLaunchKernelGGL(k_panel64, dim3(nblk - jj + 1), dim3(256), 0, s0, dA, ld, jj, nblk, dsgn,
-                           linvT, colneg, e->flags.p);
-      else
-        hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk,
+      hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk,
                            (const double*)opbuf, nz);
       // in-panel update of the panel's remaining tile columns with tile column jj
       if (jj + 1 < Jend) step_update(jj + 1, Jend - (jj + 1), jj, jj + 1);
@@ -1244,8 +972,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     }
   }
   BAE_HIP(hipGetLastError());
-  if (!panel64)
-    hipLaunchKernelGGL(k_linvT, dim3(nblk), dim3(256), 0, s0, (const double*)opbuf, (const double*)dsgn,
+  hipLaunchKernelGGL(k_linvT, dim3(nblk), dim3(256), 0, s0, (const double*)opbuf, (const double*)dsgn,
                        linvT);
   for (uint32_t ii = nblk; ii-- > 0;) {
     const uint32_t cols = ii * NB;
