@@ -480,7 +480,7 @@ static int build_structure(Engine* e) {
   const size_t nparts = std::max<size_t>({(O1 + 255) / 256, (L1 + 255) / 256, (size_t)(st.ld + 255) / 256, 1});
   BAE_HIP(e->partials.alloc(4 * nparts));
   BAE_HIP(e->scalars_out.alloc(64));
-  BAE_HIP(e->hist.alloc(2048));
+  BAE_HIP(e->hist.alloc(2048 + 8));
   BAE_HIP(e->flags.alloc(16));
   BAE_HIP(hipStreamSynchronize(e->stream));
   return 0;
@@ -1127,7 +1127,7 @@ int ba_hip_select_kth(ba_hip_engine* h, uint32_t n, const double* values, uint32
   BAE_HIP(hipSetDevice(e->device));
   DBuf<double> dv;
   BAE_HIP(dv.alloc(std::max<uint32_t>(n, 1)));
-  BAE_HIP(e->hist.alloc(2048));
+  BAE_HIP(e->hist.alloc(2048 + 8));
   if (n) BAE_HIP(hipMemcpy(dv.p, values, (size_t)n * 8, hipMemcpyHostToDevice));
   int rc = select_kth(e, dv.p, n, k, out);
   dv.release();

@@ -352,7 +352,86 @@ k_select_hist(uint32_t n, const double* __restrict__ v, unsigned long long prefi
     if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
+// Single-shard variant: the whole selection stays on the device.  The running state
+// {prefix, mask, remaining rank, error} lives in sel[0..3]; k_select_hist_dev reads it,
+// k_select_scan (one wavefront) walks the 2048 bins with a wave-wide prefix sum and advances
+// it.  Six passes are enqueued back to back; one 8-byte copy returns the result.
+__global__ void __launch_bounds__(256)
+k_select_hist_dev(uint32_t n, const double* __restrict__ v, const unsigned long long* __restrict__ sel,
+                  int shift, unsigned int digit_mask, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int h[2048];
+  const unsigned long long prefix = sel[0], prefix_mask = sel[1];
+  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+    if ((b & prefix_mask) == prefix) atomicAdd(&h[(b >> shift) & digit_mask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+__global__ void __launch_bounds__(64)
+k_select_scan(unsigned long long* __restrict__ sel, unsigned long long* __restrict__ hist, int shift,
+              int nbins, unsigned long long digit_mask) {
+  const int lane = threadIdx.x;
+  unsigned long long k = sel[2];
+  // lane owns bins [32 lane, 32 lane + 32): local sum, exclusive wave scan, then a local walk
+  unsigned long long loc = 0;
+  for (int b = 0; b < 32; ++b) loc += hist[32 * lane + b];
+  unsigned long long incl = loc;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  const unsigned long long excl = incl - loc;
+  const bool mine = (k >= excl) && (k < incl) && (32 * lane < nbins);
+  if (mine) {
+    unsigned long long r = k - excl;
+    int b = 0;
+    for (; b < 32; ++b) {
+      const unsigned long long hb = hist[32 * lane + b];
+      if (r < hb) break;
+      r -= hb;
+    }
+    sel[0] |= ((unsigned long long)(32 * lane + b)) << shift;
+    sel[1] |= digit_mask << shift;
+    sel[2] = r;
+  }
+  const unsigned long long found = __ballot(mine);
+  if (lane == 0 && found == 0) sel[3] = 1;  // rank out of range
+  __syncthreads();
+  for (int b = 0; b < 32; ++b) hist[32 * lane + b] = 0;  // ready for the next pass
+}
+
+static int select_kth_device(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out) {
+  static const int shifts[6] = {53, 42, 31, 20, 9, 0};
+  unsigned long long init[4] = {0ull, 0ull, (unsigned long long)k, 0ull};
+  unsigned long long* sel = e->hist.p + 2048;
+  BAE_HIP(hipMemsetAsync(e->hist.p, 0, 2048 * sizeof(unsigned long long), e->stream));
+  BAE_HIP(hipMemcpyAsync(sel, init, sizeof(init), hipMemcpyHostToDevice, e->stream));
+  uint32_t grid = (n_local + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  for (int pass = 0; pass < 6; ++pass) {
+    hipLaunchKernelGGL(k_select_hist_dev, dim3(grid), dim3(256), 0, e->stream, n_local, d_values,
+                       (const unsigned long long*)sel, shifts[pass], pass == 5 ? 511u : 2047u, e->hist.p);
+    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(64), 0, e->stream, sel, e->hist.p, shifts[pass],
+                       pass == 5 ? 512 : 2048, pass == 5 ? 511ull : 2047ull);
+  }
+  BAE_HIP(hipGetLastError());
+  unsigned long long res[4];
+  BAE_HIP(hipMemcpyAsync(res, sel, sizeof(res), hipMemcpyDeviceToHost, e->stream));
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  if (res[3]) return e->fail_msg("select_kth: rank out of range");
+  double r;
+  memcpy(&r, &res[0], sizeof(double));
+  *out = r;
+  return 0;
+}
+
 int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out) {
+  if (!(e->allreduce && e->nranks > 1) && n_local > 0) return select_kth_device(e, d_values, n_local, k, out);
   // digits from the top: bits [63:53] [52:42] [41:31] [30:20] [19:9] [8:0](9 bits, shift 0)
   static const int shifts[6] = {53, 42, 31, 20, 9, 0};
   unsigned long long prefix = 0, mask = 0;
