@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256, 4) k(const double* __restrict__ G, double
   __syncthreads();
   d4 acc[2][2];
   for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-  const double* g0 = G + ((size_t)(blockIdx.x % 1024) * 64 + sr) * ld + sc;  // rows < 65536
+  const double* g0 = G + ((size_t)(blockIdx.x % 8) * 64 + sr) * ld + sc;  // 8 row tiles x 8192 columns x 2: L2-resident
   const double* g1 = g0 + 32 * ld;
   double2 p0 = {1.0, 2.0}, p1 = {3.0, 4.0}, q0 = {1.5, 2.5}, q1 = {3.5, 4.5};
   double ra0 = 1.0 + lane * 1e-9, ra1 = 1.1, rb0 = 0.9, rb1 = 1.2;
