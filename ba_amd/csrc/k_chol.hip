@@ -74,18 +74,19 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   if (BULK && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the padding allocated
   if (!BULK) __builtin_amdgcn_s_setprio(2);  // critical-path launches outrank the bulk waves
   uint32_t c, i;
-  if (swz) {
+  if (swz & 1) {
     // XCD-aware 1-D launch (the big trailing updates): workgroups whose ids agree mod 8 share
     // an XCD and its L2, so each XCD walks its own 8x8 super-blocks of output tiles — the
     // 8 + 8 operand slices of a super-block (2 MB at K = 256) stay L2-resident instead of
     // being re-fetched for every tile.  Super-blocks enumerate the lower triangle row by row.
+    const uint32_t sbl = (uint32_t)swz >> 8;  // log2 of the super-block edge (3: 8x8 tiles)
     const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
-    const uint32_t t = (slot >> 6) * 8u + xcd, within = slot & 63u;
+    const uint32_t t = (slot >> (2 * sbl)) * 8u + xcd, within = slot & ((1u << (2 * sbl)) - 1u);
     uint32_t sr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
     while ((uint64_t)(sr + 1) * (sr + 2) / 2 <= t) ++sr;
     while ((uint64_t)sr * (sr + 1) / 2 > t) --sr;
     const uint32_t sc = t - (uint32_t)((uint64_t)sr * (sr + 1) / 2);
-    const uint32_t R = sr * 8u + (within >> 3), C = sc * 8u + (within & 7u);
+    const uint32_t R = (sr << sbl) + (within >> sbl), C = (sc << sbl) + (within & ((1u << sbl) - 1u));
     if (C > R) return;
     c = c0 + C;
     i = c0 + R;
@@ -834,7 +835,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
       const uint32_t grid1 = ((nsb + 7) / 8) * 8 * 64;
       e->prof_begin(e->ev_syrk, s1);
       hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                         (const double*)dsgn, (const int*)colneg, 1, nz, rank, N, KOUT);
+                         (const double*)dsgn, (const int*)colneg, 1 | (3 << 8), nz, rank, N, KOUT);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
@@ -942,16 +943,19 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
       // tile region.  Large trailing matrices (the serial chain is negligible beside them):
       // full occupancy; otherwise the capped variant leaves the chain room.
       const uint32_t m = nblk - a_end;
-      const uint32_t nsr = (m + 1 + 7) / 8;
+      static const uint32_t sbl = getenv("BA_HIP_SBL") ? (uint32_t)atoi(getenv("BA_HIP_SBL")) : 3u;
+      const uint32_t sbe = 1u << sbl;
+      const uint32_t nsr = (m + 1 + sbe - 1) / sbe;
       const uint32_t nsb = nsr * (nsr + 1) / 2;
-      const uint32_t grid1 = ((nsb + 7) / 8) * 8 * 64;
+      const uint32_t grid1 = ((nsb + 7) / 8) * 8 * sbe * sbe;
+      const int swzf = 1 | (int)(sbl << 8);
       const bool bulk_heavy = m >= bulk_full_m;
       if (no_lookahead || bulk_full || bulk_heavy)
         hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, 1, nz, 0u, 1u, 1u);
+                           (const double*)dsgn, (const int*)colneg, swzf, nz, 0u, 1u, 1u);
       else
         hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, 1, nz, 0u, 1u, 1u);
+                           (const double*)dsgn, (const int*)colneg, swzf, nz, 0u, 1u, 1u);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
