@@ -635,3 +635,23 @@ def test_large_system_properties():
     e0 = h.summary().proj_error
     h.Solve(2)
     assert h.summary().proj_error < e0
+
+
+def test_config1_scale_step_matches_oracle(oracle_lib):
+    """BASELINE.json configs[1] (1k poses / 100k landmarks / 1M residuals) against the oracle on
+    the same scene: the Gauss-Newton step of the first iteration — north_star's parity bar is
+    1e-6 relative on delta_x.  The oracle needs ~7 s for its dense LDL^T."""
+    po = oracle_lib
+    sc = scene.make_scene(1000, 100000, 10, lm_dim=1, seed=2)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    o, h = both(po, sc, 1, active=pa, apply_results=0, write_reduced_camera_matrix=0)
+    o.Solve(1)
+    h.Solve(1)
+    so, sh = o.summary(), h.summary()
+    assert so.result == sh.result == 0
+    assert abs(so.proj_error - sh.proj_error) <= 1e-10 * so.proj_error
+    assert rel_err(h.delta_p(), o.delta_p()) < 1e-6
+    assert rel_err(h.delta_l(), o.delta_l()) < 1e-6
+    print("config-1 scale: delta_p rel err %.2e, delta_l rel err %.2e" %
+          (rel_err(h.delta_p(), o.delta_p()), rel_err(h.delta_l(), o.delta_l())))
