@@ -12,10 +12,10 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 sc = scene.make_scene(P, 10 * P, 6, lm_dim=1, seed=51)
 scene.add_inertial(sc, period=60.0 * P / 100.0)
 objs = []
-for cls, opts in ((po.OracleBundleAdjuster, gn_options(po)), (adjuster.BundleAdjuster, None)):
+for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, use_dogleg=int(os.environ.get("DOGLEG", "0")))), (adjuster.BundleAdjuster, None)):
     b = cls(1, 15)
     if opts is None:
-        opts = adjuster.default_options(); opts.use_dogleg = 0; opts.error_change_threshold = 0; opts.param_change_threshold = 0
+        opts = adjuster.default_options(); opts.use_dogleg = int(os.environ.get("DOGLEG", "0")); opts.error_change_threshold = 0; opts.param_change_threshold = 0
     b.Init(opts)
     b.SetGravity(sc.gravity)
     fill(b, sc)
