@@ -120,6 +120,11 @@ struct Engine {
   DBuf<uint8_t> nzL;                     // tile pattern of the factor L (nt x nt bytes, lower), see k_chol.hip
   bool nzL_valid = false;
   std::vector<uint8_t> nzL_host;         // host copy (flop accounting of the profiled launches)
+  uint64_t nzL_version = 0;
+  // distributed solve: per panel the row tiles with a structurally nonzero tile (message rows)
+  DBuf<uint32_t> dist_rows;
+  std::vector<uint32_t> dist_rows_off;
+  uint64_t dist_rows_version = ~0ull;
   DBuf<double> dist_msg;                 // panel broadcast message (distributed solve)
   DBuf<double> packed;                   // packed lower triangle + rhs row (all-reduce staging)
   DBuf<uint32_t> pose_rows;              // [2*(Pact+1)]: pose-major J-slot ptr | incidence ptr

@@ -560,7 +560,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
   REL(obs_jrow_m); REL(obs_jrow_r); REL(obs_wrow_m); REL(obs_first); REL(lm_wrow_r);
   REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent);
-  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed); REL(nzL); REL(dist_msg);
+  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);

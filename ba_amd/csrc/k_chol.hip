@@ -672,6 +672,7 @@ int factor_tile_pattern(Engine* e) {
   BAE_HIP(e->nzL.alloc(nz.size()));
   BAE_HIP(hipMemcpy(e->nzL.p, nz.data(), nz.size(), hipMemcpyHostToDevice));
   e->nzL_host = nz;
+  e->nzL_version++;
   e->nzL_valid = true;
   return 0;
 }
@@ -707,6 +708,21 @@ k_copy_panel(double* __restrict__ A, uint32_t ld, uint32_t r0, uint32_t c0, uint
              double* __restrict__ buf, int unpack) {
   const uint32_t r = blockIdx.x;
   double* row = A + (size_t)(r0 + r) * ld + c0;
+  double* brow = buf + (size_t)r * w;
+  for (uint32_t cc = threadIdx.x; cc < w; cc += 256) {
+    if (unpack) row[cc] = brow[cc];
+    else brow[cc] = row[cc];
+  }
+}
+
+// the same for a list of 64-row tiles followed by the rhs row (row n_pad): message of a panel
+// without the structurally zero tiles
+__global__ void __launch_bounds__(256)
+k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restrict__ tiles, uint32_t ntiles,
+                  uint32_t n_pad, uint32_t c0, uint32_t w, double* __restrict__ buf, int unpack) {
+  const uint32_t r = blockIdx.x;
+  const uint32_t arow = (r < ntiles * NB) ? tiles[r >> 6] * NB + (r & 63u) : n_pad;
+  double* row = A + (size_t)arow * ld + c0;
   double* brow = buf + (size_t)r * w;
   for (uint32_t cc = threadIdx.x; cc < w; cc += 256) {
     if (unpack) row[cc] = brow[cc];
@@ -775,6 +791,27 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
   double* msg = e->dist_msg.p;
   hipStream_t s0 = e->stream, s1 = e->stream2;
   const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
+  // message rows of every panel: the row tiles at or below the panel with a structurally
+  // nonzero tile in one of its columns (all of them when there is no pattern)
+  const bool pat = nz && e->nzL_host.size() == (size_t)nblk * nblk;
+  const uint64_t want = pat ? e->nzL_version * 64 + KOUT : ~1ull;
+  if (e->dist_rows_version != want || e->dist_rows_off.size() != npanels + 1) {
+    std::vector<uint32_t> list;
+    e->dist_rows_off.assign(npanels + 1, 0);
+    for (uint32_t p = 0; p < npanels; ++p) {
+      const uint32_t J = p * KOUT, Jend = std::min(J + KOUT, nblk);
+      for (uint32_t i = J; i < nblk; ++i) {
+        bool on = !pat || i < Jend;
+        for (uint32_t kb = J; kb < Jend && !on; ++kb) on = e->nzL_host[(size_t)i * nblk + kb] != 0;
+        if (on) list.push_back(i);
+      }
+      e->dist_rows_off[p + 1] = (uint32_t)list.size();
+    }
+    BAE_HIP(e->dist_rows.alloc(std::max<size_t>(list.size(), 1)));
+    if (!list.empty())
+      BAE_HIP(hipMemcpy(e->dist_rows.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    e->dist_rows_version = want;
+  }
   while (e->ev_panel.size() < npanels) {
     hipEvent_t a, b;
     BAE_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -790,7 +827,9 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
   uint32_t pj = 0;
   for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
     const uint32_t Jend = std::min(J + KOUT, nblk), owner = pj % N;
-    const uint32_t w = (Jend - J) * NB, nrows = (nblk - J) * NB + 1;  // incl. the rhs row
+    const uint32_t ntl = e->dist_rows_off[pj + 1] - e->dist_rows_off[pj];
+    const uint32_t* tl = e->dist_rows.p + e->dist_rows_off[pj];
+    const uint32_t w = (Jend - J) * NB, nrows = ntl * NB + 1;  // active row tiles + the rhs row
     const size_t n_cols = (size_t)nrows * w;
     double* m_sgn = msg + n_cols;
     double* m_neg = m_sgn + w;
@@ -803,7 +842,8 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
           hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0, dA, ld,
                              nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, e->flags.p, nz);
       }
-      hipLaunchKernelGGL(k_copy_panel, dim3(nrows), dim3(256), 0, s0, dA, ld, J * NB, J * NB, w, msg, 0);
+      hipLaunchKernelGGL(k_copy_panel_rows, dim3(nrows), dim3(256), 0, s0, dA, ld, tl, ntl, nblk * NB, J * NB, w,
+                         msg, 0);
       BAE_HIP(hipMemcpyAsync(m_sgn, dsgn + (size_t)J * NB, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
       BAE_HIP(hipMemcpyAsync(m_neg, colneg + J, (Jend - J) * sizeof(int), hipMemcpyDeviceToDevice, s0));
       BAE_HIP(hipMemcpyAsync(m_op, opbuf + (size_t)J * NOPV * 64, (size_t)(Jend - J) * NOPV * 64 * sizeof(double),
@@ -813,7 +853,8 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     BAE_HIP(hipStreamSynchronize(s0));  // message complete / previous unpack done
     if (e->coll(e->coll_ctx, 1, msg, msg_len, (int)owner) != 0) return e->fail_msg("broadcast hook failed");
     if (rank != owner) {
-      hipLaunchKernelGGL(k_copy_panel, dim3(nrows), dim3(256), 0, s0, dA, ld, J * NB, J * NB, w, msg, 1);
+      hipLaunchKernelGGL(k_copy_panel_rows, dim3(nrows), dim3(256), 0, s0, dA, ld, tl, ntl, nblk * NB, J * NB, w,
+                         msg, 1);
       BAE_HIP(hipMemcpyAsync(dsgn + (size_t)J * NB, m_sgn, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
       BAE_HIP(hipMemcpyAsync(colneg + J, m_neg, (Jend - J) * sizeof(int), hipMemcpyDeviceToDevice, s0));
       BAE_HIP(hipMemcpyAsync(opbuf + (size_t)J * NOPV * 64, m_op, (size_t)(Jend - J) * NOPV * 64 * sizeof(double),
