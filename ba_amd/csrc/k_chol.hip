@@ -177,17 +177,33 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   BAE_SSTORE(0, 0);
   BAE_GLOAD(0, 2);
   __syncthreads();
-  for (int kc = 0; kc < nchunk; kc += 2) {
+  for (int kc = 0; kc + 2 < nchunk; kc += 2) {
     // LDS stage 0 holds chunk kc, set 1 chunk kc + 1, set 0 (in flight) chunk kc + 2
     BAE_SSTORE(1, 1);
     if (kc + 3 < nchunk) BAE_GLOAD(1, kc + 3);
     BAE_MMA(0);
     __syncthreads();
-    if (kc + 2 < nchunk) { BAE_SSTORE(0, 0); }
+    BAE_SSTORE(0, 0);
     if (kc + 4 < nchunk) BAE_GLOAD(0, kc + 4);
     BAE_MMA(1);
     __syncthreads();
   }
+  // the last two chunks, peeled: both prefetch sets are dead after the next store, so the C
+  // tile is fetched here — its latency hides under the last 32 MFMAs of the wave
+  BAE_SSTORE(1, 1);
+  double4_t cv[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        cv[ti][tj][reg] = Aic[(size_t)(r < rows ? r : 0) * ld + cb + 16 * tj + li];
+      }
+  BAE_MMA(0);
+  __syncthreads();
+  BAE_MMA(1);
 #undef BAE_GLOAD
 #undef BAE_SSTORE
 #undef BAE_MMA
@@ -196,20 +212,13 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj) {
-      double cv[4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int r = rb + 16 * ti + lk + 4 * reg;
-        cv[reg] = Aic[(size_t)(r < rows ? r : 0) * ld + cb + 16 * tj + li];
-      }
+    for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int r = rb + 16 * ti + lk + 4 * reg;
         const int cc = cb + 16 * tj + li;
-        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = cv[reg] - acc[ti][tj][reg];
+        if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = cv[ti][tj][reg] - acc[ti][tj][reg];
       }
-    }
 }
 
 // ---------------------------------------------------------------------------------
