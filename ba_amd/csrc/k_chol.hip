@@ -134,7 +134,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   const int nchunk = (int)nact * (NB / KC2);  // a multiple of 4
   // two register sets: a chunk is loaded two iterations (~2 x 4096 MFMA-pipe cycles at four
   // waves per SIMD) before it is written to LDS
-  double2 px0[2], px1[2], py0[2], py1[2], ps[2];
+  double2 px0[2], px1[2], py0[2], py1[2], ps[2] = {make_double2(1.0, 1.0), make_double2(1.0, 1.0)};
   // `plain`: a full tile and no negative pivot in the K range (every SPD system) — the staged
   // operands are then plain copies, no per-element multiplies in the loop.  The accumulators
   // collect +X D Y^T; the epilogue subtracts.
@@ -147,7 +147,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
     px1[S] = *reinterpret_cast<const double2*>(Xg1 + k0_);                        \
     py0[S] = *reinterpret_cast<const double2*>(Yg0 + k0_);                        \
     py1[S] = *reinterpret_cast<const double2*>(Yg1 + k0_);                        \
-    ps[S] = *reinterpret_cast<const double2*>(dsgn + k0_ + sc);                   \
+    if (!plain) ps[S] = *reinterpret_cast<const double2*>(dsgn + k0_ + sc);       \
   }
 #define BAE_SSTORE(B, S)                                                          \
   if (plain) {                                                                    \
