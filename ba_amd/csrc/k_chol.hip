@@ -62,42 +62,13 @@ static const int LDK2 = KC2 + 2;
 // BULK = true (the look-ahead's background updates on small systems) pads the LDS footprint
 // to 56 KB: at most two such workgroups fit on a CU, which always leaves the 45 KB + one wave
 // per SIMD that a k_step_update / k_trsm_op workgroup of the concurrent serial chain needs.
-template <bool BULK>
-__global__ void __launch_bounds__(256, BULK ? 2 : 4)
-k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
-          uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, int swz,
-          const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
-  __shared__ double X[2][NB][LDK2];
-  __shared__ double Y[2][NB][LDK2];
-  __shared__ uint32_t klist[32];  // the tile columns of [kb0, kb1) with a structurally nonzero product
-  __shared__ double pad_[BULK ? 2432 : 1];
-  if (BULK && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the padding allocated
-  if (!BULK) __builtin_amdgcn_s_setprio(2);  // critical-path launches outrank the bulk waves
-  uint32_t c, i;
-  if (swz & 1) {
-    // XCD-aware 1-D launch (the big trailing updates): workgroups whose ids agree mod 8 share
-    // an XCD and its L2, so each XCD walks its own 8x8 super-blocks of output tiles — the
-    // 8 + 8 operand slices of a super-block (2 MB at K = 256) stay L2-resident instead of
-    // being re-fetched for every tile.  Super-blocks enumerate the lower triangle row by row.
-    const uint32_t sbl = (uint32_t)swz >> 8;  // log2 of the super-block edge (3: 8x8 tiles)
-    const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
-    const uint32_t t = (slot >> (2 * sbl)) * 8u + xcd, within = slot & ((1u << (2 * sbl)) - 1u);
-    uint32_t sr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((uint64_t)(sr + 1) * (sr + 2) / 2 <= t) ++sr;
-    while ((uint64_t)sr * (sr + 1) / 2 > t) --sr;
-    const uint32_t sc = t - (uint32_t)((uint64_t)sr * (sr + 1) / 2);
-    const uint32_t R = (sr << sbl) + (within >> sbl), C = (sc << sbl) + (within & ((1u << sbl) - 1u));
-    if (C > R) return;
-    c = c0 + C;
-    i = c0 + R;
-    if (i > nblk || c >= nblk) return;
-  } else {
-    c = c0 + blockIdx.y;
-    i = c + blockIdx.x;
-    if (i > nblk) return;
-  }
-  // distributed solve: a rank only updates the column panels it owns (panel p -> rank p mod N)
-  if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
+// One 64x64 output tile (i, c): A_ic -= sum over the active tile columns kb of [kb0, kb1) of
+// X_i,kb D_kb X_c,kb^T.  Called by all 256 threads of a workgroup; X, Y, klist are its LDS.
+__device__ __forceinline__ void update_tile(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t i,
+                                            uint32_t c, uint32_t kb0, uint32_t kb1,
+                                            const double* __restrict__ dsgn, const int* __restrict__ colneg,
+                                            const uint8_t* __restrict__ nz, double (*X)[NB][LDK2],
+                                            double (*Y)[NB][LDK2], uint32_t* klist) {
   const int rows = (i == nblk) ? 1 : NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -129,7 +100,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
       ++nact;
     }
   }
-  if (nact == 0) return;  // nothing to subtract from this tile
+  if (nact == 0) return;  // nothing to subtract from this tile (uniform over the workgroup)
   __syncthreads();
   const int nchunk = (int)nact * (NB / KC2);  // a multiple of 4
   // two register sets: a chunk is loaded two iterations (~2 x 4096 MFMA-pipe cycles at four
@@ -219,6 +190,45 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
         const int cc = cb + 16 * tj + li;
         if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = cv[ti][tj][reg] - acc[ti][tj][reg];
       }
+}
+
+template <bool BULK>
+__global__ void __launch_bounds__(256, BULK ? 2 : 4)
+k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
+          uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, int swz,
+          const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
+  __shared__ double X[2][NB][LDK2];
+  __shared__ double Y[2][NB][LDK2];
+  __shared__ uint32_t klist[32];  // the tile columns of [kb0, kb1) with a structurally nonzero product
+  __shared__ double pad_[BULK ? 2432 : 1];
+  if (BULK && kb0 == 0xffffffffu) pad_[threadIdx.x] = 0.0;  // keeps the padding allocated
+  if (!BULK) __builtin_amdgcn_s_setprio(2);  // critical-path launches outrank the bulk waves
+  uint32_t c, i;
+  if (swz & 1) {
+    // XCD-aware 1-D launch (the big trailing updates): workgroups whose ids agree mod 8 share
+    // an XCD and its L2, so each XCD walks its own 8x8 super-blocks of output tiles — the
+    // 8 + 8 operand slices of a super-block (2 MB at K = 256) stay L2-resident instead of
+    // being re-fetched for every tile.  Super-blocks enumerate the lower triangle row by row.
+    const uint32_t sbl = (uint32_t)swz >> 8;  // log2 of the super-block edge (3: 8x8 tiles)
+    const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+    const uint32_t t = (slot >> (2 * sbl)) * 8u + xcd, within = slot & ((1u << (2 * sbl)) - 1u);
+    uint32_t sr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)(sr + 1) * (sr + 2) / 2 <= t) ++sr;
+    while ((uint64_t)sr * (sr + 1) / 2 > t) --sr;
+    const uint32_t sc = t - (uint32_t)((uint64_t)sr * (sr + 1) / 2);
+    const uint32_t R = (sr << sbl) + (within >> sbl), C = (sc << sbl) + (within & ((1u << sbl) - 1u));
+    if (C > R) return;
+    c = c0 + C;
+    i = c0 + R;
+    if (i > nblk || c >= nblk) return;
+  } else {
+    c = c0 + blockIdx.y;
+    i = c + blockIdx.x;
+    if (i > nblk) return;
+  }
+  // distributed solve: a rank only updates the column panels it owns (panel p -> rank p mod N)
+  if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
+  update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, X, Y, klist);
 }
 
 // ---------------------------------------------------------------------------------
@@ -421,6 +431,10 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
   const uint32_t i = c + blockIdx.x;
   if (i > nblk) return;
   const bool special = (blockIdx.x == 0 && blockIdx.y == 0);  // the diagonal tile (c0,c0)
+  if (!special) {  // every other tile: the plain trailing update
+    update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, u.X, u.Y, klist);
+    return;
+  }
   const int rows = (i == nblk) ? 1 : NB;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -433,7 +447,6 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
       ++nact;
     }
   }
-  if (nact == 0 && !special) return;  // nothing to subtract from this tile
   __syncthreads();
   double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
   double4_t acc[2][2];
@@ -490,20 +503,6 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
       }
       __syncthreads();
     }
-  }
-  if (!special) {
-    const bool diag = (i == c);
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int r = rb + 16 * ti + lk + 4 * reg;
-          const int cc = cb + 16 * tj + li;
-          if (r < rows && (!diag || cc <= r)) Aic[(size_t)r * ld + cc] = acc[ti][tj][reg];
-        }
-    return;
   }
   // ---- the diagonal tile: factorise, publish the factor packet of step c0 -------------
   __builtin_amdgcn_s_setprio(3);
