@@ -149,7 +149,9 @@ def main():
     # landmark shards: contiguous, equal counts (every landmark has K residuals, so the
     # Schur work  sum k(k+1)/2  is balanced too)
     lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
+    t_setup = time.perf_counter()
     eng, n_obs_local = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
+    t_setup = time.perf_counter() - t_setup  # host -> device uploads + structure build (once per Solve())
     if world > 1:
         eng.set_allreduce(sharding.torch_allreduce_hook(dist, "cuda"), rank, world)
         # distributed reduced solve: reduce-scatter of S to the panel owners, per-panel
@@ -252,6 +254,9 @@ def main():
                                "algorithmic_bytes": b_gather,
                                "pmc_traffic_bytes": pmc_bytes("bae::k_gather_S")}},
             "phase_ms_last_step": {k: round(v, 4) for k, v in timers.items()},
+            # one-off per Solve(): PCIe uploads of the scene + host-side structure build (gather
+            # lists, tile pattern); NOT part of `value` (inputs are resident when the timed region starts)
+            "setup_s_rank0": round(t_setup, 3),
             "accepted_steps": accepted,
             "final_error": err,
         }
