@@ -22,7 +22,8 @@
  *     insertion order exactly as the reference's Add* calls return them;
  *   - multi-GPU: one engine per device, each holding ALL poses and its shard of
  *     landmarks/projection residuals; the per-iteration sums that cross shards go
- *     through the caller-supplied all-reduce hook (ba_hip_set_allreduce), e.g. RCCL.
+ *     through the caller-supplied all-reduce hook (ba_hip_set_allreduce), e.g. RCCL; with
+ *     the collectives hook (ba_hip_set_collectives) the reduced solve itself is distributed.
  */
 #ifndef BA_HIP_H
 #define BA_HIP_H
