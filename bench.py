@@ -260,6 +260,10 @@ def main():
             "accepted_steps": accepted,
             "final_error": err,
         }
+        for hk in out["hbm_kernels"].values():  # real (PMC) traffic over the live launch time
+            if hk.get("pmc_traffic_bytes") and hk["avg_launch_us"] > 0:
+                hk["pmc_GBs"] = hk["pmc_traffic_bytes"] / (hk["avg_launch_us"] * 1e-6) / 1e9
+                hk["pmc_frac_of_8TBs"] = hk["pmc_GBs"] / HBM_PEAK_GBS
         if not args.no_cpu_baseline and world == 1:
             if P <= 1000:
                 out["cpu_baseline"] = cpu_baseline(sc, lm_dim)
