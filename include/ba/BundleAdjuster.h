@@ -582,7 +582,9 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::DownloadState()
   }
   for (uint32_t l = 0; l < L; ++l) {
     for (int i = 0; i < 4; ++i) landmarks_[l].x_w[i] = lx[4 * (size_t)l + i];
-    landmarks_[l].is_reliable = rel[l] != 0;
+    // is_reliable persists across Solve() calls in the reference (the Landmark objects live on,
+    // BundleAdjuster.cpp:127-134); the engine starts every Solve() with clean flags
+    landmarks_[l].is_reliable = landmarks_[l].is_reliable && rel[l] != 0;
     landmarks_[l].num_outlier_residuals = outl[l];
   }
   return true;

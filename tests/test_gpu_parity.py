@@ -563,6 +563,39 @@ def test_tile_sparse_factorisation_matches_oracle(oracle_lib):
     assert rc == 0 and rel_err(h.delta_p(), x) < 1e-9
 
 
+def test_landmark_reliability_and_outlier_ratio(oracle_lib):
+    """Q9 (BundleAdjuster.cpp:127-134): an inverse depth that would turn negative is reverted and
+    the landmark flagged unreliable; LandmarkOutlierRatio counts residuals above
+    projection_outlier_threshold (:184-186).  Far landmarks with noisy observations trigger both;
+    flags and ratios must agree with the oracle landmark by landmark."""
+    po = oracle_lib
+    sc = scene.make_scene(25, 120, 5, lm_dim=1, seed=29)
+    rng = np.random.default_rng(3)
+    # push a third of the landmarks far away (tiny inverse depth) and perturb their observations
+    lms = sc.landmarks.copy()
+    far = rng.choice(sc.num_landmarks, sc.num_landmarks // 3, replace=False)
+    centre = sc.poses[:, :3].mean(axis=0)
+    lms[far, :3] = centre + (lms[far, :3] - centre) * 200.0
+    sc.landmarks = lms
+    sc.obs_z = sc.obs_z + rng.normal(0, 20.0, sc.obs_z.shape)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    o, h = both(po, sc, 1, active=pa, projection_outlier_threshold=4.0)
+    for _ in range(3):
+        o.Solve(1)
+        h.Solve(1)
+        assert o.summary().result == h.summary().result
+    rel_o = np.array([o.IsLandmarkReliable(i) for i in range(sc.num_landmarks)])
+    rel_h = np.array([h.IsLandmarkReliable(i) for i in range(sc.num_landmarks)])
+    out_o = np.array([o.LandmarkOutlierRatio(i) for i in range(sc.num_landmarks)])
+    out_h = np.array([h.LandmarkOutlierRatio(i) for i in range(sc.num_landmarks)])
+    assert (~rel_o).sum() > 0, "the scene is supposed to produce unreliable landmarks"
+    assert out_o.max() > 0
+    assert np.array_equal(rel_o, rel_h)
+    assert np.allclose(out_o, out_h, rtol=0, atol=1e-12)
+    _state_close(o, h, 1e-7)
+
+
 def test_reduced_camera_matrix_dump(tmp_path, monkeypatch):
     """write_reduced_camera_matrix (BundleAdjuster.cpp:600-606): s.txt / rhs.txt in the
     reference's CSV format reproduce the tapped S and rhs to the printed precision."""
