@@ -563,6 +563,42 @@ def test_tile_sparse_factorisation_matches_oracle(oracle_lib):
     assert rc == 0 and rel_err(h.delta_p(), x) < 1e-9
 
 
+def test_incremental_use_add_then_solve_again(oracle_lib):
+    """The reference's incremental pattern ("Solve may be called repeatedly after
+    more Add* calls"): solve with the first 40 landmarks, add 40 more landmarks with their
+    observations, solve again.  Ids continue, the state of the first Solve() is kept, and the
+    second one must track the oracle."""
+    po = oracle_lib
+    sc = scene.make_scene(20, 80, 5, lm_dim=1, seed=43)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    first = sc.obs_lm < 40
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po)), (adjuster.BundleAdjuster, hip_options())):
+        b = cls(1, 6)
+        b.Init(opts)
+        b.AddCamera(sc.cam_params)
+        b.add_poses(sc.poses, is_active=pa)
+        b.add_landmarks(sc.landmarks[:40], sc.lm_ref_pose[:40])
+        b.add_projection_residuals(sc.obs_z[first], sc.obs_pose[first], sc.obs_lm[first])
+        objs.append(b)
+    o, h = objs
+    o.Solve(2)
+    h.Solve(2)
+    _state_close(o, h)
+    for b in objs:
+        b.add_landmarks(sc.landmarks[40:], sc.lm_ref_pose[40:])
+        ids = b.add_projection_residuals(sc.obs_z[~first], sc.obs_pose[~first], sc.obs_lm[~first])
+        assert b.GetNumLandmarks() == 80
+    o.Solve(2)
+    h.Solve(2)
+    so, sh = o.summary(), h.summary()
+    assert so.result == sh.result
+    assert abs(so.proj_error - sh.proj_error) <= 1e-9 * so.proj_error
+    _state_close(o, h)
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-8
+
+
 def test_landmark_reliability_and_outlier_ratio(oracle_lib):
     """Q9 (BundleAdjuster.cpp:127-134): an inverse depth that would turn negative is reverted and
     the landmark flagged unreliable; LandmarkOutlierRatio counts residuals above
