@@ -563,6 +563,49 @@ def test_tile_sparse_factorisation_matches_oracle(oracle_lib):
     assert rc == 0 and rel_err(h.delta_p(), x) < 1e-9
 
 
+@pytest.mark.parametrize("variant", ["damped", "increase_allowed", "no_robust_norm", "exit_tests", "exit_tests_dogleg"])
+def test_solve_arguments_and_exit_tests(oracle_lib, variant):
+    """Solve()'s arguments and the exit tests of BundleAdjuster.cpp:648-661 (Q14, Q15 defaults):
+    gn_damping (:1108-1110), error_increase_allowed (:1134), the robust norm switch (:1374),
+    and the default thresholds (error change 0.01, parameter change 1e-3) that end the loop with
+    ErrorChangeBelowThreshold / ParamChangeBelowThreshold — the result code, the number of
+    iterations that ran (visible in the state) and the state itself must follow the oracle."""
+    po = oracle_lib
+    sc = scene.make_scene(24, 90, 5, lm_dim=1, seed=47)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    okw, hkw, args = {}, {}, {}
+    if variant == "damped":
+        args = dict(gn_damping=0.5)
+    elif variant == "increase_allowed":
+        args = dict(gn_damping=2.5, error_increase_allowed=True)  # overshoots; the step is kept anyway
+    elif variant == "no_robust_norm":
+        okw = hkw = dict(use_robust_norm_for_proj_residuals=0)
+    oo = gn_options(po, **okw)
+    ho = hip_options(**hkw)
+    if variant.startswith("exit_tests"):
+        for opt in (oo, ho):  # the reference's defaults (BundleAdjuster.h:85-86)
+            opt.error_change_threshold = 0.01
+            opt.param_change_threshold = 1e-3
+            opt.use_dogleg = 1 if variant.endswith("dogleg") else 0
+    o = po.OracleBundleAdjuster(1, 6)
+    o.Init(oo)
+    h = adjuster.BundleAdjuster(1, 6)
+    h.Init(ho)
+    fill(o, sc, active=pa)
+    fill(h, sc, active=pa)
+    iters = 12 if variant.startswith("exit_tests") else (2 if variant == "increase_allowed" else 3)
+    o.Solve(iters, **args)
+    h.Solve(iters, **args)
+    so, sh = o.summary(), h.summary()
+    assert so.result == sh.result
+    if variant.startswith("exit_tests"):
+        assert so.result in (2, 3)  # ErrorChangeBelowThreshold / ParamChangeBelowThreshold
+    assert abs(so.proj_error - sh.proj_error) <= 1e-8 * max(so.proj_error, 1e-12)
+    assert abs(so.delta_norm - sh.delta_norm) <= 1e-6 * max(so.delta_norm, 1e-9)
+    _state_close(o, h, 1e-7)
+
+
 def test_incremental_use_add_then_solve_again(oracle_lib):
     """The reference's incremental pattern ("Solve may be called repeatedly after
     more Add* calls"): solve with the first 40 landmarks, add 40 more landmarks with their
