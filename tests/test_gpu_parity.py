@@ -606,6 +606,49 @@ def test_solve_arguments_and_exit_tests(oracle_lib, variant):
     _state_close(o, h, 1e-7)
 
 
+@pytest.mark.parametrize("pose_dim", [6, 15])
+def test_regularize_pose_and_root_pose(oracle_lib, pose_dim):
+    """Gauge handling of BuildProblem (:1237-1330, a3): RegularizePose on chosen poses (Q8: the
+    rotation flag masks indices 2,4,5), a non-default root pose (SetRootPoseId) under automatic
+    regularisation with every pose active, velocities / biases in the state for PoseSize 15
+    (gravity-axis regularisation, bias regularisation).  Masked parameters carry 1e6 on the
+    diagonal of S (Q12) and stay put."""
+    po = oracle_lib
+    P = 18
+    sc = scene.make_scene(P, 70, 5, lm_dim=1, seed=53)
+    if pose_dim == 15:
+        scene.add_inertial(sc, period=60.0 * P / 100.0)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po)), (adjuster.BundleAdjuster, hip_options())):
+        b = cls(1, pose_dim)
+        b.Init(opts)
+        if pose_dim == 15:
+            b.SetGravity(sc.gravity)
+        fill(b, sc)  # all poses active: the gauge comes from the masks alone
+        if pose_dim == 15:
+            for i in range(P - 1):
+                b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+        b.SetRootPoseId(5)
+        b.RegularizePose(2, True, False, False, False)    # translation
+        b.RegularizePose(9, False, False, False, True)    # "rotation": indices 2, 4, 5
+        b.RegularizePose(12, True, pose_dim == 15, pose_dim == 15, True)
+        objs.append(b)
+    o, h = objs
+    p_before = h.poses()[0].copy()
+    for it in range(2):
+        o.Solve(1)
+        h.Solve(1)
+        assert o.summary().result == h.summary().result
+        if it == 0:
+            assert rel_err(h.S(), o.S()) < 1e-9
+            assert rel_err(h.rhs(), o.rhs()) < 1e-9
+            d = np.diag(h.S())
+            assert (d == 1e6).sum() >= 3 + 3 + 3  # the masks put 1e6 on the diagonal
+    _state_close(o, h, 1e-6)
+    p_after = h.poses()[0]
+    assert np.array_equal(p_after[2, :3], p_before[2, :3])  # translation of pose 2 held fixed
+
+
 def test_incremental_use_add_then_solve_again(oracle_lib):
     """The reference's incremental pattern ("Solve may be called repeatedly after
     more Add* calls"): solve with the first 40 landmarks, add 40 more landmarks with their
