@@ -649,6 +649,44 @@ def test_regularize_pose_and_root_pose(oracle_lib, pose_dim):
     assert np.array_equal(p_after[2, :3], p_before[2, :3])  # translation of pose 2 held fixed
 
 
+@pytest.mark.parametrize("variant", ["robust_inertial", "biases_in_batch", "imu_weights", "imu_sigmas"])
+def test_visual_inertial_options(oracle_lib, variant):
+    """Options of the inertial path (BundleAdjuster.h:72-107, BundleAdjuster.cpp:1494-1541):
+    Huber weighting of the IMU residuals, regularize_biases_in_batch, per-residual weights of
+    AddImuResidual, non-default gyro / accelerometer sigmas in the covariance propagation."""
+    po = oracle_lib
+    P = 16
+    sc = scene.make_scene(P, 60, 5, lm_dim=1, seed=57)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    kw = {}
+    if variant == "robust_inertial":
+        kw = dict(use_robust_norm_for_inertial_residuals=1)
+    elif variant == "biases_in_batch":
+        kw = dict(regularize_biases_in_batch=1)
+    elif variant == "imu_sigmas":
+        kw = dict(gyro_sigma=2e-4, accel_sigma=5e-3, gyro_bias_sigma=1e-5, accel_bias_sigma=2e-4)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, **kw)), (adjuster.BundleAdjuster, hip_options(**kw))):
+        b = cls(1, 15)
+        b.Init(opts)
+        b.SetGravity(sc.gravity)
+        fill(b, sc)
+        for i in range(P - 1):
+            b.AddImuResidual(i, i + 1, sc.imu_meas[i], 0.25 + 0.1 * i if variant == "imu_weights" else 1.0)
+        objs.append(b)
+    o, h = objs
+    for it in range(2):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        if it == 0:
+            assert rel_err(h.S(), o.S()) < 1e-9
+            assert rel_err(h.rhs(), o.rhs()) < 1e-9
+        assert abs(so.inertial_error - sh.inertial_error) <= 1e-6 * max(so.inertial_error, 1e-12)
+    _state_close(o, h, 1e-6)
+
+
 def test_incremental_use_add_then_solve_again(oracle_lib):
     """The reference's incremental pattern ("Solve may be called repeatedly after
     more Add* calls"): solve with the first 40 landmarks, add 40 more landmarks with their
