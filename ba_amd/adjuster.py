@@ -61,6 +61,7 @@ SYMBOLS = [
     "ba_adjuster_solve", "ba_adjuster_num_poses", "ba_adjuster_num_landmarks",
     "ba_adjuster_num_proj_residuals", "ba_adjuster_get_poses", "ba_adjuster_get_landmarks",
     "ba_adjuster_is_landmark_reliable", "ba_adjuster_landmark_outlier_ratio",
+    "ba_adjuster_get_projection_residual",
     "ba_adjuster_get_summary", "ba_adjuster_get_timers", "ba_adjuster_engine",
     "ba_adjuster_set_allreduce",
 ]
@@ -205,6 +206,14 @@ class BundleAdjuster:
 
     def LandmarkOutlierRatio(self, i):
         return self.L.ba_adjuster_landmark_outlier_ratio(self.h, int(i))
+
+    def GetProjectionResidual(self, i):
+        """dict view of ba::ProjectionResidualT (reference BundleAdjuster.h:568-571)."""
+        o = np.empty(11)
+        self.L.ba_adjuster_get_projection_residual(self.h, int(i), _p(o, dp))
+        return {"z": o[0:2].copy(), "residual": o[2:4].copy(), "weight": o[4], "orig_weight": o[5],
+                "mahalanobis_distance": o[6], "x_meas_id": int(o[7]), "x_ref_id": int(o[8]),
+                "landmark_id": int(o[9]), "cam_id": int(o[10])}
 
     # -- bulk adders -----------------------------------------------------------------
     def add_poses(self, t_wp, v_w=None, b=None, is_active=None, time=None):

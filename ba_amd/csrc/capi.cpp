@@ -28,6 +28,7 @@ struct Iface {
   virtual void get_landmarks(double* x) const = 0;
   virtual int reliable(uint32_t id) const = 0;
   virtual double outlier_ratio(uint32_t id) const = 0;
+  virtual void proj_residual(uint32_t id, double* out11) const = 0;
   virtual void summary(ba_summary* s) = 0;
   virtual void timers(ba_hip_timers* t) const = 0;
   virtual ba_hip_engine* engine() = 0;
@@ -116,6 +117,12 @@ struct Impl : Iface {
   }
   int reliable(uint32_t id) const override { return ba.IsLandmarkReliable(id) ? 1 : 0; }
   double outlier_ratio(uint32_t id) const override { return ba.LandmarkOutlierRatio(id); }
+  void proj_residual(uint32_t id, double* o) const override {
+    const typename BA::ProjectionResidual& r = ba.GetProjectionResidual(id);
+    o[0] = r.z[0]; o[1] = r.z[1]; o[2] = r.residual[0]; o[3] = r.residual[1];
+    o[4] = r.weight; o[5] = r.orig_weight; o[6] = r.mahalanobis_distance;
+    o[7] = r.x_meas_id; o[8] = r.x_ref_id; o[9] = r.landmark_id; o[10] = r.cam_id;
+  }
   void summary(ba_summary* s) override {
     const auto& m = ba.GetSolutionSummary();
     s->num_proj_residuals = m.num_proj_residuals; s->num_inertial_residuals = m.num_inertial_residuals;
@@ -222,6 +229,7 @@ void ba_adjuster_get_poses(const ba_adjuster* a, double* t_wp, double* v_w, doub
 void ba_adjuster_get_landmarks(const ba_adjuster* a, double* x_w) { a->p->get_landmarks(x_w); }
 int ba_adjuster_is_landmark_reliable(const ba_adjuster* a, uint32_t id) { return a->p->reliable(id); }
 double ba_adjuster_landmark_outlier_ratio(const ba_adjuster* a, uint32_t id) { return a->p->outlier_ratio(id); }
+void ba_adjuster_get_projection_residual(const ba_adjuster* a, uint32_t id, double* out11) { a->p->proj_residual(id, out11); }
 void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s) { a->p->summary(s); }
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t) { a->p->timers(t); }
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a) { return a->p->engine(); }

@@ -196,6 +196,7 @@ struct Engine {
 int launch_pose_prep(Engine* e);                       // T_sw, T_ws, T_wp of the current state
 int launch_begin_solve(Engine* e);                     // x_s from x_w
 int launch_end_solve(Engine* e);                       // x_w from x_s
+int launch_residual_vectors(Engine* e, double* d_r2);  // z - pi per observation at the current state
 int launch_residuals(Engine* e, int mode);             // mode 0: errors for the median; 1: EvaluateResiduals
 int launch_landmarks(Engine* e, double c_huber, int use_robust);  // Jacobians, V, W, rows
 int launch_gather_S(Engine* e);

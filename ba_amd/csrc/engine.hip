@@ -1039,6 +1039,27 @@ int ba_hip_get_proj_weights(ba_hip_engine* h, double* weight) {
   return 0;
 }
 
+int ba_hip_get_proj_residuals(ba_hip_engine* h, double* residual2) {
+  ENG(h);
+  NEED_FINAL();
+  const Structure& st = e->st;
+  if (st.O == 0) return 0;
+  BAE_HIP(hipSetDevice(e->device));
+  DBuf<double> d;
+  BAE_HIP(d.alloc((size_t)2 * st.O));
+  int rc = launch_residual_vectors(e, d.p);
+  if (rc) { d.release(); return rc; }
+  std::vector<double> r((size_t)2 * st.O);
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  BAE_HIP(hipMemcpy(r.data(), d.p, r.size() * sizeof(double), hipMemcpyDeviceToHost));
+  d.release();
+  for (uint32_t s = 0; s < st.O; ++s) {
+    residual2[2 * (size_t)st.obs_perm[s]] = r[2 * (size_t)s];
+    residual2[2 * (size_t)st.obs_perm[s] + 1] = r[2 * (size_t)s + 1];
+  }
+  return 0;
+}
+
 int ba_hip_get_unary_scales(ba_hip_engine* h, double* scale) {
   ENG(h);
   NEED_FINAL();

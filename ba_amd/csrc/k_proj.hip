@@ -168,6 +168,49 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
   }
 }
 
+// Debug / read-back tap: the residual vector z - pi of every observation at the CURRENT state
+// (what ProjectionResidual::residual holds after the last EvaluateResiduals of a Solve(),
+// BundleAdjuster.cpp:155-181).
+template <int LM>
+__global__ void k_residual_vectors(int O, int C, const double* __restrict__ obs_z,
+                                   const uint32_t* __restrict__ obs_pose, const uint32_t* __restrict__ obs_cam,
+                                   const uint32_t* __restrict__ obs_lm, const double* __restrict__ lm_x,
+                                   const uint32_t* __restrict__ lm_ref_pose,
+                                   const uint32_t* __restrict__ lm_ref_cam, const double* __restrict__ cam,
+                                   const double* __restrict__ tsw, const double* __restrict__ tws,
+                                   double* __restrict__ r2) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= O) return;
+  const uint32_t l = obs_lm[a], pm = obs_pose[a], cm = obs_cam[a];
+  const double* x = lm_x + (size_t)l * 4;
+  const Rt t_sw_m = load_rt(tsw + ((size_t)pm * C + cm) * kRt);
+  Rt t_ws_r = t_sw_m;
+  if (LM == 1) t_ws_r = load_rt(tws + ((size_t)lm_ref_pose[l] * C + lm_ref_cam[l]) * kRt);
+  const V3 P = proj_point<LM>(t_sw_m, t_ws_r, x);
+  const double* cp = cam + (size_t)cm * 35;
+  Cam cc = {cp[0], cp[1], cp[2], cp[3]};
+  double u, v;
+  project(cc, P, &u, &v);
+  r2[2 * (size_t)a] = obs_z[2 * (size_t)a] - u;
+  r2[2 * (size_t)a + 1] = obs_z[2 * (size_t)a + 1] - v;
+}
+
+int launch_residual_vectors(Engine* e, double* d_r2) {
+  const int O = e->st.O;
+  if (O == 0) return 0;
+  int rc;
+  if ((rc = launch_pose_prep(e))) return rc;
+  const dim3 grid((O + 255) / 256), block(256);
+#define BAE_ARGS                                                                              \
+  O, (int)e->st.C, e->obs_z.p, e->obs_pose.p, e->obs_cam.p, e->obs_lm.p, e->lm_x[e->cur].p,   \
+      e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->tsw.p, e->tws.p, d_r2
+  if (e->lm_dim == 1) hipLaunchKernelGGL(k_residual_vectors<1>, grid, block, 0, e->stream, BAE_ARGS);
+  else hipLaunchKernelGGL(k_residual_vectors<3>, grid, block, 0, e->stream, BAE_ARGS);
+#undef BAE_ARGS
+  BAE_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_residuals(Engine* e, int mode) {
   const int O = e->st.O;
   if (O == 0) return 0;

@@ -107,6 +107,7 @@ class BundleAdjuster {
 
   typedef PoseT<Scalar> Pose;
   typedef LandmarkT<Scalar, LmSize> Landmark;
+  typedef ProjectionResidualT<Scalar, LmSize> ProjectionResidual;
   typedef ImuMeasurementT<Scalar> ImuMeasurement;
   typedef ImuCalibrationT<Scalar> ImuCalibration;
   typedef ba::Vector2t Vector2t;
@@ -144,6 +145,7 @@ class BundleAdjuster {
     poses_.clear(); landmarks_.clear();
     poses_.reserve(std::max(1u, num_poses)); landmarks_.reserve(std::max(1u, num_landmarks));
     pr_z_.clear(); pr_pose_.clear(); pr_lm_.clear(); pr_cam_.clear(); pr_w_.clear();
+    proj_view_dirty_ = true; uploaded_once_ = false;
     pr_z_.reserve(2 * (size_t)std::max(1u, num_measurements));
     un_pose_.clear(); un_t_.clear(); un_cov_inv_.clear(); un_rot_.clear();
     bin_p1_.clear(); bin_p2_.clear(); bin_t_.clear(); bin_cov_inv_.clear(); bin_cov_inv_sqrt_.clear();
@@ -307,6 +309,30 @@ class BundleAdjuster {
   uint32_t GetNumPoses() const { return (uint32_t)poses_.size(); }
   uint32_t GetNumImuResiduals() const { return (uint32_t)imu_p1_.size(); }
   uint32_t GetNumProjResiduals() const { return (uint32_t)pr_pose_.size(); }
+  // reference :568-571.  The residual vectors and Huber weights are fetched from the device on
+  // the first call after a Solve() (one copy of 3 doubles per residual), then served from the host.
+  const ProjectionResidual& GetProjectionResidual(uint32_t id) const {
+    if (proj_view_dirty_ && engine_ && !pr_pose_.empty() && uploaded_once_ && !structure_dirty_) {
+      proj_view_r_.assign(2 * pr_pose_.size(), 0.0);
+      proj_view_w_.assign(pr_pose_.size(), 0.0);
+      if (ba_hip_get_proj_residuals(engine_, proj_view_r_.data()) == 0 &&
+          ba_hip_get_proj_weights(engine_, proj_view_w_.data()) == 0)
+        proj_view_dirty_ = false;
+    }
+    ProjectionResidual& r = proj_view_;
+    r.residual_id = id;
+    r.residual_offset = id * ProjectionResidual::kResSize;
+    r.z[0] = pr_z_[2 * (size_t)id]; r.z[1] = pr_z_[2 * (size_t)id + 1];
+    r.x_meas_id = pr_pose_[id]; r.landmark_id = pr_lm_[id]; r.cam_id = pr_cam_[id];
+    r.x_ref_id = landmarks_[pr_lm_[id]].ref_pose_id;
+    r.orig_weight = pr_w_[id];
+    const bool have = !proj_view_dirty_ && !structure_dirty_ && proj_view_w_.size() == pr_pose_.size();
+    r.weight = have ? proj_view_w_[id] : pr_w_[id];
+    r.residual[0] = have ? proj_view_r_[2 * (size_t)id] : 0.0;
+    r.residual[1] = have ? proj_view_r_[2 * (size_t)id + 1] : 0.0;
+    r.mahalanobis_distance = (r.residual[0] * r.residual[0] + r.residual[1] * r.residual[1]) * r.weight;
+    return r;
+  }
   uint32_t GetNumLandmarks() const { return (uint32_t)landmarks_.size(); }
   uint32_t GetNumUnaryResiduals() const { return (uint32_t)un_pose_.size(); }
   const ImuCalibration& GetImuCalibration() const { return imu_; }
@@ -395,6 +421,10 @@ class BundleAdjuster {
   std::vector<Pose> poses_;
   std::vector<Landmark> landmarks_;
   std::vector<double> pr_z_, pr_w_;
+  mutable std::vector<double> proj_view_r_, proj_view_w_;  // GetProjectionResidual cache
+  mutable ProjectionResidual proj_view_;
+  mutable bool proj_view_dirty_ = true;
+  bool uploaded_once_ = false;
   std::vector<uint32_t> pr_pose_, pr_lm_, pr_cam_;
   std::vector<uint32_t> un_pose_; std::vector<double> un_t_, un_cov_inv_; std::vector<uint8_t> un_rot_;
   std::vector<uint32_t> bin_p1_, bin_p2_; std::vector<double> bin_t_, bin_cov_inv_, bin_cov_inv_sqrt_, bin_w_;
@@ -744,6 +774,8 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     ba_hip_get_step(engine_, last_step_.delta_p.data(), last_step_.delta_l.data());
   }
   if (!DownloadState()) return;
+  uploaded_once_ = true;
+  proj_view_dirty_ = true;  // GetProjectionResidual re-reads the device on its next call
   if (!un_pose_.empty()) {
     // the reference scales each unary cov_inv in place every BuildProblem
     // (BundleAdjuster.cpp:1469), so the compounded weights survive across Solve() calls

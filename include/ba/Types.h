@@ -161,6 +161,20 @@ struct LandmarkT {
   bool is_active = true, is_reliable = true;
 };
 
+// reference Types.h:246-253, 282-298: what callers read back of a projection residual (the
+// cached Jacobian blocks dz_dx_meas / dz_dx_ref / dz_dlm live only on the device)
+template <typename Scalar = double, int LmSize = 1>
+struct ProjectionResidualT {
+  static const uint32_t kResSize = 2;
+  uint32_t residual_id = 0, residual_offset = 0;
+  Scalar mahalanobis_distance = 0;  // |residual|^2 * weight at the last evaluation
+  Scalar weight = 1, orig_weight = 1;
+  Vector2t z;
+  uint32_t x_meas_id = 0, x_ref_id = 0, landmark_id = 0, cam_id = 0;
+  Vector2t residual;                // z - pi at the state the last Solve() left behind
+  bool is_conditioning = false;
+};
+
 // reference Types.h:112-159 (fields used on the hot path)
 template <typename Scalar = double>
 struct ImuCalibrationT {

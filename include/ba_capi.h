@@ -80,6 +80,9 @@ void ba_adjuster_get_poses(const ba_adjuster* a, double* t_wp, double* v_w, doub
 void ba_adjuster_get_landmarks(const ba_adjuster* a, double* x_w);
 int ba_adjuster_is_landmark_reliable(const ba_adjuster* a, uint32_t id);
 double ba_adjuster_landmark_outlier_ratio(const ba_adjuster* a, uint32_t id);
+/* GetProjectionResidual(id): out11 = z(2), residual(2), weight, orig_weight, mahalanobis_distance,
+ * x_meas_id, x_ref_id, landmark_id, cam_id */
+void ba_adjuster_get_projection_residual(const ba_adjuster* a, uint32_t id, double* out11);
 void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s);
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
 /* the engine behind the adjuster (valid after the first Solve) for the debug taps of ba_hip.h */

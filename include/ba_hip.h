@@ -166,6 +166,9 @@ int ba_hip_get_rhs(ba_hip_engine* e, double* rhs_p_sc, double* rhs_p, double* rh
 int ba_hip_get_delta_gn(ba_hip_engine* e, double* delta_p, double* delta_l);
 int ba_hip_get_step(ba_hip_engine* e, double* delta_p, double* delta_l);
 int ba_hip_get_proj_weights(ba_hip_engine* e, double* weight); /* per residual id */
+/* residual vectors z - pi (2 doubles per residual id) at the current state, i.e. what
+ * ProjectionResidual::residual holds after a Solve() (BundleAdjuster.cpp:155-181) */
+int ba_hip_get_proj_residuals(ba_hip_engine* e, double* residual2);
 int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
 /* cumulative Huber scale of every unary residual's cov^-1 (the reference multiplies
  * cov_inv in place every BuildProblem, BundleAdjuster.cpp:1469) */

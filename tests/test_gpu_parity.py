@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from ba_amd import adjuster, hipapi, scene
-from helpers import fill, gn_options, rel_err
+from helpers import accepted_obs, fill, gn_options, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -685,6 +685,31 @@ def test_visual_inertial_options(oracle_lib, variant):
             assert rel_err(h.rhs(), o.rhs()) < 1e-9
         assert abs(so.inertial_error - sh.inertial_error) <= 1e-6 * max(so.inertial_error, 1e-12)
     _state_close(o, h, 1e-6)
+
+
+def test_get_projection_residual(oracle_lib):
+    """GetProjectionResidual(id) after a Solve() (reference BundleAdjuster.h:568-571,
+    BundleAdjuster.cpp:155-181): ids, measurement, Huber weight and the residual vector z - pi at
+    the state the solve left behind, against the oracle's per-residual records."""
+    po = oracle_lib
+    sc = scene.make_scene(15, 50, 5, lm_dim=1, seed=59)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    o, h = both(po, sc, 1, active=pa)
+    o.Solve(2)
+    h.Solve(2)
+    assert o.summary().result == h.summary().result == 0
+    r_o, w_o = o.proj_residuals(), o.proj_weights()
+    acc = accepted_obs(sc)
+    n = h.GetNumProjResiduals()
+    assert n == len(acc) == len(w_o)
+    for rid in list(range(0, n, 7)) + [n - 1]:
+        r = h.GetProjectionResidual(rid)
+        assert (r["x_meas_id"], r["x_ref_id"], r["landmark_id"]) == acc[rid]
+        assert np.allclose(r["residual"], r_o[rid], rtol=0, atol=1e-7 * max(1.0, np.abs(r_o[rid]).max()))
+        assert abs(r["weight"] - w_o[rid]) <= 1e-9 * max(w_o[rid], 1e-12)
+        assert abs(r["mahalanobis_distance"] - (r_o[rid] ** 2).sum() * w_o[rid]) <= 1e-6 * max(1.0, (r_o[rid] ** 2).sum())
+        assert r["orig_weight"] == 1.0
 
 
 def test_incremental_use_add_then_solve_again(oracle_lib):
