@@ -1,0 +1,80 @@
+"""Randomised parity sweep (scratch soak, not part of the suite): many small scenes with random
+sizes, LmSize, PoseSize, dogleg on/off, random inactive poses / landmarks, optional IMU and
+pose-pose constraints; engine vs oracle over 3 iterations."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from ba_amd import adjuster, scene
+from oracle import pyoracle as po
+from helpers import fill, gn_options, rel_err
+po.build()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+worst = 0.0
+ONLY = set(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 else None
+for trial in range(N):
+    P = int(rng.integers(6, 60)); L = int(rng.integers(10, 200)); K = int(rng.integers(3, min(P - 1, 8)))
+    lm_dim = int(rng.choice([1, 3])); pose_dim = int(rng.choice([6, 6, 15])); dog = int(rng.integers(0, 2))
+    seed = int(rng.integers(1, 10000))
+    try:
+        sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=seed)
+    except RuntimeError:
+        print('trial %2d skipped (scene generator)' % trial); continue
+    if pose_dim == 15:
+        scene.add_inertial(sc, period=60.0 * P / 100.0)
+    pa = np.ones(P, dtype=np.uint8); la = np.ones(L, dtype=np.uint8)
+    if pose_dim == 6:
+        pa[sc.anchor_poses] = 0
+    if rng.random() < 0.5:
+        pa[rng.choice(P, max(1, P // 10), replace=False)] = 0
+    if rng.random() < 0.5:
+        la[rng.choice(L, max(1, L // 10), replace=False)] = 0
+    if ONLY is not None and trial not in ONLY:
+        rng.random(); rng.random(); continue
+    objs = []
+    for cls in (po.OracleBundleAdjuster, adjuster.BundleAdjuster):
+        if cls is po.OracleBundleAdjuster:
+            opts = gn_options(po, use_dogleg=dog)
+        else:
+            opts = adjuster.default_options(); opts.use_dogleg = dog; opts.error_change_threshold = 0; opts.param_change_threshold = 0
+        b = cls(lm_dim, pose_dim); b.Init(opts)
+        if pose_dim == 15:
+            b.SetGravity(sc.gravity)
+        fill(b, sc, active=pa, lm_active=la)
+        if pose_dim == 15:
+            for i in range(P - 1):
+                b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+        if rng.random() < 0.0:
+            pass
+        objs.append(b)
+    # the same random pose-pose constraints on both
+    r2 = np.random.default_rng(seed)
+    for i in range(0, P - 1, 3):
+        if r2.random() < 0.3:
+            for b in objs:
+                b.AddUnaryConstraint(i, sc.gt_poses[i], 1e-2 * np.eye(6), bool(i % 2))
+    o, h = objs
+    ok = True; cond = 1.0
+    for it in range(3):
+        o.Solve(1); h.Solve(1)
+        S0 = o.S()
+        if S0.size:
+            w0 = np.linalg.eigvalsh(np.triu(S0) + np.triu(S0, 1).T); cond = max(cond, w0.max() / max(w0.min(), 1e-300) if w0.min() > 0 else np.inf)
+        so, sh = o.summary(), h.summary()
+        if so.result != sh.result:
+            ok = False; print("RESULT MISMATCH", trial, it, so.result, sh.result); break
+        if ONLY is not None:
+            S = o.S(); U = np.triu(S); w = np.linalg.eigvalsh(U + np.triu(S, 1).T) if S.size else np.zeros(1)
+            print('   it %d pose diff %.2e lm diff %.2e  proj err oracle %.15g engine %.15g  delta %.3e/%.3e eig(S) min %.3e max %.3e' % (it, rel_err(h.poses()[0], o.poses()[0]), rel_err(h.landmarks(), o.landmarks()), so.proj_error, sh.proj_error, so.delta_norm, sh.delta_norm, w.min(), w.max()))
+    po_, ph = o.poses()[0], h.poses()[0]
+    d = rel_err(ph, po_)
+    dl = rel_err(h.landmarks(), o.landmarks())
+    # a numerically singular reduced system (an unobserved direction) has no unique solution:
+    # unpivoted LDLT on either side returns an arbitrary one, so only well-posed trials are compared
+    tol = max(1e-9, 1e-15 * cond)
+    flag = "" if (ok and d < tol and dl < tol) else ("  (singular S: not comparable)" if cond > 1e14 else "  <-- CHECK")
+    if cond <= 1e14:
+        worst = max(worst, d, dl)
+    print("trial %2d P=%2d L=%3d K=%d lm=%d D=%2d dogleg=%d result=%d cond %.1e pose %.1e lm %.1e%s" % (trial, P, L, K, lm_dim, pose_dim, dog, so.result, cond, d, dl, flag), flush=True)
+print("worst rel diff %.2e" % worst)
