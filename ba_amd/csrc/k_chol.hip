@@ -59,6 +59,126 @@ static const int LDM = 18;  // LDS row stride of the 16x16 diagonal inverses
 static const int KC2 = 16;
 static const int LDK2 = KC2 + 2;
 
+// Fast path of update_tile — a full 64-row tile and no negative pivot in the K range (every tile
+// of an SPD system except the rhs row).  Hand-scheduled:
+//   * the active tile columns come from a wave-uniform bit mask (one pattern byte per lane,
+//     __ballot) and are walked with scalar bit operations: no LDS list, no serial loads;
+//   * one loop iteration = one tile column = four 16-wide chunks with static LDS stages and
+//     static prefetch sets; the last tile column is a second copy of the body that fetches the C
+//     tile instead of operands;
+//   * operand fragments of k-step s + 1 are read from LDS while the four MFMAs of k-step s run
+//     (two fragment sets); the single barrier of a chunk sits between k-steps 2 and 3, so the
+//     first fragments of the next chunk are read under the last MFMAs of this one.
+//     sched_barrier pins that order (the compiler otherwise issues each fragment read directly
+//     in front of the MFMAs that need it).
+__device__ __forceinline__ void update_tile_fast(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t c,
+                                                 uint32_t kb0, uint64_t mask, double (*X)[NB][LDK2],
+                                                 double (*Y)[NB][LDK2]) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1);
+  double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int sr = tid >> 3, sc = (tid & 7) * 2;
+  const double* Xg0 = A + ((size_t)i * NB + sr) * ld + sc;
+  const double* Xg1 = Xg0 + (size_t)32 * ld;
+  const double* Yg0 = A + ((size_t)c * NB + sr) * ld + sc;
+  const double* Yg1 = Yg0 + (size_t)32 * ld;
+  double2 px0[2], px1[2], py0[2], py1[2];
+  double F0[4], F1[4];
+  double4_t cv[2][2];
+#define BAE_SB __builtin_amdgcn_sched_barrier(0)
+#define BAE_GLOAD(S, K0)                                        \
+  {                                                             \
+    px0[S] = *reinterpret_cast<const double2*>(Xg0 + (K0));     \
+    px1[S] = *reinterpret_cast<const double2*>(Xg1 + (K0));     \
+    py0[S] = *reinterpret_cast<const double2*>(Yg0 + (K0));     \
+    py1[S] = *reinterpret_cast<const double2*>(Yg1 + (K0));     \
+  }
+#define BAE_SSTORE(B, S)                                                    \
+  {                                                                         \
+    X[B][sr][sc] = px0[S].x; X[B][sr][sc + 1] = px0[S].y;                   \
+    X[B][sr + 32][sc] = px1[S].x; X[B][sr + 32][sc + 1] = px1[S].y;         \
+    Y[B][sr][sc] = py0[S].x; Y[B][sr][sc + 1] = py0[S].y;                   \
+    Y[B][sr + 32][sc] = py1[S].x; Y[B][sr + 32][sc + 1] = py1[S].y;         \
+  }
+#define BAE_LDF(F, B, KS)                                                              \
+  {                                                                                    \
+    F[0] = X[B][rb + li][4 * (KS) + lk]; F[1] = X[B][rb + 16 + li][4 * (KS) + lk];     \
+    F[2] = Y[B][cb + li][4 * (KS) + lk]; F[3] = Y[B][cb + 16 + li][4 * (KS) + lk];     \
+  }
+#define BAE_MM(F)                                                                    \
+  {                                                                                  \
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], F[2], acc[0][0], 0, 0, 0); \
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[0], F[3], acc[0][1], 0, 0, 0); \
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], F[2], acc[1][0], 0, 0, 0); \
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[1], F[3], acc[1][1], 0, 0, 0); \
+  }
+// chunk j of a tile column, operands in LDS stage (j & 1), ks = 0 fragments already in F0
+#define BAE_CHUNK(J, STORE, LOADK, NEXT)                          \
+  {                                                               \
+    if (STORE) BAE_SSTORE(((J) + 1) & 1, ((J) + 1) & 1);          \
+    LOADK;                                                        \
+    BAE_SB; BAE_LDF(F1, (J) & 1, 1); BAE_SB; BAE_MM(F0); BAE_SB;  \
+    BAE_LDF(F0, (J) & 1, 2); BAE_SB; BAE_MM(F1); BAE_SB;          \
+    BAE_LDF(F1, (J) & 1, 3); BAE_SB; BAE_MM(F0); BAE_SB;          \
+    __syncthreads(); BAE_SB;                                      \
+    if (NEXT) BAE_LDF(F0, ((J) + 1) & 1, 0);                      \
+    BAE_SB; BAE_MM(F1); BAE_SB;                                   \
+  }
+  // scalar walk over the set bits of the mask
+  uint32_t kcur = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
+  mask &= mask - 1;
+  BAE_GLOAD(0, kcur);
+  BAE_GLOAD(1, kcur + KC2);
+  BAE_SSTORE(0, 0);
+  BAE_GLOAD(0, kcur + 2 * KC2);
+  __syncthreads();
+  BAE_LDF(F0, 0, 0);
+  while (mask) {
+    const uint32_t knext = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
+    mask &= mask - 1;
+    // stage 0 holds chunk 0 of this column, set 1 chunk 1, set 0 (in flight) chunk 2
+    BAE_CHUNK(0, true, BAE_GLOAD(1, kcur + 3 * KC2), true);
+    BAE_CHUNK(1, true, BAE_GLOAD(0, knext), true);
+    BAE_CHUNK(2, true, BAE_GLOAD(1, knext + KC2), true);
+    BAE_CHUNK(3, true, BAE_GLOAD(0, knext + 2 * KC2), true);
+    kcur = knext;
+  }
+  // the last tile column: the C tile is fetched under its MFMAs once a prefetch set is dead
+  BAE_CHUNK(0, true, BAE_GLOAD(1, kcur + 3 * KC2), true);
+  BAE_CHUNK(1, true, , true);
+#define BAE_CLOAD                                                                              \
+  _Pragma("unroll") for (int ti = 0; ti < 2; ++ti)                                             \
+    _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)                                           \
+      _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                                      \
+        cv[ti][tj][reg] = Aic[(size_t)(rb + 16 * ti + lk + 4 * reg) * ld + cb + 16 * tj + li];
+  BAE_CHUNK(2, true, BAE_CLOAD, true);
+#undef BAE_CLOAD
+  BAE_CHUNK(3, false, , false);
+#undef BAE_SB
+#undef BAE_GLOAD
+#undef BAE_SSTORE
+#undef BAE_LDF
+#undef BAE_MM
+#undef BAE_CHUNK
+  const bool diag = (i == c);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rb + 16 * ti + lk + 4 * reg;
+        const int cc = cb + 16 * tj + li;
+        if (!diag || cc <= r) Aic[(size_t)r * ld + cc] = cv[ti][tj][reg] - acc[ti][tj][reg];
+      }
+}
+
 // BULK = true (the look-ahead's background updates on small systems) pads the LDS footprint
 // to 56 KB: at most two such workgroups fit on a CU, which always leaves the 45 KB + one wave
 // per SIMD that a k_step_update / k_trsm_op workgroup of the concurrent serial chain needs.
@@ -92,6 +212,24 @@ __device__ __forceinline__ void update_tile(double* __restrict__ A, uint32_t ld,
   const double xm0 = sr < rows ? 1.0 : 0.0, xm1 = sr + 32 < rows ? 1.0 : 0.0;
   // tile-sparse factor: column kb contributes only where both operand tiles are structurally
   // nonzero (nz = tile pattern of L, nblk x nblk bytes; the rhs row is dense)
+#ifndef BAE_NO_FAST
+  if (rows == NB && kb1 - kb0 <= 64u) {
+    // wave-uniform pattern mask of the K range: lane l looks at tile column kb0 + l
+    const uint32_t kl = kb0 + (uint32_t)lane;
+    bool on = kl < kb1;
+    bool neg = false;
+    if (on) {
+      neg = colneg[kl] != 0;
+      if (nz) on = nz[(size_t)i * nblk + kl] && nz[(size_t)c * nblk + kl];
+    }
+    const uint64_t mask = __ballot(on);
+    if (__ballot(neg) == 0) {
+      if (mask == 0) return;
+      update_tile_fast(A, ld, i, c, kb0, mask, X, Y);
+      return;
+    }
+  }
+#endif
   uint32_t nact = 0;
   for (uint32_t kb = kb0; kb < kb1; ++kb) {
     const bool on = !nz || ((i == nblk || nz[(size_t)i * nblk + kb]) && nz[(size_t)c * nblk + kb]);
