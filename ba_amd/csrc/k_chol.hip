@@ -359,6 +359,12 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
     c = c0 + C;
     i = c0 + R;
     if (i > nblk || c >= nblk) return;
+  } else if (swz & 2) {
+    // row mode: the bottom rows of the trailing matrix (blockIdx.y = 0: the rhs row, 1: the last
+    // tile row) that a k_update128 launch leaves over
+    c = c0 + blockIdx.x;
+    i = nblk - blockIdx.y;
+    if (c > i || c >= nblk) return;
   } else {
     c = c0 + blockIdx.y;
     i = c + blockIdx.x;
@@ -367,6 +373,172 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
   // distributed solve: a rank only updates the column panels it owns (panel p -> rank p mod N)
   if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
   update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, X, Y, klist);
+}
+
+// ---------------------------------------------------------------------------------
+// 128x128 trailing update for the big look-ahead launches: one workgroup forms the 2x2 block of
+// 64-tiles (i, i+1) x (c, c+1), four waves x 64x64 (4x4 MFMA tiles each).  Per MFMA it moves half
+// the LDS fragments, half the LDS stores and half the L2 -> register operand bytes of the 64x64
+// kernel.  That is what counts on this chip: with real data the 64x64 kernel runs into the
+// package power limit (1.36 kW, sclk 2.40 -> 2.23 GHz measured; all-zero operands run 13 % faster),
+// so the energy spent on moving operands is paid for in MFMA clock.
+//   * same summation order per element as the 64x64 kernel (results are bitwise identical): tile
+//     columns of [kb0, kb1) where either row tile and either column tile is structurally nonzero
+//     are formed for the whole block — a structurally zero operand tile holds exact zeros;
+//   * one-deep register prefetch (the 128 accumulator registers leave room for one set), chunks of
+//     16, two LDS stages of 2 x 128 x 16, fragments of k-step s + 1 read under the 16 MFMAs of
+//     k-step s, one barrier per chunk (as update_tile_fast);
+//   * the C block is read and written in the epilogue, one row of MFMA tiles at a time;
+//   * a negative pivot in the K range (indefinite system) sends the block through update_tile,
+//     one 64-tile at a time.
+// Launched over the even part of the trailing matrix; the odd last tile row and the rhs row are
+// left to a row-mode launch of k_update2.
+static const int NB2 = 128;
+__global__ void __launch_bounds__(256, 2)
+k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t m2, uint32_t kb0,
+            uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, uint32_t sbl,
+            const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
+  __shared__ double X[2][NB2][LDK2];
+  __shared__ double Y[2][NB2][LDK2];
+  __shared__ uint32_t klist[32];
+  // XCD-aware mapping as in k_update2, over the m2 x m2 grid of 128-blocks
+  const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+  const uint32_t t = (slot >> (2 * sbl)) * 8u + xcd, within = slot & ((1u << (2 * sbl)) - 1u);
+  uint32_t sr_ = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((uint64_t)(sr_ + 1) * (sr_ + 2) / 2 <= t) ++sr_;
+  while ((uint64_t)sr_ * (sr_ + 1) / 2 > t) --sr_;
+  const uint32_t sc_ = t - (uint32_t)((uint64_t)sr_ * (sr_ + 1) / 2);
+  const uint32_t R = (sr_ << sbl) + (within >> sbl), C = (sc_ << sbl) + (within & ((1u << sbl) - 1u));
+  if (C > R || R >= m2) return;
+  const uint32_t c = c0 + 2 * C, i = c0 + 2 * R;
+  if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // pattern mask of the K range (lane l: tile column kb0 + l) and pivot-sign check
+  const uint32_t kl = kb0 + (uint32_t)lane;
+  bool on = kl < kb1, neg = false;
+  if (on) {
+    neg = colneg[kl] != 0;
+    if (nz)
+      on = (nz[(size_t)i * nblk + kl] | nz[(size_t)(i + 1) * nblk + kl]) &&
+           (nz[(size_t)c * nblk + kl] | nz[(size_t)(c + 1) * nblk + kl]);
+  }
+  uint64_t mask = __ballot(on);
+  if (mask == 0) return;
+  if (__ballot(neg) != 0 || kb1 - kb0 > 64u) {
+    double(*X64)[NB][LDK2] = reinterpret_cast<double(*)[NB][LDK2]>(&X[0][0][0]);
+    double(*Y64)[NB][LDK2] = reinterpret_cast<double(*)[NB][LDK2]>(&Y[0][0][0]);
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint32_t ii = i + (q >> 1), cc = c + (q & 1);
+      if (cc > ii) continue;
+      __syncthreads();
+      update_tile(A, ld, nblk, ii, cc, kb0, kb1, dsgn, colneg, nz, X64, Y64, klist);
+    }
+    return;
+  }
+  const bool diag = (i == c);
+  const int li = lane & 15, lk = lane >> 4;
+  const int rb = 64 * (wave >> 1), cb = 64 * (wave & 1);
+  double4_t acc[4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int sr = tid >> 3, sc = (tid & 7) * 2;
+  const double* Xg = A + ((size_t)i * NB + sr) * ld + sc;
+  const double* Yg = A + ((size_t)c * NB + sr) * ld + sc;
+  const size_t ld32 = (size_t)32 * ld;
+  double2 px[4], py[4];
+  double FA0[4], FB0[4], FA1[4], FB1[4];
+#define BAE_SB __builtin_amdgcn_sched_barrier(0)
+#define BAE_GLOAD(K0)                                                                \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                    \
+    px[u] = *reinterpret_cast<const double2*>(Xg + u * ld32 + (K0));                 \
+    py[u] = *reinterpret_cast<const double2*>(Yg + u * ld32 + (K0));                 \
+  }
+#define BAE_SSTORE(B)                                                                \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                    \
+    X[B][sr + 32 * u][sc] = px[u].x; X[B][sr + 32 * u][sc + 1] = px[u].y;            \
+    Y[B][sr + 32 * u][sc] = py[u].x; Y[B][sr + 32 * u][sc + 1] = py[u].y;            \
+  }
+#define BAE_LDF(FA, FB, B, KS)                                                       \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                    \
+    FA[q] = X[B][rb + 16 * q + li][4 * (KS) + lk];                                   \
+    FB[q] = Y[B][cb + 16 * q + li][4 * (KS) + lk];                                   \
+  }
+#define BAE_MM(FA, FB)                                                               \
+  _Pragma("unroll") for (int ti = 0; ti < 4; ++ti)                                   \
+    _Pragma("unroll") for (int tj = 0; tj < 4; ++tj)                                 \
+      acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[ti], FB[tj], acc[ti][tj], 0, 0, 0);
+#define BAE_CHUNK(J, STORE, LOADK, NEXT)                                             \
+  {                                                                                  \
+    if (STORE) BAE_SSTORE(((J) + 1) & 1);                                            \
+    LOADK;                                                                           \
+    BAE_SB; BAE_LDF(FA1, FB1, (J) & 1, 1); BAE_SB; BAE_MM(FA0, FB0); BAE_SB;         \
+    BAE_LDF(FA0, FB0, (J) & 1, 2); BAE_SB; BAE_MM(FA1, FB1); BAE_SB;                 \
+    BAE_LDF(FA1, FB1, (J) & 1, 3); BAE_SB; BAE_MM(FA0, FB0); BAE_SB;                 \
+    __syncthreads(); BAE_SB;                                                         \
+    if (NEXT) BAE_LDF(FA0, FB0, ((J) + 1) & 1, 0);                                   \
+    BAE_SB; BAE_MM(FA1, FB1); BAE_SB;                                                \
+  }
+  uint32_t kcur = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
+  mask &= mask - 1;
+  BAE_GLOAD(kcur);
+  BAE_SSTORE(0);
+  BAE_GLOAD(kcur + KC2);
+  __syncthreads();
+  BAE_LDF(FA0, FB0, 0, 0);
+  while (mask) {
+    const uint32_t knext = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
+    mask &= mask - 1;
+    // stage 0 holds chunk 0 of this tile column, the register set (in flight) chunk 1
+    BAE_CHUNK(0, true, BAE_GLOAD(kcur + 2 * KC2), true);
+    BAE_CHUNK(1, true, BAE_GLOAD(kcur + 3 * KC2), true);
+    BAE_CHUNK(2, true, BAE_GLOAD(knext), true);
+    BAE_CHUNK(3, true, BAE_GLOAD(knext + KC2), true);
+    kcur = knext;
+  }
+  // the last tile column; the C block is read and written one row of four MFMA tiles (16 doubles
+  // per lane) at a time, two rows in flight: row 0 is fetched under the last chunk (the prefetch
+  // set is dead by then), row t + 2 when row t has been stored
+  double* Aic = A + ((size_t)i * NB) * ld + (size_t)c * NB;
+  double4_t cva[4], cvb[4];
+#define BAE_CLOAD(CV, TI)                                                            \
+  _Pragma("unroll") for (int tj = 0; tj < 4; ++tj)                                   \
+    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg)                              \
+      CV[tj][reg] = Aic[(size_t)(rb + 16 * (TI) + lk + 4 * reg) * ld + cb + 16 * tj + li];
+#define BAE_CSTORE(CV, TI)                                                           \
+  _Pragma("unroll") for (int tj = 0; tj < 4; ++tj)                                   \
+    _Pragma("unroll") for (int reg = 0; reg < 4; ++reg) {                            \
+      const int r = rb + 16 * (TI) + lk + 4 * reg;                                   \
+      const int cc = cb + 16 * tj + li;                                              \
+      if (!diag || cc <= r) Aic[(size_t)r * ld + cc] = CV[tj][reg] - acc[TI][tj][reg]; \
+    }
+  BAE_CHUNK(0, true, BAE_GLOAD(kcur + 2 * KC2), true);
+  BAE_CHUNK(1, true, BAE_GLOAD(kcur + 3 * KC2), true);
+  BAE_CHUNK(2, true, , true);
+  BAE_CHUNK(3, false, BAE_CLOAD(cva, 0), false);
+  if (diag && wave == 1) return;  // the strictly upper 64-tile of a diagonal block (computed, not stored)
+  BAE_SB;
+  BAE_CLOAD(cvb, 1);
+  BAE_SB;
+  BAE_CSTORE(cva, 0);
+  BAE_SB;
+  BAE_CLOAD(cva, 2);
+  BAE_SB;
+  BAE_CSTORE(cvb, 1);
+  BAE_SB;
+  BAE_CLOAD(cvb, 3);
+  BAE_SB;
+  BAE_CSTORE(cva, 2);
+  BAE_CSTORE(cvb, 3);
+#undef BAE_CLOAD
+#undef BAE_CSTORE
+#undef BAE_SB
+#undef BAE_GLOAD
+#undef BAE_SSTORE
+#undef BAE_LDF
+#undef BAE_MM
+#undef BAE_CHUNK
 }
 
 // ---------------------------------------------------------------------------------
@@ -825,7 +997,7 @@ int factor_tile_pattern(Engine* e) {
 
 uint32_t choose_kout(uint32_t nblk) {
   static const uint32_t kout_env = getenv("BA_HIP_KOUT") ? (uint32_t)atoi(getenv("BA_HIP_KOUT")) : 0;
-  return kout_env ? kout_env : (nblk >= 256 ? 8u : 4u);
+  return kout_env ? kout_env : (nblk >= 512 ? 16u : nblk >= 256 ? 8u : 4u);
 }
 
 // ---------------------------------------------------------------------------------
@@ -874,6 +1046,63 @@ k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restric
     if (unpack) row[cc] = brow[cc];
     else brow[cc] = row[cc];
   }
+}
+
+// The serial chain of one outer panel [J, Jend) on stream s (its owner in the distributed solve).
+// Two-level inside the panel: sub-panels of KIN tile columns are factorised right-looking, one
+// K = 64 update of the rest of the sub-panel per tile column; at the end of a sub-panel the
+// remaining columns of the outer panel get ONE update with all KIN columns (K = 256) — a third of
+// the tile updates of a flat right-looking panel at KOUT = 16, and mostly four times as deep.
+// Every update launch also factorises the next diagonal tile (k_step_update).
+static const uint32_t KIN = 4;
+static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t Jend,
+                               double* dsgn, double* opbuf, int* colneg, int* flags, const uint8_t* nz) {
+  for (uint32_t sub = J; sub < Jend; sub += KIN) {
+    const uint32_t sub_end = std::min(sub + KIN, Jend);
+    for (uint32_t jj = sub; jj < sub_end; ++jj) {
+      hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s, dA, ld, jj, nblk, (const double*)opbuf, nz);
+      if (jj + 1 < sub_end)
+        hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
+                           nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz);
+    }
+    if (sub_end < Jend)
+      hipLaunchKernelGGL(k_step_update, dim3(nblk - sub_end + 1, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk,
+                         sub_end, sub, sub_end, dsgn, opbuf, colneg, flags, nz);
+  }
+}
+
+// Bulk trailing update of the tile rows / columns >= a_end (and the rhs row) with the tile columns
+// [J, Jend).  Big trailing matrices: 128x128 blocks over the even part (k_update128, XCD-aware 4x4
+// super-blocks = the footprint of the 64-tile kernel's 8x8) + a row-mode launch for the rhs row
+// and an odd last tile row; otherwise the 64-tile kernel, capped (`full` = false) to leave the
+// serial chain room.
+static void launch_bulk_update(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t a_end, uint32_t J,
+                               uint32_t Jend, const double* dsgn, const int* colneg, const uint8_t* nz, bool full,
+                               uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
+  static const bool no128 = getenv("BA_HIP_NO128") != nullptr;  // A/B switch
+  static const uint32_t sbl = getenv("BA_HIP_SBL") ? (uint32_t)atoi(getenv("BA_HIP_SBL")) : 3u;
+  const uint32_t m = nblk - a_end;
+  if (full && !no128 && m >= 16 && (a_end % 2u) == 0 && (own_n <= 1 || own_kout % 2u == 0)) {
+    static const uint32_t sbl2 = getenv("BA_HIP_SBL2") ? (uint32_t)atoi(getenv("BA_HIP_SBL2")) : 2u;
+    const uint32_t m2 = m / 2, sbe2 = 1u << sbl2;
+    const uint32_t nsr = (m2 + sbe2 - 1) / sbe2, nsb = nsr * (nsr + 1) / 2;
+    hipLaunchKernelGGL(k_update128, dim3(((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk, a_end, m2,
+                       J, Jend, dsgn, colneg, sbl2, nz, own_rank, own_n, own_kout);
+    hipLaunchKernelGGL(k_update2<false>, dim3(m, 1 + (m & 1u)), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn,
+                       colneg, 2, nz, own_rank, own_n, own_kout);
+    return;
+  }
+  // 1-D XCD-aware launch over the 8x8 super-blocks of the (m + 1) x m lower-triangular tile region
+  const uint32_t sbe = 1u << sbl;
+  const uint32_t nsr = (m + 1 + sbe - 1) / sbe, nsb = nsr * (nsr + 1) / 2;
+  const uint32_t grid1 = ((nsb + 7) / 8) * 8 * sbe * sbe;
+  const int swzf = 1 | (int)(sbl << 8);
+  if (full)
+    hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn, colneg,
+                       swzf, nz, own_rank, own_n, own_kout);
+  else
+    hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn, colneg,
+                       swzf, nz, own_rank, own_n, own_kout);
 }
 
 struct DistLayout {
@@ -982,12 +1211,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     double* m_op = m_neg + KOUT;
     const size_t msg_len = n_cols + w + KOUT + (size_t)(Jend - J) * NOPV * 64;
     if (rank == owner) {
-      for (uint32_t jj = J; jj < Jend; ++jj) {
-        hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk, (const double*)opbuf, nz);
-        if (jj + 1 < Jend)
-          hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, Jend - (jj + 1)), dim3(256), 0, s0, dA, ld,
-                             nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, e->flags.p, nz);
-      }
+      launch_panel_chain(s0, dA, ld, nblk, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
       hipLaunchKernelGGL(k_copy_panel_rows, dim3(nrows), dim3(256), 0, s0, dA, ld, tl, ntl, nblk * NB, J * NB, w,
                          msg, 0);
       BAE_HIP(hipMemcpyAsync(m_sgn, dsgn + (size_t)J * NB, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
@@ -1017,12 +1241,8 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     }
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
-      const uint32_t m = nblk - a_end;
-      const uint32_t nsr = (m + 1 + 7) / 8, nsb = nsr * (nsr + 1) / 2;
-      const uint32_t grid1 = ((nsb + 7) / 8) * 8 * 64;
       e->prof_begin(e->ev_syrk, s1);
-      hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                         (const double*)dsgn, (const int*)colneg, 1 | (3 << 8), nz, rank, N, KOUT);
+      launch_bulk_update(s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz, true, rank, N, KOUT);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
@@ -1110,12 +1330,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   uint32_t pj = 0;
   for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
     const uint32_t Jend = J + KOUT < nblk ? J + KOUT : nblk;
-    for (uint32_t jj = J; jj < Jend; ++jj) {
-      hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s0, dA, ld, jj, nblk,
-                           (const double*)opbuf, nz);
-      // in-panel update of the panel's remaining tile columns with tile column jj
-      if (jj + 1 < Jend) step_update(jj + 1, Jend - (jj + 1), jj, jj + 1);
-    }
+    launch_panel_chain(s0, dA, ld, nblk, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
     if (Jend >= nblk) break;
     BAE_HIP(hipEventRecord(e->ev_panel[pj], s0));
     const uint32_t a_end = Jend + KOUT < nblk ? Jend + KOUT : nblk;  // columns of the next panel
@@ -1126,23 +1341,11 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
       e->prof_begin(e->ev_syrk, s1);
-      // 1-D XCD-aware launch over the 8x8 super-blocks of the (m + 1) x m lower-triangular
-      // tile region.  Large trailing matrices (the serial chain is negligible beside them):
-      // full occupancy; otherwise the capped variant leaves the chain room.
+      // large trailing matrices (the serial chain is negligible beside them): full occupancy;
+      // otherwise the capped variant leaves the chain room
       const uint32_t m = nblk - a_end;
-      static const uint32_t sbl = getenv("BA_HIP_SBL") ? (uint32_t)atoi(getenv("BA_HIP_SBL")) : 3u;
-      const uint32_t sbe = 1u << sbl;
-      const uint32_t nsr = (m + 1 + sbe - 1) / sbe;
-      const uint32_t nsb = nsr * (nsr + 1) / 2;
-      const uint32_t grid1 = ((nsb + 7) / 8) * 8 * sbe * sbe;
-      const int swzf = 1 | (int)(sbl << 8);
-      const bool bulk_heavy = m >= bulk_full_m;
-      if (no_lookahead || bulk_full || bulk_heavy)
-        hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, swzf, nz, 0u, 1u, 1u);
-      else
-        hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s1, dA, ld, nblk, a_end, J, Jend,
-                           (const double*)dsgn, (const int*)colneg, swzf, nz, 0u, 1u, 1u);
+      launch_bulk_update(s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz,
+                         no_lookahead || bulk_full || m >= bulk_full_m, 0u, 1u, 1u);
       e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
@@ -1159,6 +1362,22 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
           tiles += mk * (mk + 1) / 2 + mk;
         }
         e->kstats.syrk_flops += tiles * 2.0 * NB * NB * NB;
+        static const bool dbg_formed = getenv("BA_HIP_DEBUG_FORMED") != nullptr;
+        if (dbg_formed && nz && e->nzL_host.size() == (size_t)nblk * nblk) {
+          // products a 128-block launch forms (either row tile x either column tile nonzero)
+          double formed = 0.0;
+          const uint32_t m = nblk - a_end, m2 = m / 2;
+          for (uint32_t kb = J; kb < Jend; ++kb) {
+            double mk2 = 0.0;
+            for (uint32_t R = 0; R < m2; ++R)
+              mk2 += (e->nzL_host[(size_t)(a_end + 2 * R) * nblk + kb] | e->nzL_host[(size_t)(a_end + 2 * R + 1) * nblk + kb]) ? 1.0 : 0.0;
+            formed += 4.0 * (mk2 * (mk2 + 1) / 2);
+          }
+          static double tot_formed = 0.0, tot_alg = 0.0;
+          tot_formed += formed;
+          tot_alg += tiles;
+          fprintf(stderr, "[formed] a_end %u alg %.0f formed128 %.0f  cumulative ratio %.4f\n", a_end, tiles, formed, tot_formed / tot_alg);
+        }
       }
     }
   }

@@ -873,3 +873,22 @@ def test_config1_scale_step_matches_oracle(oracle_lib):
     assert rel_err(h.delta_l(), o.delta_l()) < 1e-6
     print("config-1 scale: delta_p rel err %.2e, delta_l rel err %.2e" %
           (rel_err(h.delta_p(), o.delta_p()), rel_err(h.delta_l(), o.delta_l())))
+
+
+@pytest.mark.gpu
+def test_blocked_128_trailing_update_on_small_systems():
+    """k_update128 (the 128x128 trailing-update kernel, its row-mode companion launch, its
+    indefinite fallback and the ownership filter of the distributed solve) normally only runs on
+    trailing matrices of >= 128 tiles.  BA_HIP_BULK_FULL_M is read once per process, so the solver
+    tests are re-run in a child process with the threshold lowered to 16 tiles."""
+    import subprocess
+    import sys
+    if os.environ.get("BA_TEST_NESTED"):
+        pytest.skip("nested run")
+    env = dict(os.environ, BA_HIP_BULK_FULL_M="16", BA_TEST_NESTED="1")
+    r = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+         "dense_cholesky_solve or tile_sparse or distributed_solve_matches_single or reduced_system_and_step"],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
