@@ -359,12 +359,6 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
     c = c0 + C;
     i = c0 + R;
     if (i > nblk || c >= nblk) return;
-  } else if (swz & 2) {
-    // row mode: the bottom rows of the trailing matrix (blockIdx.y = 0: the rhs row, 1: the last
-    // tile row) that a k_update128 launch leaves over
-    c = c0 + blockIdx.x;
-    i = nblk - blockIdx.y;
-    if (c > i || c >= nblk) return;
   } else {
     c = c0 + blockIdx.y;
     i = c + blockIdx.x;
@@ -391,18 +385,30 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 //   * the C block is read and written in the epilogue, one row of MFMA tiles at a time;
 //   * a negative pivot in the K range (indefinite system) sends the block through update_tile,
 //     one 64-tile at a time.
-// Launched over the even part of the trailing matrix; the odd last tile row and the rhs row are
-// left to a row-mode launch of k_update2.
+// The blocks cover the even part of the trailing matrix; the rhs row and an odd last tile row are
+// 64-tiles taken by the first workgroups of the same launch.
 static const int NB2 = 128;
 __global__ void __launch_bounds__(256, 2)
 k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t m2, uint32_t kb0,
             uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, uint32_t sbl,
-            const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
+            const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout,
+            uint32_t nrow64) {
   __shared__ double X[2][NB2][LDK2];
   __shared__ double Y[2][NB2][LDK2];
   __shared__ uint32_t klist[32];
+  // The first nrow64 workgroups take the 64-tiles the 128-blocks leave over: the rhs row (row
+  // nblk) and, when the trailing matrix has an odd number of tile rows, its last tile row.
+  if (blockIdx.x < nrow64) {
+    const uint32_t mcols = nblk - c0, y = blockIdx.x / mcols;
+    const uint32_t c = c0 + blockIdx.x % mcols, i = nblk - y;
+    if (y > (mcols & 1u) || c > i || c >= nblk) return;  // (nrow64 is rounded up to a multiple of 8)
+    if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
+    update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, reinterpret_cast<double(*)[NB][LDK2]>(&X[0][0][0]),
+                reinterpret_cast<double(*)[NB][LDK2]>(&Y[0][0][0]), klist);
+    return;
+  }
   // XCD-aware mapping as in k_update2, over the m2 x m2 grid of 128-blocks
-  const uint32_t b = blockIdx.x, xcd = b & 7u, slot = b >> 3;
+  const uint32_t b = blockIdx.x - nrow64, xcd = b & 7u, slot = b >> 3;
   const uint32_t t = (slot >> (2 * sbl)) * 8u + xcd, within = slot & ((1u << (2 * sbl)) - 1u);
   uint32_t sr_ = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((uint64_t)(sr_ + 1) * (sr_ + 2) / 2 <= t) ++sr_;
@@ -1073,12 +1079,14 @@ static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t 
 
 // Bulk trailing update of the tile rows / columns >= a_end (and the rhs row) with the tile columns
 // [J, Jend).  Big trailing matrices: 128x128 blocks over the even part (k_update128, XCD-aware 4x4
-// super-blocks = the footprint of the 64-tile kernel's 8x8) + a row-mode launch for the rhs row
-// and an odd last tile row; otherwise the 64-tile kernel, capped (`full` = false) to leave the
+// super-blocks = the footprint of the 64-tile kernel's 8x8; the rhs row and an odd last tile row
+// ride along as 64-tiles); otherwise the 64-tile kernel, capped (`full` = false) to leave the
 // serial chain room.
-static void launch_bulk_update(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t a_end, uint32_t J,
-                               uint32_t Jend, const double* dsgn, const int* colneg, const uint8_t* nz, bool full,
-                               uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
+// One launch, bracketed by the profiling events.
+static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t a_end,
+                                   uint32_t J, uint32_t Jend, const double* dsgn, const int* colneg,
+                                   const uint8_t* nz, bool full, uint32_t own_rank, uint32_t own_n,
+                                   uint32_t own_kout) {
   static const bool no128 = getenv("BA_HIP_NO128") != nullptr;  // A/B switch
   static const uint32_t sbl = getenv("BA_HIP_SBL") ? (uint32_t)atoi(getenv("BA_HIP_SBL")) : 3u;
   const uint32_t m = nblk - a_end;
@@ -1086,10 +1094,12 @@ static void launch_bulk_update(hipStream_t s, double* dA, uint32_t ld, uint32_t 
     static const uint32_t sbl2 = getenv("BA_HIP_SBL2") ? (uint32_t)atoi(getenv("BA_HIP_SBL2")) : 2u;
     const uint32_t m2 = m / 2, sbe2 = 1u << sbl2;
     const uint32_t nsr = (m2 + sbe2 - 1) / sbe2, nsb = nsr * (nsr + 1) / 2;
-    hipLaunchKernelGGL(k_update128, dim3(((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk, a_end, m2,
-                       J, Jend, dsgn, colneg, sbl2, nz, own_rank, own_n, own_kout);
-    hipLaunchKernelGGL(k_update2<false>, dim3(m, 1 + (m & 1u)), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn,
-                       colneg, 2, nz, own_rank, own_n, own_kout);
+    // leftover 64-tiles first (a multiple of 8 workgroups keeps the XCD phase of the blocks)
+    const uint32_t nrow64 = (m * (1 + (m & 1u)) + 7) / 8 * 8;
+    if (e) e->prof_begin(e->ev_syrk, s);
+    hipLaunchKernelGGL(k_update128, dim3(nrow64 + ((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk,
+                       a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own_rank, own_n, own_kout, nrow64);
+    if (e) e->prof_end(e->ev_syrk, s);
     return;
   }
   // 1-D XCD-aware launch over the 8x8 super-blocks of the (m + 1) x m lower-triangular tile region
@@ -1097,12 +1107,14 @@ static void launch_bulk_update(hipStream_t s, double* dA, uint32_t ld, uint32_t 
   const uint32_t nsr = (m + 1 + sbe - 1) / sbe, nsb = nsr * (nsr + 1) / 2;
   const uint32_t grid1 = ((nsb + 7) / 8) * 8 * sbe * sbe;
   const int swzf = 1 | (int)(sbl << 8);
+  if (e) e->prof_begin(e->ev_syrk, s);
   if (full)
     hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn, colneg,
                        swzf, nz, own_rank, own_n, own_kout);
   else
     hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn, colneg,
                        swzf, nz, own_rank, own_n, own_kout);
+  if (e) e->prof_end(e->ev_syrk, s);
 }
 
 struct DistLayout {
@@ -1241,9 +1253,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     }
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
-      e->prof_begin(e->ev_syrk, s1);
-      launch_bulk_update(s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz, true, rank, N, KOUT);
-      e->prof_end(e->ev_syrk, s1);
+      launch_bulk_update(e, s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz, true, rank, N, KOUT);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
       if (e->profiling) {
@@ -1340,13 +1350,11 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     // (b) the rest, concurrently with the next panel's factorisation
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
-      e->prof_begin(e->ev_syrk, s1);
       // large trailing matrices (the serial chain is negligible beside them): full occupancy;
       // otherwise the capped variant leaves the chain room
       const uint32_t m = nblk - a_end;
-      launch_bulk_update(s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz,
+      launch_bulk_update(e, s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz,
                          no_lookahead || bulk_full || m >= bulk_full_m, 0u, 1u, 1u);
-      e->prof_end(e->ev_syrk, s1);
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
       if (e->profiling) {

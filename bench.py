@@ -203,10 +203,12 @@ def main():
         # per launch), null if the summary is absent
         traffic = None
         pmc = {}
+        # 128x128 blocks on trailing matrices of >= 128 tiles, the capped 64-tile kernel below
+        bulk_kernel = "k_update128" if n >= 128 * 64 else "k_update2<true>"
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg%d.json" % args.config)) as f:
                 pmc = json.load(f)["kernels"]
-            bulk = "bae::k_update2<false>" if "bae::k_update2<false>" in pmc and P > 1000 else "bae::k_update2<true>"
+            bulk = "bae::k_update128" if n >= 128 * 64 else "bae::k_update2<true>"
             traffic = pmc[bulk]["traffic_bytes_per_launch_corrected"]
         except (OSError, KeyError, ValueError):
             pass
@@ -235,7 +237,7 @@ def main():
                        "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
                        "parallelism": ("landmark-sharded x%d, reduce-scatter of S to panel owners, distributed LDL^T "
                                        "(panel broadcast)" % world) if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_update2 (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)",
+            "roofline": {"bound": "mfma", "kernel": "%s (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)" % bulk_kernel,
                          "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_traffic_cfg%d.json (rocprofv3 --pmc, bytes per launch)" % args.config,

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < REPS; ++rep) {
     if (rep == 1) hipEventRecord(e0, 0);
     if (full == 2)
-      launch_bulk_update(0, A, ld, nblk, a_end, 0u, KOUT, dsgn, colneg, nullptr, true, 0u, 1u, 1u);
+      launch_bulk_update(nullptr, 0, A, ld, nblk, a_end, 0u, KOUT, dsgn, colneg, nullptr, true, 0u, 1u, 1u);
     else if (full)
       hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, 0, A, ld, nblk, a_end, 0u, KOUT, (const double*)dsgn, (const int*)colneg, swzf, (const uint8_t*)nullptr, 0u, 1u, 1u);
     else
