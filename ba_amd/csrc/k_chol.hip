@@ -1,19 +1,20 @@
 // FP64 solve of the reduced camera system S delta = rhs on gfx950.
 //
 // Replaces CalculateGn (BundleAdjuster.cpp:748-833): the reference converts the dense s_ to
-// a sparse view and runs Eigen::SimplicialLDLT<Upper> (or dense LDLT<Upper>).  Here: two-level
-// blocked right-looking L D L^T, D = diag(+-1), on the LOWER storage (row-major, leading
-// dimension ld, a multiple of 64), tile-sparse at 64x64 granularity, with look-ahead:
+// a sparse view and runs Eigen::SimplicialLDLT<Upper> (or dense LDLT<Upper>).  Here: blocked
+// right-looking L D L^T, D = diag(+-1), on the LOWER storage (row-major, leading dimension ld, a
+// multiple of 64), tile-sparse at 64x64 granularity, three blocking levels, with look-ahead:
 //
-//   for every outer panel J of KOUT tile columns (256 columns, 512 for n >= 16k)
-//     for every 64-column tile jj of the panel                                   [stream s0]
+//   for every outer panel J of KOUT tile columns (4; 8 for n >= 16k; 16 for n >= 32k)
+//     for every sub-panel of 4 tile columns, for every 64-column tile jj of it      [stream s0]
 //       k_trsm_op      rows below the diagonal tile: X = A L_jj^-T D (blocked substitution on
 //                      the matrix cores from the "factor packet" of tile jj)
-//       k_step_update  update of the panel's remaining tile columns with column jj (K = 64);
+//       k_step_update  update of the sub-panel's remaining tile columns with column jj (K = 64);
 //                      its workgroup (0,0) also factorises the next diagonal tile in LDS and
 //                      publishes that tile's factor packet
+//     k_step_update    after a sub-panel: the rest of the outer panel with its 4 columns (K = 256)
 //     k_step_update    (a) the next panel's columns, K = 64 KOUT, + its first diagonal tile
-//     k_update2        (b) everything right of the next panel, K = 64 KOUT        [stream s1]
+//     k_update128 / k_update2   (b) everything right of the next panel, K = 64 KOUT  [stream s1]
 //                      concurrently with the next panel's serial chain
 //   k_linvT, k_backward   L^T x = y, one tile row per launch
 //
