@@ -2,6 +2,10 @@
 // per-Solve structure build (observation CSR, incidences, gather lists) and the phase
 // drivers that enqueue the kernels of k_proj.hip / k_reduce.hip / k_chol.hip.
 #include "engine.h"
+#include <chrono>
+#include <functional>
+#include <memory>
+#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -67,10 +71,26 @@ struct EventTimer {
 
 struct PairRec { uint64_t key; uint32_t a, b; };
 
+// threads for the host-side structure build (BA_HIP_HOST_THREADS overrides; at most 16)
+static unsigned host_threads() {
+  if (const char* v = getenv("BA_HIP_HOST_THREADS")) return (unsigned)std::max(1, atoi(v));
+  const unsigned hc = std::thread::hardware_concurrency();
+  return std::min(16u, std::max(1u, hc));
+}
+
 // Build everything that depends only on the problem graph (not on the state).
 static int build_structure(Engine* e) {
   Problem& pb = e->prob;
   Structure& st = e->st;
+  // BA_HIP_DEBUG_SETUP: wall-clock of the stages of the structure build on stderr
+  static const bool dbg_setup = getenv("BA_HIP_DEBUG_SETUP") != nullptr;
+  auto t_stage = std::chrono::steady_clock::now();
+  auto stage = [&](const char* name) {
+    if (!dbg_setup) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[setup] %-28s %.3f s\n", name, std::chrono::duration<double>(now - t_stage).count());
+    t_stage = now;
+  };
   const int LM = e->lm_dim, D = e->pose_dim;
   st.P = pb.num_poses; st.L = pb.num_lms; st.O = pb.num_proj; st.C = pb.num_cams;
   if (st.O > 0 && st.C == 0) return e->fail_msg("projection residuals without a camera");
@@ -115,6 +135,7 @@ static int build_structure(Engine* e) {
     obs_lm[s] = pb.proj_lm[a]; obs_rid[s] = a;
   }
 
+  stage("obs sort by landmark");
   // ---- Jacobian slots (obs, side) and incidences ---------------------------------
   // A residual carries pose Jacobian blocks iff it is "listed" (it passed the
   // diff_poses test of AddProjectionResidual, BundleAdjuster.h:489-497) and the pose
@@ -209,84 +230,141 @@ static int build_structure(Engine* e) {
   std::vector<uint32_t> linc_row(st.n_inc);
   for (uint32_t q = 0; q < st.n_inc; ++q) linc_row[q] = inc_pm[q] * 2 * LM;
 
+  stage("jacobian slots / incidences");
   // ---- gather lists for S ------------------------------------------------------------
-  std::vector<PairRec> recs;
-  {
-    size_t est = (size_t)st.Pact;
-    for (uint32_t l = 0; l < st.L; ++l) {
-      const size_t m = linc_ptr[l + 1] - linc_ptr[l];
-      est += m * (m + 1) / 2 * LM;
-    }
-    est += (size_t)st.O * 6;
-    recs.reserve(est);
-  }
+  // 75 M records at configs[3]: generated, radix-sorted (stable, so the order of the terms of a
+  // block — and with it every bit of S — does not depend on the thread count) and cut into pairs
+  // by a pool of host threads.
+  const unsigned T = host_threads();
+  auto parallel_for = [&](size_t count, const std::function<void(unsigned, size_t, size_t)>& fn) {
+    if (T <= 1 || count < (1u << 16)) { fn(0, 0, count); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t, count * t / T, count * (t + 1) / T);
+    for (auto& x : th) x.join();
+  };
   auto key = [](uint32_t i, uint32_t j) { return ((uint64_t)i << 32) | j; };
   // The diagonal blocks (i,i) are NOT in the lists: their terms — J^T J over the pose's own
   // J rows, (-W V^-1) W^T over its own incidences — are contiguous row ranges in the
   // pose-major numbering and are streamed by k_gather_S_diag.
   (void)zero_row;
+  // record offsets: landmark l emits m(m-1)/2 * LM records, observation s 0 / 2 / 4
+  std::vector<size_t> lm_off((size_t)st.L + 1, 0), obs_off((size_t)st.O + 1, 0);
   for (uint32_t l = 0; l < st.L; ++l) {
-    for (uint32_t qa = linc_ptr[l]; qa < linc_ptr[l + 1]; ++qa)
-      for (uint32_t qb = qa + 1; qb < linc_ptr[l + 1]; ++qb) {  // poses ascending within a landmark
-        const uint32_t ia = linc_pose_lm[qa], ib = linc_pose_lm[qb];
-        for (int k = 0; k < LM; ++k)
-          recs.push_back({key(ia, ib), linc_row[qa] + LM + k, linc_row[qb] + k});  // (-W V^-1)_a W_b^T
-      }
+    const size_t m = linc_ptr[l + 1] - linc_ptr[l];
+    lm_off[l + 1] = lm_off[l] + m * (m - 1) / 2 * LM;
   }
-  for (uint32_t s = 0; s < st.O; ++s) {
-    const int32_t m = meas_opt(s), r = ref_opt(s);
-    const int32_t jm = obs_jrow_m[s], jr = obs_jrow_r[s];
-    if (m >= 0 && r >= 0) {
+  parallel_for(st.O, [&](unsigned, size_t s0, size_t s1) {
+    for (size_t s = s0; s < s1; ++s) {
+      const int32_t m = meas_opt((uint32_t)s), r = ref_opt((uint32_t)s);
+      obs_off[s + 1] = (m >= 0 && r >= 0) ? (m == r ? 4 : 2) : 0;
+    }
+  });
+  for (uint32_t s = 0; s < st.O; ++s) obs_off[s + 1] += obs_off[s];
+  const size_t n_lm_recs = lm_off[st.L], n_recs = n_lm_recs + obs_off[st.O];
+  if (n_recs >= 0xFFFFFFFFull) return e->fail_msg("gather list exceeds 2^32 entries");
+  // uninitialised: the pages are first touched by the threads that fill them
+  std::unique_ptr<PairRec[]> recs(new PairRec[std::max<size_t>(n_recs, 1)]);
+  // landmarks: chunks of equal record count
+  const unsigned lm_parts = (T > 1 && n_lm_recs >= (1u << 16)) ? T : 1;
+  auto lm_part = [&](unsigned cpart) {
+    {
+      const size_t lo = n_lm_recs * cpart / lm_parts, hi = n_lm_recs * (cpart + 1) / lm_parts;
+      uint32_t l = (uint32_t)(std::upper_bound(lm_off.begin(), lm_off.end(), lo) - lm_off.begin());
+      l = l ? l - 1 : 0;
+      while (l < st.L && lm_off[l] < lo) ++l;  // first landmark starting at or after lo
+      for (; l < st.L && lm_off[l] < hi; ++l) {
+        size_t w = lm_off[l];
+        for (uint32_t qa = linc_ptr[l]; qa < linc_ptr[l + 1]; ++qa)
+          for (uint32_t qb = qa + 1; qb < linc_ptr[l + 1]; ++qb) {  // poses ascending within a landmark
+            const uint32_t ia = linc_pose_lm[qa], ib = linc_pose_lm[qb];
+            for (int k = 0; k < LM; ++k)
+              recs[w++] = {key(ia, ib), linc_row[qa] + LM + k, linc_row[qb] + k};  // (-W V^-1)_a W_b^T
+          }
+      }
+    }
+  };
+  if (lm_parts == 1) lm_part(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < lm_parts; ++t) th.emplace_back(lm_part, t);
+    for (auto& x : th) x.join();
+  }
+  parallel_for(st.O, [&](unsigned, size_t s0, size_t s1) {
+    for (size_t s = s0; s < s1; ++s) {
+      if (obs_off[s + 1] == obs_off[s]) continue;
+      const int32_t m = meas_opt((uint32_t)s), r = ref_opt((uint32_t)s);
+      const int32_t jm = obs_jrow_m[s], jr = obs_jrow_r[s];
+      size_t w = n_lm_recs + obs_off[s];
       for (int k = 0; k < 2; ++k) {
-        if (m < r) recs.push_back({key(m, r), (uint32_t)jm + k, (uint32_t)jr + k});
-        else if (r < m) recs.push_back({key(r, m), (uint32_t)jr + k, (uint32_t)jm + k});
+        if (m < r) recs[w++] = {key(m, r), (uint32_t)jm + k, (uint32_t)jr + k};
+        else if (r < m) recs[w++] = {key(r, m), (uint32_t)jr + k, (uint32_t)jm + k};
         else {  // both sides on the same pose: J = J_m + J_r, the two cross terms
-          recs.push_back({key(m, m), (uint32_t)jm + k, (uint32_t)jr + k});
-          recs.push_back({key(m, m), (uint32_t)jr + k, (uint32_t)jm + k});
+          recs[w++] = {key(m, m), (uint32_t)jm + k, (uint32_t)jr + k};
+          recs[w++] = {key(m, m), (uint32_t)jr + k, (uint32_t)jm + k};
         }
       }
     }
-  }
+  });
   {
     int bits = 1;
     while ((1u << bits) < std::max(st.Pact, 2u)) ++bits;
-    // sort by j (low 32 bits) then i (high 32 bits): two groups of 16-bit digit passes
-    std::vector<PairRec> tmp;
-    // low word
-    {
-      std::vector<PairRec> t2(recs.size());
-      std::vector<size_t> cnt(65537);
-      for (int shift = 0; shift < bits; shift += 16) {
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (const PairRec& r : recs) cnt[((r.key >> shift) & 0xFFFF) + 1]++;
-        for (int i = 0; i < 65536; ++i) cnt[i + 1] += cnt[i];
-        for (const PairRec& r : recs) t2[cnt[(r.key >> shift) & 0xFFFF]++] = r;
-        recs.swap(t2);
-      }
-      for (int shift = 32; shift < 32 + bits; shift += 16) {
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (const PairRec& r : recs) cnt[((r.key >> shift) & 0xFFFF) + 1]++;
-        for (int i = 0; i < 65536; ++i) cnt[i + 1] += cnt[i];
-        for (const PairRec& r : recs) t2[cnt[(r.key >> shift) & 0xFFFF]++] = r;
-        recs.swap(t2);
-      }
-    }
+    // sort by j (low 32 bits) then i (high 32 bits): 16-bit digit passes, stable; per-thread
+    // histograms, bucket offsets digit-major then thread-major
+    std::unique_ptr<PairRec[]> t2(new PairRec[std::max<size_t>(n_recs, 1)]);
+    std::vector<std::vector<size_t>> cnt(T > 1 ? T : 1, std::vector<size_t>(65536));
+    auto radix_pass = [&](int shift) {
+      parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
+        std::vector<size_t>& c = cnt[t];
+        std::fill(c.begin(), c.end(), 0);
+        for (size_t i = i0; i < i1; ++i) c[(recs[i].key >> shift) & 0xFFFF]++;
+      });
+      const bool par = !(T <= 1 || n_recs < (1u << 16));
+      const unsigned used = par ? T : 1;
+      size_t run = 0;
+      for (int d = 0; d < 65536; ++d)
+        for (unsigned t = 0; t < used; ++t) { const size_t c = cnt[t][d]; cnt[t][d] = run; run += c; }
+      parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
+        std::vector<size_t>& c = cnt[t];
+        for (size_t i = i0; i < i1; ++i) t2[c[(recs[i].key >> shift) & 0xFFFF]++] = recs[i];
+      });
+      recs.swap(t2);
+    };
+    for (int shift = 0; shift < bits; shift += 16) radix_pass(shift);
+    for (int shift = 32; shift < 32 + bits; shift += 16) radix_pass(shift);
   }
-  if (recs.size() >= 0xFFFFFFFFull) return e->fail_msg("gather list exceeds 2^32 entries");
+  // cut into pairs: a pair starts where the key changes
   std::vector<uint32_t> pair_ptr;
-  std::vector<uint2> pair_ij, pair_ent(recs.size());
-  for (size_t i = 0; i < recs.size(); ++i) {
-    if (i == 0 || recs[i].key != recs[i - 1].key) {
-      pair_ptr.push_back((uint32_t)i);
-      pair_ij.push_back(make_uint2((uint32_t)(recs[i].key >> 32), (uint32_t)(recs[i].key & 0xFFFFFFFFu)));
-    }
-    pair_ent[i] = make_uint2(recs[i].a, recs[i].b);
+  std::vector<uint2> pair_ij;
+  std::unique_ptr<uint2[]> pair_ent(new uint2[std::max<size_t>(n_recs, 1)]);
+  {
+    const unsigned parts = (T <= 1 || n_recs < (1u << 16)) ? 1 : T;
+    std::vector<size_t> nstart(parts + 1, 0);
+    parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
+      size_t c = 0;
+      for (size_t i = i0; i < i1; ++i) {
+        c += (i == 0 || recs[i].key != recs[i - 1].key);
+        pair_ent[i] = make_uint2(recs[i].a, recs[i].b);
+      }
+      nstart[t + 1] = c;
+    });
+    for (unsigned t = 0; t < parts; ++t) nstart[t + 1] += nstart[t];
+    pair_ptr.resize(nstart[parts] + 1);
+    pair_ij.resize(nstart[parts]);
+    parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
+      size_t w = nstart[t];
+      for (size_t i = i0; i < i1; ++i)
+        if (i == 0 || recs[i].key != recs[i - 1].key) {
+          pair_ptr[w] = (uint32_t)i;
+          pair_ij[w++] = make_uint2((uint32_t)(recs[i].key >> 32), (uint32_t)(recs[i].key & 0xFFFFFFFFu));
+        }
+    });
+    pair_ptr[nstart[parts]] = (uint32_t)n_recs;
   }
-  pair_ptr.push_back((uint32_t)recs.size());
   st.n_pairs = (uint32_t)pair_ij.size();
-  st.n_pair_entries = recs.size();
-  recs.clear(); recs.shrink_to_fit();
+  st.n_pair_entries = n_recs;
+  recs.reset();
 
+  stage("S gather lists");
   // ---- gather lists for rhs -------------------------------------------------------------
   // per active pose: [observation rows | incidence rows]; scalars: sqrt(w) r at 2*obs,
   // b_l at 2*O + l*LM
@@ -318,6 +396,7 @@ static int build_structure(Engine* e) {
           prhs_ent[curB[linc_pose_lm[q]]++] = make_uint2(linc_row[q] + LM + k, 2 * st.O + l * LM + k);
   }
 
+  stage("rhs gather lists");
   // ---- pose-pose residuals: slots [unary | binary | imu], scatter lists per active pose ------
   const uint32_t nu = pb.num_unary, nbn = pb.num_binary, ni = pb.num_imu, nres = nu + nbn + ni;
   std::vector<uint32_t> res_p1(nres), res_p2(nres, 0xffffffffu);
@@ -348,6 +427,7 @@ static int build_structure(Engine* e) {
     }
   }
 
+  stage("pose-pose lists");
   // ---- 64x64-tile pattern of S (for the tile-sparse factorisation) ---------------------------
   {
     const uint32_t nt = st.ld / 64, D = (uint32_t)e->pose_dim;
@@ -369,6 +449,7 @@ static int build_structure(Engine* e) {
     e->nzL_valid = false;
   }
 
+  stage("tile pattern");
   // ---- upload ------------------------------------------------------------------------------
   int rc;
 #define UP(buf, vec) if ((rc = upload(e, e->buf, vec))) return rc
@@ -379,7 +460,10 @@ static int build_structure(Engine* e) {
   UP(obs_jrow_m, obs_jrow_m); UP(obs_jrow_r, obs_jrow_r); UP(obs_wrow_m, obs_wrow_m);
   UP(obs_first, obs_first); UP(lm_wrow_r, lm_wrow_r);
   UP(linc_ptr, linc_ptr); UP(linc_row, linc_row); UP(linc_pose, linc_pose_lm);
-  UP(pair_ptr, pair_ptr); UP(pair_ij, pair_ij); UP(pair_ent, pair_ent);
+  UP(pair_ptr, pair_ptr); UP(pair_ij, pair_ij);
+  BAE_HIP(e->pair_ent.alloc(std::max<size_t>(st.n_pair_entries, 1)));
+  if (st.n_pair_entries)
+    BAE_HIP(hipMemcpyAsync(e->pair_ent.p, pair_ent.get(), st.n_pair_entries * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
   UP(prhs_ptr, prhs); UP(prhs_ent, prhs_ent);
   {
     std::vector<uint32_t> pose_rows(pslot_ptr);
@@ -483,6 +567,7 @@ static int build_structure(Engine* e) {
   BAE_HIP(e->hist.alloc(2048 + 8));
   BAE_HIP(e->flags.alloc(16));
   BAE_HIP(hipStreamSynchronize(e->stream));
+  stage("upload / device buffers");
   return 0;
 }
 

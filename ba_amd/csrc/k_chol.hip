@@ -1061,9 +1061,10 @@ k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restric
 // remaining columns of the outer panel get ONE update with all KIN columns (K = 256) — a third of
 // the tile updates of a flat right-looking panel at KOUT = 16, and mostly four times as deep.
 // Every update launch also factorises the next diagonal tile (k_step_update).
-static const uint32_t KIN = 4;
+static const uint32_t KIN_DEFAULT = 4;
 static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t Jend,
                                double* dsgn, double* opbuf, int* colneg, int* flags, const uint8_t* nz) {
+  static const uint32_t KIN = getenv("BA_HIP_KIN") ? (uint32_t)atoi(getenv("BA_HIP_KIN")) : KIN_DEFAULT;  // A/B
   for (uint32_t sub = J; sub < Jend; sub += KIN) {
     const uint32_t sub_end = std::min(sub + KIN, Jend);
     for (uint32_t jj = sub; jj < sub_end; ++jj) {
