@@ -1061,10 +1061,9 @@ k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restric
 // remaining columns of the outer panel get ONE update with all KIN columns (K = 256) — a third of
 // the tile updates of a flat right-looking panel at KOUT = 16, and mostly four times as deep.
 // Every update launch also factorises the next diagonal tile (k_step_update).
-static const uint32_t KIN_DEFAULT = 4;
+static const uint32_t KIN = 4;
 static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t Jend,
                                double* dsgn, double* opbuf, int* colneg, int* flags, const uint8_t* nz) {
-  static const uint32_t KIN = getenv("BA_HIP_KIN") ? (uint32_t)atoi(getenv("BA_HIP_KIN")) : KIN_DEFAULT;  // A/B
   for (uint32_t sub = J; sub < Jend; sub += KIN) {
     const uint32_t sub_end = std::min(sub + KIN, Jend);
     for (uint32_t jj = sub; jj < sub_end; ++jj) {
@@ -1093,8 +1092,7 @@ static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld
   static const uint32_t sbl = getenv("BA_HIP_SBL") ? (uint32_t)atoi(getenv("BA_HIP_SBL")) : 3u;
   const uint32_t m = nblk - a_end;
   if (full && !no128 && m >= 16 && (a_end % 2u) == 0 && (own_n <= 1 || own_kout % 2u == 0)) {
-    static const uint32_t sbl2 = getenv("BA_HIP_SBL2") ? (uint32_t)atoi(getenv("BA_HIP_SBL2")) : 2u;
-    const uint32_t m2 = m / 2, sbe2 = 1u << sbl2;
+    const uint32_t m2 = m / 2, sbl2 = 2, sbe2 = 1u << sbl2;
     const uint32_t nsr = (m2 + sbe2 - 1) / sbe2, nsb = nsr * (nsr + 1) / 2;
     // leftover 64-tiles first (a multiple of 8 workgroups keeps the XCD phase of the blocks)
     const uint32_t nrow64 = (m * (1 + (m & 1u)) + 7) / 8 * 8;
@@ -1372,22 +1370,6 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
           tiles += mk * (mk + 1) / 2 + mk;
         }
         e->kstats.syrk_flops += tiles * 2.0 * NB * NB * NB;
-        static const bool dbg_formed = getenv("BA_HIP_DEBUG_FORMED") != nullptr;
-        if (dbg_formed && nz && e->nzL_host.size() == (size_t)nblk * nblk) {
-          // products a 128-block launch forms (either row tile x either column tile nonzero)
-          double formed = 0.0;
-          const uint32_t m = nblk - a_end, m2 = m / 2;
-          for (uint32_t kb = J; kb < Jend; ++kb) {
-            double mk2 = 0.0;
-            for (uint32_t R = 0; R < m2; ++R)
-              mk2 += (e->nzL_host[(size_t)(a_end + 2 * R) * nblk + kb] | e->nzL_host[(size_t)(a_end + 2 * R + 1) * nblk + kb]) ? 1.0 : 0.0;
-            formed += 4.0 * (mk2 * (mk2 + 1) / 2);
-          }
-          static double tot_formed = 0.0, tot_alg = 0.0;
-          tot_formed += formed;
-          tot_alg += tiles;
-          fprintf(stderr, "[formed] a_end %u alg %.0f formed128 %.0f  cumulative ratio %.4f\n", a_end, tiles, formed, tot_formed / tot_alg);
-        }
       }
     }
   }
