@@ -122,6 +122,10 @@ struct Engine {
   std::vector<uint8_t> nzL_host;         // host copy (flop accounting of the profiled launches)
   uint64_t nzL_version = 0;
   // distributed solve: per panel the row tiles with a structurally nonzero tile (message rows)
+  std::vector<uint8_t> nzS_host;         // tile pattern of S itself (union over the shards), before fill
+  DBuf<uint32_t> dist_srows;             // reduce-scatter: row tiles of every panel with a nonzero S tile
+  std::vector<uint32_t> dist_srows_off;
+  uint64_t dist_srows_version = ~0ull;
   DBuf<uint32_t> dist_rows;
   std::vector<uint32_t> dist_rows_off;
   uint64_t dist_rows_version = ~0ull;

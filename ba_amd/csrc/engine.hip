@@ -870,6 +870,8 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
       // distributed reduced solve: every rank only needs the sum of the column panels it owns
       // (reduce-scatter); the reduced rhs (one row) and rhs_p are summed everywhere
       BAE_HIP(hipStreamSynchronize(e->stream));
+      // the union tile pattern decides which tiles of S travel (a collective on first use)
+      if (!e->nzL_valid && (rc = factor_tile_pattern(e))) return rc;
       if (e->allreduce(e->allreduce_ctx, e->rhs_sc.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
       if (e->allreduce(e->allreduce_ctx, e->rhs_p.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
       if ((rc = dist_reduce_scatter_S(e))) return rc;

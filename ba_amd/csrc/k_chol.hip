@@ -977,6 +977,7 @@ int factor_tile_pattern(Engine* e) {
     d.release();
     for (size_t i = 0; i < nz.size(); ++i) nz[i] = cnt[i] > 0.5 ? 1 : 0;
   }
+  e->nzS_host = nz;
   // symbolic right-looking elimination on the lower triangle; the working copy is column-major
   // (c[k * nt + i] = L(i,k)) so that both the scan of column k and the fill of column j are
   // contiguous
@@ -1123,7 +1124,8 @@ struct DistLayout {
   size_t chunk;             // padded chunk size (doubles)
 };
 
-static DistLayout dist_layout(uint32_t nblk, uint32_t nranks) {
+// rows_off[p + 1] - rows_off[p] = row tiles of panel p that travel
+static DistLayout dist_layout(uint32_t nblk, uint32_t nranks, const std::vector<uint32_t>& rows_off) {
   DistLayout d;
   d.kout = choose_kout(nblk);
   d.npanels = (nblk + d.kout - 1) / d.kout;
@@ -1131,7 +1133,7 @@ static DistLayout dist_layout(uint32_t nblk, uint32_t nranks) {
   std::vector<size_t> used(nranks, 0);
   for (uint32_t p = 0; p < d.npanels; ++p) {
     const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
-    const size_t rows = (size_t)(nblk - J) * NB, w = (size_t)(Jend - J) * NB;
+    const size_t rows = (size_t)(rows_off[p + 1] - rows_off[p]) * NB, w = (size_t)(Jend - J) * NB;
     d.off[p] = used[p % nranks];
     used[p % nranks] += rows * w;
   }
@@ -1141,13 +1143,42 @@ static DistLayout dist_layout(uint32_t nblk, uint32_t nranks) {
   return d;
 }
 
+// Reduce-scatter of S onto the panel owners.  Only the row tiles of a panel that hold a
+// structurally nonzero tile of S on SOME shard travel (the union pattern of
+// factor_tile_pattern, identical on every rank; S itself is half as dense as its factor): the
+// other tiles are zero on every rank already.
 int dist_reduce_scatter_S(Engine* e) {
   const uint32_t ld = e->st.ld, nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
-  const DistLayout d = dist_layout(nblk, N);
+  const uint32_t KOUT = choose_kout(nblk), npanels = (nblk + KOUT - 1) / KOUT;
+  const bool pat = e->nzS_host.size() == (size_t)nblk * nblk;
+  const uint64_t want = pat ? e->nzL_version * 64 + KOUT : ~1ull;
+  if (e->dist_srows_version != want || e->dist_srows_off.size() != npanels + 1) {
+    std::vector<uint32_t> list;
+    e->dist_srows_off.assign(npanels + 1, 0);
+    for (uint32_t p = 0; p < npanels; ++p) {
+      const uint32_t J = p * KOUT, Jend = std::min(J + KOUT, nblk);
+      for (uint32_t i = J; i < nblk; ++i) {
+        bool on = !pat || i < Jend;
+        for (uint32_t kb = J; kb < Jend && !on; ++kb) on = e->nzS_host[(size_t)i * nblk + kb] != 0;
+        if (on) list.push_back(i);
+      }
+      e->dist_srows_off[p + 1] = (uint32_t)list.size();
+    }
+    BAE_HIP(e->dist_srows.alloc(std::max<size_t>(list.size(), 1)));
+    if (!list.empty())
+      BAE_HIP(hipMemcpy(e->dist_srows.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    e->dist_srows_version = want;
+  }
+  const DistLayout d = dist_layout(nblk, N, e->dist_srows_off);
   BAE_HIP(e->packed.alloc(d.chunk * N));
+  // the padding between the panels of a chunk is summed too: keep it finite
+  BAE_HIP(hipMemsetAsync(e->packed.p, 0, d.chunk * N * sizeof(double), e->stream));
   for (uint32_t p = 0; p < d.npanels; ++p) {
     const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
-    hipLaunchKernelGGL(k_copy_panel, dim3((nblk - J) * NB), dim3(256), 0, e->stream, e->A.p, ld, J * NB, J * NB,
+    const uint32_t ntl = e->dist_srows_off[p + 1] - e->dist_srows_off[p];
+    if (ntl == 0) continue;
+    hipLaunchKernelGGL(k_copy_panel_rows, dim3(ntl * NB), dim3(256), 0, e->stream, e->A.p, ld,
+                       (const uint32_t*)(e->dist_srows.p + e->dist_srows_off[p]), ntl, nblk * NB, J * NB,
                        (Jend - J) * NB, e->packed.p + (size_t)(p % N) * d.chunk + d.off[p], 0);
   }
   BAE_HIP(hipGetLastError());
@@ -1155,7 +1186,10 @@ int dist_reduce_scatter_S(Engine* e) {
   if (e->coll(e->coll_ctx, 2, e->packed.p, d.chunk, 0) != 0) return e->fail_msg("reduce-scatter hook failed");
   for (uint32_t p = rank; p < d.npanels; p += N) {
     const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
-    hipLaunchKernelGGL(k_copy_panel, dim3((nblk - J) * NB), dim3(256), 0, e->stream, e->A.p, ld, J * NB, J * NB,
+    const uint32_t ntl = e->dist_srows_off[p + 1] - e->dist_srows_off[p];
+    if (ntl == 0) continue;
+    hipLaunchKernelGGL(k_copy_panel_rows, dim3(ntl * NB), dim3(256), 0, e->stream, e->A.p, ld,
+                       (const uint32_t*)(e->dist_srows.p + e->dist_srows_off[p]), ntl, nblk * NB, J * NB,
                        (Jend - J) * NB, e->packed.p + (size_t)rank * d.chunk + d.off[p], 1);
   }
   BAE_HIP(hipGetLastError());
