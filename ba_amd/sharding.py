@@ -57,7 +57,9 @@ def torch_allreduce_hook(dist, device="cuda"):
                 step = 1 << 29
                 for lo in range(0, count, step):
                     dist.all_reduce(t[lo:lo + step], op=dist.ReduceOp.SUM)
-                torch.cuda.synchronize()
+                # the collective is ordered into torch's current stream: wait for that stream only
+                # (a device-wide synchronize would also wait for the engine's look-ahead stream)
+                torch.cuda.current_stream().synchronize()
             else:
                 a = _host_view(ptr, count, dtype)
                 t = torch.from_numpy(a.view(np.int64) if dtype == 1 else a)
@@ -97,7 +99,7 @@ def torch_collectives_hook(dist, device="cuda"):
             else:
                 raise ValueError("unknown collective op %d" % op)
             if device == "cuda":
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()  # not device-wide: see torch_allreduce_hook
             return 0
         except Exception as exc:  # the engine reports the failure
             import sys
