@@ -1018,7 +1018,7 @@ uint32_t choose_kout(uint32_t nblk) {
 //     signs and the factor packets into one message and BROADCASTS it; everybody else unpacks;
 //   * trailing update with panel J: the owner of panel J+1 applies it to that panel (and
 //     factorises its first diagonal tile in the same launch), every rank applies it to the
-//     panels it owns further right (k_update2's ownership filter) on its second stream,
+//     panels it owns further right (ownership filter of k_update128 / k_update2) on its second stream,
 //     overlapping the next panel's chain and broadcast;
 //   * the backward substitution is replicated (every rank holds all of L after the broadcasts).
 // Enabled when the caller installed the collectives hook (ba_hip_set_collectives), more than

@@ -196,7 +196,7 @@ typedef int (*ba_hip_allreduce_fn)(void* ctx, void* dev_ptr, size_t count, int d
 int ba_hip_set_allreduce(ba_hip_engine* e, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);
 /* Collectives hook (optional, on top of the all-reduce hook): with it the dense reduced solve
  * is DISTRIBUTED over the shards instead of replicated:
- * the partial S of every shard is reduce-scattered to the owners of its 256/512-column panels
+ * the partial S of every shard is reduce-scattered to the owners of its column panels (256 / 512 / 1024 columns by system size)
  * (panel p belongs to rank p mod nranks), every panel is factorised by its owner and broadcast,
  * and each rank applies the trailing updates to the panels it owns.
  *   op 1 = broadcast `count` doubles at dev_ptr from rank `root`;
