@@ -393,31 +393,45 @@ __global__ void __launch_bounds__(256, 2)
 k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t m2, uint32_t kb0,
             uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, uint32_t sbl,
             const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout,
-            uint32_t nrow64) {
+            uint32_t nrow64, uint32_t r0, uint32_t rect_cols) {
   __shared__ double X[2][NB2][LDK2];
   __shared__ double Y[2][NB2][LDK2];
   __shared__ uint32_t klist[32];
   // The first nrow64 workgroups take the 64-tiles the 128-blocks leave over: the rhs row (row
   // nblk) and, when the trailing matrix has an odd number of tile rows, its last tile row.
+  // Two shapes: the lower triangle of the trailing matrix from tile c0 on (rect_cols = 0, r0 = c0),
+  // or the rectangle rows >= r0 x the rect_cols 128-column blocks from c0 on (the next panel's
+  // columns below the panel itself).
   if (blockIdx.x < nrow64) {
-    const uint32_t mcols = nblk - c0, y = blockIdx.x / mcols;
+    const uint32_t mcols = rect_cols ? 2 * rect_cols : nblk - c0, y = blockIdx.x / mcols;
     const uint32_t c = c0 + blockIdx.x % mcols, i = nblk - y;
-    if (y > (mcols & 1u) || c > i || c >= nblk) return;  // (nrow64 is rounded up to a multiple of 8)
+    if (y > ((nblk - r0) & 1u) || c > i || c >= nblk) return;  // (nrow64 is rounded up to a multiple of 8)
     if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
     update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, reinterpret_cast<double(*)[NB][LDK2]>(&X[0][0][0]),
                 reinterpret_cast<double(*)[NB][LDK2]>(&Y[0][0][0]), klist);
     return;
   }
-  // XCD-aware mapping as in k_update2, over the m2 x m2 grid of 128-blocks
-  const uint32_t b = blockIdx.x - nrow64, xcd = b & 7u, slot = b >> 3;
-  const uint32_t t = (slot >> (2 * sbl)) * 8u + xcd, within = slot & ((1u << (2 * sbl)) - 1u);
-  uint32_t sr_ = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((uint64_t)(sr_ + 1) * (sr_ + 2) / 2 <= t) ++sr_;
-  while ((uint64_t)sr_ * (sr_ + 1) / 2 > t) --sr_;
-  const uint32_t sc_ = t - (uint32_t)((uint64_t)sr_ * (sr_ + 1) / 2);
-  const uint32_t R = (sr_ << sbl) + (within >> sbl), C = (sc_ << sbl) + (within & ((1u << sbl) - 1u));
-  if (C > R || R >= m2) return;
-  const uint32_t c = c0 + 2 * C, i = c0 + 2 * R;
+  const uint32_t b = blockIdx.x - nrow64;
+  uint32_t R, C;
+  if (rect_cols) {
+    // consecutive workgroups (= the XCDs, round-robin) take the column blocks of one row block:
+    // an XCD keeps "its" column operands in L2 for all rows
+    R = b / rect_cols;
+    C = b % rect_cols;
+    if (R >= m2) return;
+  } else {
+    // XCD-aware mapping as in k_update2, over the m2 x m2 grid of 128-blocks
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t t = (slot >> (2 * sbl)) * 8u + xcd, within = slot & ((1u << (2 * sbl)) - 1u);
+    uint32_t sr_ = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)(sr_ + 1) * (sr_ + 2) / 2 <= t) ++sr_;
+    while ((uint64_t)sr_ * (sr_ + 1) / 2 > t) --sr_;
+    const uint32_t sc_ = t - (uint32_t)((uint64_t)sr_ * (sr_ + 1) / 2);
+    R = (sr_ << sbl) + (within >> sbl);
+    C = (sc_ << sbl) + (within & ((1u << sbl) - 1u));
+    if (C > R || R >= m2) return;
+  }
+  const uint32_t c = c0 + 2 * C, i = r0 + 2 * R;
   if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // pattern mask of the K range (lane l: tile column kb0 + l) and pivot-sign check
@@ -736,7 +750,8 @@ __device__ __forceinline__ void subst_rows(double4_t R[4], const double op[NOPV]
 __global__ void __launch_bounds__(256, 2)
 k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
               uint32_t kb1, double* __restrict__ dsgn, double* __restrict__ opbuf,
-              int* __restrict__ colneg, int* __restrict__ status, const uint8_t* __restrict__ nz) {
+              int* __restrict__ colneg, int* __restrict__ status, const uint8_t* __restrict__ nz,
+              uint32_t row_end) {
   struct UpdLds { double X[2][NB][LDK2]; double Y[2][NB][LDK2]; };
   __shared__ uint32_t klist[32];  // active tile columns (tile-sparse factor, see k_update2)
   constexpr size_t kLds = sizeof(TileLds) > sizeof(UpdLds) ? sizeof(TileLds) : sizeof(UpdLds);
@@ -746,7 +761,7 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
   __builtin_amdgcn_s_setprio(2);
   const uint32_t c = c0 + blockIdx.y;
   const uint32_t i = c + blockIdx.x;
-  if (i > nblk) return;
+  if (i > nblk || i >= row_end) return;  // row_end: rows from there on belong to a k_update128 launch
   const bool special = (blockIdx.x == 0 && blockIdx.y == 0);  // the diagonal tile (c0,c0)
   if (!special) {  // every other tile: the plain trailing update
     update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, u.X, u.Y, klist);
@@ -1071,12 +1086,34 @@ static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t 
       hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s, dA, ld, jj, nblk, (const double*)opbuf, nz);
       if (jj + 1 < sub_end)
         hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
-                           nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz);
+                           nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
     }
     if (sub_end < Jend)
       hipLaunchKernelGGL(k_step_update, dim3(nblk - sub_end + 1, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk,
-                         sub_end, sub, sub_end, dsgn, opbuf, colneg, flags, nz);
+                         sub_end, sub, sub_end, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
   }
+}
+
+// Update of the NEXT panel's tile columns [c0, c0 + ncols) with the tile columns [kb0, kb1) on the
+// chain stream: the panel's own triangle — with the factorisation of tile (c0, c0) in workgroup
+// (0,0) — stays a k_step_update launch; the rectangle below the panel goes to 128x128 blocks when
+// it is big enough.
+static void launch_next_panel_update(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t c0,
+                                     uint32_t ncols, uint32_t kb0, uint32_t kb1, double* dsgn, double* opbuf,
+                                     int* colneg, int* flags, const uint8_t* nz) {
+  static const bool no128 = getenv("BA_HIP_NO128") != nullptr;
+  const uint32_t r0 = c0 + ncols;
+  if (!no128 && r0 + 16 <= nblk && ncols % 2u == 0 && c0 % 2u == 0) {
+    const uint32_t m = nblk - r0, m2 = m / 2, rect_cols = ncols / 2;
+    hipLaunchKernelGGL(k_step_update, dim3(ncols, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn, opbuf,
+                       colneg, flags, nz, r0);
+    const uint32_t nrow64 = (ncols * (1 + (m & 1u)) + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_update128, dim3(nrow64 + m2 * rect_cols), dim3(256), 0, s, dA, ld, nblk, c0, m2, kb0, kb1,
+                       (const double*)dsgn, (const int*)colneg, 0u, nz, 0u, 1u, 1u, nrow64, r0, rect_cols);
+    return;
+  }
+  hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn,
+                     opbuf, colneg, flags, nz, nblk + 1u);
 }
 
 // Bulk trailing update of the tile rows / columns >= a_end (and the rhs row) with the tile columns
@@ -1099,7 +1136,7 @@ static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld
     const uint32_t nrow64 = (m * (1 + (m & 1u)) + 7) / 8 * 8;
     if (e) e->prof_begin(e->ev_syrk, s);
     hipLaunchKernelGGL(k_update128, dim3(nrow64 + ((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk,
-                       a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own_rank, own_n, own_kout, nrow64);
+                       a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own_rank, own_n, own_kout, nrow64, a_end, 0u);
     if (e) e->prof_end(e->ev_syrk, s);
     return;
   }
@@ -1243,7 +1280,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
   BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), s0));
   if (rank == 0)  // factor packet of tile 0
     hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
-                       colneg, e->flags.p, nz);
+                       colneg, e->flags.p, nz, nblk + 1u);
   int prev_bulk = -1;
   uint32_t pj = 0;
   for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
@@ -1282,8 +1319,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     if (rank == (pj + 1) % N) {
       // next panel's columns (owned here): update + factor packet of its first diagonal tile
       if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
-      hipLaunchKernelGGL(k_step_update, dim3(nblk - Jend + 1, a_end - Jend), dim3(256), 0, s0, dA, ld, nblk, Jend,
-                         J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
+      launch_next_panel_update(s0, dA, ld, nblk, Jend, a_end - Jend, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
     }
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
@@ -1358,15 +1394,9 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     e->ev_bulk.push_back(b);
   }
   BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), s0));
-  // update of the tile columns [c0, c0 + ncols) with the tile columns [kb0, kb1) on the
-  // critical-path stream; in the pipelined scheme the launch also factorises tile (c0,c0)
-  auto step_update = [&](uint32_t c0, uint32_t ncols, uint32_t kb0, uint32_t kb1) {
-    hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s0, dA, ld, nblk, c0,
-                         kb0, kb1, dsgn, opbuf, colneg, e->flags.p, nz);
-  };
   // factor packet of tile 0 (nothing to update: one workgroup)
   hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
-                       colneg, e->flags.p, nz);
+                       colneg, e->flags.p, nz, nblk + 1u);
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
   // overlapping the serial factorisation of the next panel.
@@ -1380,7 +1410,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     const uint32_t a_end = Jend + KOUT < nblk ? Jend + KOUT : nblk;  // columns of the next panel
     // (a) next panel's columns: needs every earlier bulk update of those columns
     if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
-    step_update(Jend, a_end - Jend, J, Jend);
+    launch_next_panel_update(s0, dA, ld, nblk, Jend, a_end - Jend, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
     // (b) the rest, concurrently with the next panel's factorisation
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
