@@ -57,6 +57,7 @@ SYMBOLS = [
     "ba_adjuster_add_landmark", "ba_adjuster_add_projection_residual",
     "ba_adjuster_add_unary_constraint", "ba_adjuster_add_binary_constraint",
     "ba_adjuster_add_imu_residual", "ba_adjuster_regularize_pose", "ba_adjuster_set_root_pose_id",
+    "ba_adjuster_set_pose_cam_params",
     "ba_adjuster_add_poses", "ba_adjuster_add_landmarks", "ba_adjuster_add_projection_residuals",
     "ba_adjuster_solve", "ba_adjuster_num_poses", "ba_adjuster_num_landmarks",
     "ba_adjuster_num_proj_residuals", "ba_adjuster_get_poses", "ba_adjuster_get_landmarks",
@@ -152,6 +153,21 @@ class BundleAdjuster:
         t, v, bb = _d(t_wp), _d(v_w), _d(b)
         return self.L.ba_adjuster_add_pose(self.h, _p(t, dp), _p(v, dp), _p(bb, dp), int(is_active),
                                            C.c_double(time))
+
+    def SetPoseCamParams(self, pose_cam_params):
+        """Per-pose pinhole intrinsics (P x 4) + Options::use_per_pose_cam_params (reference
+        BundleAdjuster.h:96, 292-323); None switches back to the rig camera."""
+        if pose_cam_params is None:
+            rc = self.L.ba_adjuster_set_pose_cam_params(self.h, 0, None)
+        else:
+            a = _d(pose_cam_params).reshape(-1, 4)
+            rc = self.L.ba_adjuster_set_pose_cam_params(self.h, a.shape[0], _p(a, dp))
+        if rc != 0:
+            raise ValueError("SetPoseCamParams: one [fx, fy, u0, v0] per pose expected")
+
+    def SetUsePerPoseCamParams(self, on=True):
+        if not on:
+            self.SetPoseCamParams(None)
 
     def AddLandmark(self, x_w, ref_pose_id, ref_cam_id=0, is_active=True):
         x = _d(x_w)

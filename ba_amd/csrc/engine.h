@@ -41,6 +41,7 @@ struct Problem {  // host copies, reference ids
   uint32_t num_cams = 0, num_poses = 0, num_lms = 0, num_proj = 0;
   uint32_t num_unary = 0, num_binary = 0, num_imu = 0;
   std::vector<double> cam_params, cam_tvs;                 // [C][4], [C][7]
+  std::vector<double> pose_cam_params;                     // [P][4] or empty (use_per_pose_cam_params)
   std::vector<double> pose_state;                          // [P][16]
   std::vector<uint8_t> pose_active;
   std::vector<double> lm_xw;                               // [L][4]
@@ -99,6 +100,8 @@ struct Engine {
 
   // ---- device: static problem data
   DBuf<double> cam;                 // [C][4 + 12 (T_vs) + 12 (T_sv)]
+  DBuf<double> pose_cam;            // [P][4] per-pose intrinsics (Options::use_per_pose_cam_params)
+  const double* pose_cam_ptr() const { return prob.pose_cam_params.empty() ? nullptr : pose_cam.p; }
   DBuf<int32_t> pose_opt, lm_opt;
   DBuf<uint16_t> pose_mask;
   DBuf<uint32_t> lm_ref_pose, lm_ref_cam;

@@ -683,6 +683,16 @@ int ba_hip_set_cameras(ba_hip_engine* h, uint32_t n, const double* params4, cons
   return 0;
 }
 
+int ba_hip_set_pose_cam_params(ba_hip_engine* h, uint32_t n, const double* params4) {
+  ENG(h);
+  if (n == 0 || !params4) {
+    e->prob.pose_cam_params.clear();
+    return 0;
+  }
+  e->prob.pose_cam_params.assign(params4, params4 + 4 * (size_t)n);
+  return upload(e, e->pose_cam, e->prob.pose_cam_params);
+}
+
 int ba_hip_set_poses(ba_hip_engine* h, uint32_t n, const double* t_wp7, const double* v_w3,
                      const double* b6, const uint8_t* is_active) {
   ENG(h);
@@ -809,6 +819,8 @@ int ba_hip_begin_solve(ba_hip_engine* h) {
   ENG(h);
   NEED_FINAL();
   BAE_HIP(hipSetDevice(e->device));
+  if (!e->prob.pose_cam_params.empty() && e->prob.pose_cam_params.size() != 4 * (size_t)e->prob.num_poses)
+    return e->fail_msg("per-pose camera parameters: one [fx,fy,u0,v0] per pose expected");
   int rc = launch_pose_prep(e);
   if (rc) return rc;
   rc = launch_begin_solve(e);

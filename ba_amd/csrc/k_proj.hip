@@ -131,7 +131,8 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
                             const double* __restrict__ wts, const double* __restrict__ lm_x,
                             const uint32_t* __restrict__ lm_ref_pose,
                             const uint32_t* __restrict__ lm_ref_cam,
-                            const double* __restrict__ cam, const double* __restrict__ tsw,
+                            const double* __restrict__ cam, const double* __restrict__ pose_cam,
+                            const double* __restrict__ tsw,
                             const double* __restrict__ tws, double* __restrict__ err,
                             uint32_t* __restrict__ lm_outliers, double* __restrict__ partials) {
   __shared__ double red[256];
@@ -145,7 +146,9 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
     if (LM == 1) t_ws_r = load_rt(tws + ((size_t)lm_ref_pose[l] * C + lm_ref_cam[l]) * kRt);
     const V3 P = proj_point<LM>(t_sw_m, t_ws_r, x);
     const double* cp = cam + (size_t)cm * 35;
-    Cam cc = {cp[0], cp[1], cp[2], cp[3]};
+    // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
+    const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
+    Cam cc = {ip[0], ip[1], ip[2], ip[3]};
     double u, v;
     project(cc, P, &u, &v);
     const double r0 = obs_z[2 * (size_t)a] - u, r1 = obs_z[2 * (size_t)a + 1] - v;
@@ -177,6 +180,7 @@ __global__ void k_residual_vectors(int O, int C, const double* __restrict__ obs_
                                    const uint32_t* __restrict__ obs_lm, const double* __restrict__ lm_x,
                                    const uint32_t* __restrict__ lm_ref_pose,
                                    const uint32_t* __restrict__ lm_ref_cam, const double* __restrict__ cam,
+                                   const double* __restrict__ pose_cam,
                                    const double* __restrict__ tsw, const double* __restrict__ tws,
                                    double* __restrict__ r2) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,7 +192,9 @@ __global__ void k_residual_vectors(int O, int C, const double* __restrict__ obs_
   if (LM == 1) t_ws_r = load_rt(tws + ((size_t)lm_ref_pose[l] * C + lm_ref_cam[l]) * kRt);
   const V3 P = proj_point<LM>(t_sw_m, t_ws_r, x);
   const double* cp = cam + (size_t)cm * 35;
-  Cam cc = {cp[0], cp[1], cp[2], cp[3]};
+  // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
+    const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
+    Cam cc = {ip[0], ip[1], ip[2], ip[3]};
   double u, v;
   project(cc, P, &u, &v);
   r2[2 * (size_t)a] = obs_z[2 * (size_t)a] - u;
@@ -203,7 +209,7 @@ int launch_residual_vectors(Engine* e, double* d_r2) {
   const dim3 grid((O + 255) / 256), block(256);
 #define BAE_ARGS                                                                              \
   O, (int)e->st.C, e->obs_z.p, e->obs_pose.p, e->obs_cam.p, e->obs_lm.p, e->lm_x[e->cur].p,   \
-      e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->tsw.p, e->tws.p, d_r2
+      e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, d_r2
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_residual_vectors<1>, grid, block, 0, e->stream, BAE_ARGS);
   else hipLaunchKernelGGL(k_residual_vectors<3>, grid, block, 0, e->stream, BAE_ARGS);
 #undef BAE_ARGS
@@ -220,7 +226,7 @@ int launch_residuals(Engine* e, int mode) {
 #define BAE_ARGS                                                                          \
   O, (int)e->st.C, mode, e->opt.projection_outlier_threshold, e->obs_z.p, e->obs_pose.p,  \
       e->obs_cam.p, e->obs_lm.p, w, e->lm_x[e->cur].p, e->lm_ref_pose.p, e->lm_ref_cam.p, \
-      e->cam.p, e->tsw.p, e->tws.p, e->obs_e.p, e->lm_outliers.p, e->partials.p
+      e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->obs_e.p, e->lm_outliers.p, e->partials.p
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_residuals<1>, grid, block, 0, e->stream, BAE_ARGS);
   else hipLaunchKernelGGL(k_residuals<3>, grid, block, 0, e->stream, BAE_ARGS);
 #undef BAE_ARGS
@@ -263,7 +269,8 @@ __global__ void __launch_bounds__(64) k_landmarks(int L, int C, int O, double c_
                             const double* __restrict__ lm_x,
                             const uint32_t* __restrict__ lm_ref_pose,
                             const uint32_t* __restrict__ lm_ref_cam,
-                            const double* __restrict__ cam, const double* __restrict__ tsw,
+                            const double* __restrict__ cam, const double* __restrict__ pose_cam,
+                            const double* __restrict__ tsw,
                             const double* __restrict__ tws, const double* __restrict__ twp,
                             double* __restrict__ obs_w, double* __restrict__ frow,
                             double* __restrict__ scal, double* __restrict__ lm_vinv,
@@ -296,7 +303,9 @@ __global__ void __launch_bounds__(64) k_landmarks(int L, int C, int O, double c_
   for (uint32_t a = a0; a < a1; ++a) {
     const uint32_t pm = obs_pose[a], cm = obs_cam[a];
     const double* cp = cam + (size_t)cm * 35;
-    Cam cc = {cp[0], cp[1], cp[2], cp[3]};
+    // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
+    const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
+    Cam cc = {ip[0], ip[1], ip[2], ip[3]};
     const Rt t_sw_m = load_rt(tsw + ((size_t)pm * C + cm) * kRt);
     const Rt t_wp_m = load_rt(twp + (size_t)pm * kRt);
     const Rt t_sv_m = load_rt(cp + 16);
@@ -418,7 +427,7 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
       e->obs_cam.p, e->obs_w0.p, e->obs_jrow_m.p, e->obs_jrow_r.p, e->obs_wrow_m.p,           \
       e->obs_first.p, e->lm_wrow_r.p, e->linc_ptr.p, e->linc_row.p, e->lm_opt.p,              \
       e->pose_mask.p, e->lm_x[e->cur].p, e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p,         \
-      e->tsw.p, e->tws.p, e->twp.p, e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p,   \
+      e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->twp.p, e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p,   \
       e->obs_jl.p
   e->prof_begin(e->ev_landmarks);
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_landmarks<1>, grid, block, 0, e->stream, BAE_ARGS);

@@ -63,7 +63,7 @@ COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t
 # every entry point include/ba_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "ba_hip_create", "ba_hip_destroy", "ba_hip_last_error", "ba_hip_set_options",
-    "ba_hip_set_cameras", "ba_hip_set_poses", "ba_hip_set_landmarks",
+    "ba_hip_set_cameras", "ba_hip_set_pose_cam_params", "ba_hip_set_poses", "ba_hip_set_landmarks",
     "ba_hip_set_projection_residuals", "ba_hip_set_unary_residuals",
     "ba_hip_set_binary_residuals", "ba_hip_set_imu_residuals", "ba_hip_set_gravity",
     "ba_hip_finalize", "ba_hip_begin_solve", "ba_hip_set_pose_masks", "ba_hip_linearize",
@@ -163,6 +163,14 @@ class Engine:
     def set_cameras(self, params, t_vs):
         p, t = _d(params).reshape(-1, 4), _d(t_vs).reshape(-1, 7)
         self._chk(self.L.ba_hip_set_cameras(self.h, p.shape[0], _p(p, dp), _p(t, dp)))
+
+    def set_pose_cam_params(self, params):
+        """P x 4 pinhole intrinsics per pose (use_per_pose_cam_params), None = rig camera."""
+        if params is None:
+            self._chk(self.L.ba_hip_set_pose_cam_params(self.h, 0, None))
+        else:
+            p = _d(params).reshape(-1, 4)
+            self._chk(self.L.ba_hip_set_pose_cam_params(self.h, p.shape[0], _p(p, dp)))
 
     def set_poses(self, t_wp, v_w=None, b=None, is_active=None):
         t = _d(t_wp).reshape(-1, 7)

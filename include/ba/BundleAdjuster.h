@@ -173,13 +173,15 @@ class BundleAdjuster {
     return AddPose(t_wp, std::vector<Scalar>(), Vector3t::Zero(), Vector6t::Zero(), is_active, time,
                    external_id);
   }
-  // reference :292-323 (cam_params accepted for signature compatibility; per-pose camera
-  // parameters are outside this path)
+  // reference :292-323; cam_params (any indexable container of the pinhole intrinsics fx, fy, u0,
+  // v0; may be empty) is what Options::use_per_pose_cam_params projects this pose's
+  // measurements with (parallel_algos.h:54-57)
   template <typename CamParams>
-  uint32_t AddPose(const SE3t& t_wv, const CamParams& /*cam_params*/, const Vector3t& v_w,
+  uint32_t AddPose(const SE3t& t_wv, const CamParams& cam_params, const Vector3t& v_w,
                    const Vector6t& b, const bool is_active = true, const double time = -1,
                    const int external_id = -1) {
     Pose pose;
+    for (size_t i = 0; i < (size_t)cam_params.size(); ++i) pose.cam_params.push_back((Scalar)cam_params[i]);
     pose.external_id = external_id;
     pose.time = time;
     pose.t_wp = t_wv;
@@ -359,6 +361,14 @@ class BundleAdjuster {
   }
   const SolutionSummary<Scalar>& GetSolutionSummary() const { return summary_; }
   Options<Scalar>& options() { return options_; }
+  // extension (not in the reference, where the parameters can only be given to AddPose): replace
+  // the camera intrinsics stored on a pose; used by the flat C API
+  template <typename CamParams>
+  void SetPoseCamParams(const uint32_t pose_id, const CamParams& cam_params) {
+    assert(pose_id < poses_.size());
+    poses_[pose_id].cam_params.clear();
+    for (size_t i = 0; i < (size_t)cam_params.size(); ++i) poses_[pose_id].cam_params.push_back((Scalar)cam_params[i]);
+  }
   const std::shared_ptr<Rig<Scalar>> rig() const { return rig_; }
 
   // reference :608-631 (the rotation flag masks indices 2,4,5 — kept as is)
@@ -508,6 +518,22 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   }
   if (!Check(ba_hip_set_cameras(engine_, C, cam_p.data(), cam_t.data()), "ba_hip_set_cameras")) return false;
   if (!Check(ba_hip_set_poses(engine_, P, pt.data(), pv.data(), pb.data(), pa.data()), "ba_hip_set_poses")) return false;
+  if (options_.use_per_pose_cam_params) {
+    // reference parallel_algos.h:54-57: cam->SetParams(pose.cam_params) per residual
+    std::vector<double> pc(4 * (size_t)P);
+    for (uint32_t p = 0; p < P; ++p) {
+      if (poses_[p].cam_params.size() != 4) {
+        std::cerr << "ba::BundleAdjuster: use_per_pose_cam_params needs 4 pinhole parameters on every pose "
+                     "(AddPose with cam_params); pose " << p << " has " << poses_[p].cam_params.size() << std::endl;
+        summary_.result = SolverError;
+        return false;
+      }
+      for (int i = 0; i < 4; ++i) pc[4 * (size_t)p + i] = (double)poses_[p].cam_params[i];
+    }
+    if (!Check(ba_hip_set_pose_cam_params(engine_, P, pc.data()), "ba_hip_set_pose_cam_params")) return false;
+  } else if (!Check(ba_hip_set_pose_cam_params(engine_, 0, nullptr), "ba_hip_set_pose_cam_params")) {
+    return false;
+  }
   if (!Check(ba_hip_set_landmarks(engine_, L, lx.data(), lrp.data(), lrc.data(), la.data()), "ba_hip_set_landmarks")) return false;
   if (!Check(ba_hip_set_projection_residuals(engine_, (uint32_t)pr_pose_.size(), pr_z_.data(), pr_pose_.data(),
                                              pr_lm_.data(), pr_cam_.data(), pr_w_.data()),

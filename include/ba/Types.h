@@ -145,6 +145,9 @@ struct PoseT {
   int external_id = -1;
   uint32_t id = 0, opt_id = 0;
   double time = -1;
+  // camera intrinsics of this pose (reference Types.h:46), pinhole [fx, fy, u0, v0]; used instead
+  // of the rig camera's when Options::use_per_pose_cam_params is set
+  std::vector<Scalar> cam_params;
   // constraint counts (the reference keeps id lists; only emptiness is ever tested
   // outside the solver, BundleAdjuster.cpp:1252-1265)
   uint32_t num_proj_residuals = 0, num_inertial_residuals = 0, num_binary_residuals = 0,

@@ -63,6 +63,10 @@ void ba_adjuster_regularize_pose(ba_adjuster* a, uint32_t pose_id, int translati
                                  int bias, int rotation);
 void ba_adjuster_set_root_pose_id(ba_adjuster* a, uint32_t id);
 /* bulk adders = n single calls */
+/* Options::use_per_pose_cam_params + PoseT::cam_params (reference BundleAdjuster.h:96,292-323):
+ * pinhole [fx,fy,u0,v0] for every pose added so far (n must equal the number of poses) and the
+ * option switched on; n = 0 switches it off.  Returns 0 on success. */
+int ba_adjuster_set_pose_cam_params(ba_adjuster* a, uint32_t n, const double* params4);
 void ba_adjuster_add_poses(ba_adjuster* a, uint32_t n, const double* t_wp, const double* v_w,
                            const double* b, const uint8_t* is_active, const double* time);
 void ba_adjuster_add_landmarks(ba_adjuster* a, uint32_t n, const double* x_w,

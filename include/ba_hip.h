@@ -93,6 +93,12 @@ int ba_hip_set_options(ba_hip_engine* e, const ba_hip_options* o);
 /* ---- problem upload (replaces the AoS graph of Types.h:41-321) -------------------- */
 /* calibu::Rig cameras: pinhole params [fx,fy,u0,v0] and T_vs (BundleAdjuster.h:259-263) */
 int ba_hip_set_cameras(ba_hip_engine* e, uint32_t n, const double* params4, const double* t_vs7);
+/* Options::use_per_pose_cam_params (BundleAdjuster.h:96; parallel_algos.h:54-57,
+ * BundleAdjuster.cpp:162-176): every projection residual is evaluated with the pinhole
+ * intrinsics [fx,fy,u0,v0] of its MEASUREMENT pose (PoseT::cam_params, Types.h:46) instead of the
+ * rig camera's.  n = number of poses (checked at ba_hip_begin_solve), n = 0 switches back to the
+ * rig intrinsics.  May be called at any time before ba_hip_linearize; not part of the structure. */
+int ba_hip_set_pose_cam_params(ba_hip_engine* e, uint32_t n, const double* params4);
 /* poses_ (BundleAdjuster.h:292-323); v_w/b may be NULL (zeros) */
 int ba_hip_set_poses(ba_hip_engine* e, uint32_t n, const double* t_wp7, const double* v_w3,
                      const double* b6, const uint8_t* is_active);

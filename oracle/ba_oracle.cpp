@@ -52,6 +52,8 @@ struct Pose {  // Types.h:41-71
   bool is_param_mask_used = false, is_active = true;
   uint32_t id = 0, opt_id = 0;
   double time = -1;
+  double cam_params[4] = {0, 0, 0, 0};  // Types.h:46 (pinhole fx, fy, u0, v0); used with use_per_pose_cam_params
+  bool has_cam_params = false;
   std::vector<int> proj_residuals, inertial_residuals, binary_residuals,
       unary_residuals, landmarks;
   std::vector<SE3> t_sw;
@@ -228,6 +230,17 @@ struct orc_ba {
   uint32_t proj_residual_offset = 0, binary_residual_offset_ = 0,
            unary_residual_offset_ = 0, inertial_residual_offset_ = 0;
   bool is_param_mask_used_ = false;
+  bool use_per_pose_cam_params_ = false;  // Options::use_per_pose_cam_params (BundleAdjuster.h:96)
+  // parallel_algos.h:54-57, BundleAdjuster.cpp:162-165: the camera model takes the intrinsics of
+  // the MEASUREMENT pose for the duration of one residual (and is restored afterwards)
+  Pinhole cam_for(const ProjectionResidual& res) const {
+    Pinhole c = rig_[res.cam_id].model;
+    if (use_per_pose_cam_params_) {
+      const Pose& p = poses_[res.x_meas_id];
+      c.fx = p.cam_params[0]; c.fy = p.cam_params[1]; c.u0 = p.cam_params[2]; c.v0 = p.cam_params[3];
+    }
+    return c;
+  }
   double proj_error_ = 0, binary_error_ = 0, unary_error_ = 0, inertial_error_ = 0;
 
   Vec3 g_vec;     // imu_.g_vec
@@ -419,7 +432,7 @@ struct orc_ba {
     Landmark& lm = landmarks_[res.landmark_id];
     Pose& pose = poses_[res.x_meas_id];
     Pose& ref_pose = poses_[res.x_ref_id];
-    const Pinhole& cam = rig_[res.cam_id].model;
+    const Pinhole cam = cam_for(res);
     const SE3& t_vs_m = rig_[res.cam_id].t_vs;
     const SE3& t_vs_r = rig_[lm.ref_cam_id].t_vs;
     const SE3 t_sw_m = pose.GetTsw(res.cam_id, rig_);
@@ -1100,7 +1113,7 @@ struct orc_ba {
         Pose& ref_pose = poses_[res.x_ref_id];
         const SE3 t_sw_m = pose.GetTsw(res.cam_id, rig_);
         const SE3 t_ws_r = ref_pose.GetTsw(lm.ref_cam_id, rig_).inverse();
-        const Pinhole& cam = rig_[res.cam_id].model;
+        const Pinhole cam = cam_for(res);
         Vec3 xs3, xw3;
         for (int i = 0; i < 3; ++i) { xs3[i] = lm.x_s[i]; xw3[i] = lm.x_w[i]; }
         const Vec2 p = kLmDim == 3 ? cam.Transfer3d(t_sw_m, xw3, lm.x_w[3])
@@ -1460,6 +1473,18 @@ uint32_t orc_add_pose(orc_ba* h, const double t_wp[7], const double v_w[3], cons
   if (v_w) for (int i = 0; i < 3; ++i) v[i] = v_w[i];
   if (b) for (int i = 0; i < 6; ++i) bb[i] = b[i];
   return h->AddPose(se3_from7(t_wp), v, bb, is_active != 0, time);
+}
+void orc_set_pose_cam_params(orc_ba* h, uint32_t pose_id, const double params4[4]) {
+  if (pose_id >= h->poses_.size()) return;
+  for (int i = 0; i < 4; ++i) h->poses_[pose_id].cam_params[i] = params4[i];
+  h->poses_[pose_id].has_cam_params = true;
+}
+int orc_set_use_per_pose_cam_params(orc_ba* h, int on) {
+  if (on)
+    for (const auto& p : h->poses_)
+      if (!p.has_cam_params) return 1;  // the reference would SetParams an empty vector
+  h->use_per_pose_cam_params_ = on != 0;
+  return 0;
 }
 uint32_t orc_add_landmark(orc_ba* h, const double x_w[4], uint32_t ref_pose_id,
                           uint32_t ref_cam_id, int is_active) {

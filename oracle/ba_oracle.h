@@ -74,6 +74,12 @@ void orc_regularize_pose(orc_ba* h, uint32_t pose_id, int translation, int gravi
 void orc_set_root_pose_id(orc_ba* h, uint32_t id);
 
 /* bulk adders (same semantics as n single calls; ids returned in out_ids if non-null) */
+/* Options::use_per_pose_cam_params (BundleAdjuster.h:96, parallel_algos.h:54-57,
+ * BundleAdjuster.cpp:162-176): every projection residual is evaluated with the pinhole
+ * intrinsics stored on its MEASUREMENT pose (AddPose overload with cam_params, BundleAdjuster.h:292).
+ * orc_set_use_per_pose_cam_params returns 1 if a pose has no parameters. */
+void orc_set_pose_cam_params(orc_ba* h, uint32_t pose_id, const double params4[4]);
+int orc_set_use_per_pose_cam_params(orc_ba* h, int on);
 void orc_add_poses(orc_ba* h, uint32_t n, const double* t_wp, const double* v_w,
                    const double* b, const uint8_t* is_active, const double* time);
 void orc_add_landmarks(orc_ba* h, uint32_t n, const double* x_w, const uint32_t* ref_pose_id,

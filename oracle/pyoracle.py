@@ -139,6 +139,19 @@ class OracleBundleAdjuster:
         return self.L.orc_add_pose(self.h, _dp(t), _dp(v), _dp(bb), int(is_active),
                                    C.c_double(time))
 
+    def SetPoseCamParams(self, pose_cam_params):
+        """Per-pose pinhole intrinsics (P x 4: fx, fy, u0, v0), the `cam_params` argument of the
+        reference's AddPose overload (BundleAdjuster.h:292-323)."""
+        a = _d(pose_cam_params).reshape(-1, 4)
+        for i in range(a.shape[0]):
+            row = np.ascontiguousarray(a[i])
+            self.L.orc_set_pose_cam_params(self.h, i, _dp(row))
+
+    def SetUsePerPoseCamParams(self, on=True):
+        """Options::use_per_pose_cam_params (BundleAdjuster.h:96)."""
+        if self.L.orc_set_use_per_pose_cam_params(self.h, int(on)) != 0:
+            raise ValueError("use_per_pose_cam_params: a pose has no camera parameters")
+
     def AddLandmark(self, x_w, ref_pose_id, ref_cam_id=0, is_active=True):
         x = _d(x_w)
         return self.L.orc_add_landmark(self.h, _dp(x), int(ref_pose_id), int(ref_cam_id),

@@ -14,7 +14,7 @@ NORM_THRESHOLD = 1e-3
 EPS = 1e-6
 
 
-def _run(po, sc, lm_dim, poses, lms, pose_dim=6):
+def _run(po, sc, lm_dim, poses, lms, pose_dim=6, pose_cam=None):
     ba = po.OracleBundleAdjuster(lm_dim, pose_dim)
     o = po.default_options()
     o.use_dogleg = 0
@@ -25,8 +25,17 @@ def _run(po, sc, lm_dim, poses, lms, pose_dim=6):
     ba.add_poses(poses)
     ba.add_landmarks(lms, sc.lm_ref_pose)
     ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    if pose_cam is not None:  # Options::use_per_pose_cam_params
+        ba.SetPoseCamParams(pose_cam)
+        ba.SetUsePerPoseCamParams(True)
     ba.Solve(1)
     return ba
+
+
+def _pose_cams(sc):
+    """Distinct pinhole intrinsics for every pose (a few percent around the rig camera's)."""
+    rng = np.random.default_rng(11)
+    return np.asarray(sc.cam_params)[None, :] * (1.0 + 0.05 * rng.uniform(-1, 1, (sc.num_poses, 4)))
 
 
 def _move_lms(sc, p, t_new):
@@ -83,11 +92,16 @@ def test_exp_log_decoupled_roundtrip(oracle_lib):
         assert np.allclose(back[3:], rw, atol=1e-10)
 
 
-@pytest.mark.parametrize("lm_dim", [1, 3])
-def test_projection_pose_jacobians(oracle_lib, lm_dim):
+@pytest.mark.parametrize("lm_dim,per_pose_cam", [(1, False), (3, False), (1, True)])
+def test_projection_pose_jacobians(oracle_lib, lm_dim, per_pose_cam):
+    """per_pose_cam: Options::use_per_pose_cam_params — the measurement pose's own intrinsics
+    (parallel_algos.h:54-57) in the residual and in every Jacobian."""
     po = oracle_lib
     sc = scene.make_scene(24, 12, 4, lm_dim=lm_dim, seed=3)
-    ba = _run(po, sc, lm_dim, sc.poses, sc.landmarks)
+    pc = _pose_cams(sc) if per_pose_cam else None
+    ba = _run(po, sc, lm_dim, sc.poses, sc.landmarks, pose_cam=pc)
+    if per_pose_cam:  # the option changes the residuals
+        assert np.abs(ba.proj_residuals() - _run(po, sc, lm_dim, sc.poses, sc.landmarks).proj_residuals()).max() > 1.0
     jm, jr, _ = ba.proj_jacobians()
     acc = accepted_obs(sc)
     fd_m, fd_r = np.zeros_like(jm), np.zeros_like(jr)
@@ -100,8 +114,8 @@ def test_projection_pose_jacobians(oracle_lib, lm_dim):
             pp[p], pm[p] = tp, tm
             lp = _move_lms(sc, p, tp) if lm_dim == 1 else sc.landmarks
             ln = _move_lms(sc, p, tm) if lm_dim == 1 else sc.landmarks
-            fd = (_run(po, sc, lm_dim, pp, lp).proj_residuals() -
-                  _run(po, sc, lm_dim, pm, ln).proj_residuals()) / (2 * EPS)
+            fd = (_run(po, sc, lm_dim, pp, lp, pose_cam=pc).proj_residuals() -
+                  _run(po, sc, lm_dim, pm, ln, pose_cam=pc).proj_residuals()) / (2 * EPS)
             for rid, (m, r, _l) in enumerate(acc):
                 if m == p:
                     fd_m[rid, :, j] = fd[rid]
