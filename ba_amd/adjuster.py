@@ -62,7 +62,7 @@ SYMBOLS = [
     "ba_adjuster_solve", "ba_adjuster_num_poses", "ba_adjuster_num_landmarks",
     "ba_adjuster_num_proj_residuals", "ba_adjuster_get_poses", "ba_adjuster_get_landmarks",
     "ba_adjuster_is_landmark_reliable", "ba_adjuster_landmark_outlier_ratio",
-    "ba_adjuster_get_projection_residual",
+    "ba_adjuster_get_projection_residual", "ba_adjuster_get_imu_residual",
     "ba_adjuster_get_summary", "ba_adjuster_get_timers", "ba_adjuster_engine",
     "ba_adjuster_set_allreduce",
 ]
@@ -230,6 +230,14 @@ class BundleAdjuster:
         return {"z": o[0:2].copy(), "residual": o[2:4].copy(), "weight": o[4], "orig_weight": o[5],
                 "mahalanobis_distance": o[6], "x_meas_id": int(o[7]), "x_ref_id": int(o[8]),
                 "landmark_id": int(o[9]), "cam_id": int(o[10])}
+
+    def GetImuResidual(self, i):
+        """dict view of ba::ImuResidualT (reference BundleAdjuster.h:563-565)."""
+        o = np.empty(19)
+        self.L.ba_adjuster_get_imu_residual.restype = C.c_uint32
+        n = self.L.ba_adjuster_get_imu_residual(self.h, int(i), _p(o, dp))
+        return {"pose1_id": int(o[0]), "pose2_id": int(o[1]), "weight": o[2], "num_measurements": int(n),
+                "residual": o[4:19].copy()}
 
     # -- bulk adders -----------------------------------------------------------------
     def add_poses(self, t_wp, v_w=None, b=None, is_active=None, time=None):

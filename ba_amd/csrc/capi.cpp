@@ -30,6 +30,7 @@ struct Iface {
   virtual int reliable(uint32_t id) const = 0;
   virtual double outlier_ratio(uint32_t id) const = 0;
   virtual void proj_residual(uint32_t id, double* out11) const = 0;
+  virtual uint32_t imu_residual(uint32_t id, double* out19) const = 0;
   virtual void summary(ba_summary* s) = 0;
   virtual void timers(ba_hip_timers* t) const = 0;
   virtual ba_hip_engine* engine() = 0;
@@ -126,6 +127,13 @@ struct Impl : Iface {
   }
   int reliable(uint32_t id) const override { return ba.IsLandmarkReliable(id) ? 1 : 0; }
   double outlier_ratio(uint32_t id) const override { return ba.LandmarkOutlierRatio(id); }
+  uint32_t imu_residual(uint32_t id, double* o) const override {
+    if (id >= ba.GetNumImuResiduals()) return 0;
+    const auto& r = ba.GetImuResidual(id);
+    o[0] = r.pose1_id; o[1] = r.pose2_id; o[2] = r.weight; o[3] = (double)r.measurements.size();
+    for (int i = 0; i < 15; ++i) o[4 + i] = r.residual[i];
+    return (uint32_t)r.measurements.size();
+  }
   void proj_residual(uint32_t id, double* o) const override {
     const typename BA::ProjectionResidual& r = ba.GetProjectionResidual(id);
     o[0] = r.z[0]; o[1] = r.z[1]; o[2] = r.residual[0]; o[3] = r.residual[1];
@@ -240,6 +248,7 @@ void ba_adjuster_get_landmarks(const ba_adjuster* a, double* x_w) { a->p->get_la
 int ba_adjuster_is_landmark_reliable(const ba_adjuster* a, uint32_t id) { return a->p->reliable(id); }
 double ba_adjuster_landmark_outlier_ratio(const ba_adjuster* a, uint32_t id) { return a->p->outlier_ratio(id); }
 void ba_adjuster_get_projection_residual(const ba_adjuster* a, uint32_t id, double* out11) { a->p->proj_residual(id, out11); }
+uint32_t ba_adjuster_get_imu_residual(const ba_adjuster* a, uint32_t id, double* out19) { return a->p->imu_residual(id, out19); }
 void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s) { a->p->summary(s); }
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t) { a->p->timers(t); }
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a) { return a->p->engine(); }

@@ -224,6 +224,7 @@ int factor_tile_pattern(Engine* e);
 uint32_t choose_kout(uint32_t nblk);
 bool dist_solve_enabled(const Engine* e);
 int dist_reduce_scatter_S(Engine* e);
+int launch_imu_residual_vectors(Engine* e, double* d_r15);
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz);
 
 }  // namespace bae

@@ -1159,6 +1159,22 @@ int ba_hip_get_proj_residuals(ba_hip_engine* h, double* residual2) {
   return 0;
 }
 
+int ba_hip_get_imu_residuals(ba_hip_engine* h, double* residual15) {
+  ENG(h);
+  NEED_FINAL();
+  const uint32_t ni = e->prob.num_imu;
+  if (ni == 0) return 0;
+  BAE_HIP(hipSetDevice(e->device));
+  DBuf<double> d;
+  BAE_HIP(d.alloc((size_t)15 * ni));
+  int rc = launch_imu_residual_vectors(e, d.p);
+  if (rc) { d.release(); return rc; }
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  BAE_HIP(hipMemcpy(residual15, d.p, (size_t)15 * ni * sizeof(double), hipMemcpyDeviceToHost));
+  d.release();
+  return 0;
+}
+
 int ba_hip_get_unary_scales(ba_hip_engine* h, double* scale) {
   ENG(h);
   NEED_FINAL();

@@ -120,7 +120,8 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
       const double* __restrict__ noise /* r6 | rb6 */, const uint8_t* __restrict__ pose_active,
       const double* __restrict__ state, double* __restrict__ cov_inv_store,
       double* __restrict__ pp_h, double* __restrict__ pp_g, double* __restrict__ pp_dz,
-      double* __restrict__ pp_info, uint32_t slot0, double* __restrict__ out_err) {
+      double* __restrict__ pp_info, uint32_t slot0, double* __restrict__ out_err,
+      double* __restrict__ res_out /* mode 2, optional: the residual vectors, 15 per residual */) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double* s1 = state + (size_t)p1[i] * kPoseState;
@@ -132,6 +133,8 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
   double* cst = cov_inv_store + (size_t)i * kPPH;
   if (mode == 2) {
     imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, false, &io);
+    if (res_out)
+      for (int r = 0; r < 15; ++r) res_out[(size_t)i * 15 + r] = io.r[r];
     double e = 0.0;
     for (int r = 0; r < 15; ++r) {
       double q = 0.0;
@@ -317,7 +320,7 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
                        e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
                        e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                        e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
-                       e->pp_info.p, nu + nb, e->pp_err.p + nu + nb);
+                       e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr);
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
@@ -356,7 +359,7 @@ int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
     hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 2, e->pose_dim, 0,
                        0.0, e->imu_p1.p, e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p,
                        e->imu_consts.p + 3, e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p,
-                       e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb);
+                       e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr);
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
@@ -376,6 +379,21 @@ int launch_posepose_jrhs(Engine* e, double* out) {
     BAE_HIP(hipGetLastError());
   }
   return sum_small(e, nres, e->pp_err.p, out);
+}
+
+// The residual vectors of the inertial residuals at the current state (what ImuResidual::residual
+// holds after EvaluateResiduals, BundleAdjuster.cpp:225-256), 15 doubles each (the first
+// PoseSize are used), into the device buffer d_r15.
+int launch_imu_residual_vectors(Engine* e, double* d_r15) {
+  const Problem& pb = e->prob;
+  const uint32_t nu = pb.num_unary, nb = pb.num_binary, ni = pb.num_imu;
+  if (ni == 0) return 0;
+  hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 2, e->pose_dim, 0, 0.0,
+                     e->imu_p1.p, e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
+                     e->pose_active.p, (const double*)e->pose_state[e->cur].p, e->imu_cov_inv.p, e->pp_h.p,
+                     e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, d_r15);
+  BAE_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace bae

@@ -109,6 +109,7 @@ class BundleAdjuster {
   typedef LandmarkT<Scalar, LmSize> Landmark;
   typedef ProjectionResidualT<Scalar, LmSize> ProjectionResidual;
   typedef ImuMeasurementT<Scalar> ImuMeasurement;
+  typedef ImuResidualT<Scalar, kPoseDim, kPoseDim> ImuResidual;  // reference :142
   typedef ImuCalibrationT<Scalar> ImuCalibration;
   typedef ba::Vector2t Vector2t;
   typedef ba::Vector3t Vector3t;
@@ -145,7 +146,7 @@ class BundleAdjuster {
     poses_.clear(); landmarks_.clear();
     poses_.reserve(std::max(1u, num_poses)); landmarks_.reserve(std::max(1u, num_landmarks));
     pr_z_.clear(); pr_pose_.clear(); pr_lm_.clear(); pr_cam_.clear(); pr_w_.clear();
-    proj_view_dirty_ = true; uploaded_once_ = false;
+    proj_view_dirty_ = true; imu_view_dirty_ = true; uploaded_once_ = false;
     pr_z_.reserve(2 * (size_t)std::max(1u, num_measurements));
     un_pose_.clear(); un_t_.clear(); un_cov_inv_.clear(); un_rot_.clear();
     bin_p1_.clear(); bin_p2_.clear(); bin_t_.clear(); bin_cov_inv_.clear(); bin_cov_inv_sqrt_.clear();
@@ -313,6 +314,30 @@ class BundleAdjuster {
   uint32_t GetNumProjResiduals() const { return (uint32_t)pr_pose_.size(); }
   // reference :568-571.  The residual vectors and Huber weights are fetched from the device on
   // the first call after a Solve() (one copy of 3 doubles per residual), then served from the host.
+  // reference :563-565.  The view is rebuilt on every call (valid until the next one); `residual` is
+  // read back from the device after a Solve() (ba_hip_get_imu_residuals), zero before.
+  const ImuResidual& GetImuResidual(const uint32_t id) const {
+    assert(id < imu_p1_.size());
+    if (imu_view_dirty_ && engine_ && !imu_p1_.empty() && uploaded_once_ && !structure_dirty_) {
+      imu_view_r_.assign(15 * imu_p1_.size(), 0.0);
+      if (ba_hip_get_imu_residuals(engine_, imu_view_r_.data()) == 0) imu_view_dirty_ = false;
+    }
+    ImuResidual& r = imu_view_;
+    r.residual_id = id;
+    r.residual_offset = id * ImuResidual::kResSize;
+    r.pose1_id = imu_p1_[id]; r.pose2_id = imu_p2_[id];
+    r.orig_weight = r.weight = imu_w_[id];
+    r.measurements.clear();
+    for (uint32_t m = imu_ptr_[id]; m < imu_ptr_[id + 1]; ++m) {
+      ImuMeasurement meas;
+      for (int i = 0; i < 3; ++i) { meas.w[i] = imu_meas_[7 * (size_t)m + i]; meas.a[i] = imu_meas_[7 * (size_t)m + 3 + i]; }
+      meas.time = imu_meas_[7 * (size_t)m + 6];
+      r.measurements.push_back(meas);
+    }
+    const bool have = !imu_view_dirty_ && !structure_dirty_ && imu_view_r_.size() == 15 * imu_p1_.size();
+    for (int i = 0; i < 15; ++i) r.residual[i] = have ? (Scalar)imu_view_r_[15 * (size_t)id + i] : (Scalar)0;
+    return r;
+  }
   const ProjectionResidual& GetProjectionResidual(uint32_t id) const {
     if (proj_view_dirty_ && engine_ && !pr_pose_.empty() && uploaded_once_ && !structure_dirty_) {
       proj_view_r_.assign(2 * pr_pose_.size(), 0.0);
@@ -434,6 +459,9 @@ class BundleAdjuster {
   mutable std::vector<double> proj_view_r_, proj_view_w_;  // GetProjectionResidual cache
   mutable ProjectionResidual proj_view_;
   mutable bool proj_view_dirty_ = true;
+  mutable std::vector<double> imu_view_r_;  // GetImuResidual cache
+  mutable ImuResidual imu_view_;
+  mutable bool imu_view_dirty_ = true;
   bool uploaded_once_ = false;
   std::vector<uint32_t> pr_pose_, pr_lm_, pr_cam_;
   std::vector<uint32_t> un_pose_; std::vector<double> un_t_, un_cov_inv_; std::vector<uint8_t> un_rot_;
@@ -802,6 +830,7 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
   if (!DownloadState()) return;
   uploaded_once_ = true;
   proj_view_dirty_ = true;  // GetProjectionResidual re-reads the device on its next call
+  imu_view_dirty_ = true;
   if (!un_pose_.empty()) {
     // the reference scales each unary cov_inv in place every BuildProblem
     // (BundleAdjuster.cpp:1469), so the compounded weights survive across Solve() calls

@@ -178,6 +178,22 @@ struct ProjectionResidualT {
   bool is_conditioning = false;
 };
 
+// reference Types.h:300-321, the host-visible part (the Jacobian / covariance blocks dz_dx1, dz_dx2,
+// cov_inv ... and the integrated trajectory `poses` live only on the device)
+template <typename Scalar = double, int ResidualSize = 15, int PoseSize = 15>
+struct ImuResidualT {
+  typedef ImuMeasurementT<Scalar> ImuMeasurement;
+  static const uint32_t kResSize = ResidualSize;
+  uint32_t residual_id = 0, residual_offset = 0;
+  uint32_t pose1_id = 0, pose2_id = 0;
+  Scalar mahalanobis_distance = 0;
+  Scalar weight = 1, orig_weight = 1;
+  std::vector<ImuMeasurement> measurements;
+  // residual at the state the last Solve() left behind: translation, rotation, velocity
+  // [, gyro bias, accelerometer bias] (Types.h:654-689); the first kResSize entries are used
+  Scalar residual[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+
 // reference Types.h:112-159 (fields used on the hot path)
 template <typename Scalar = double>
 struct ImuCalibrationT {

@@ -87,6 +87,9 @@ double ba_adjuster_landmark_outlier_ratio(const ba_adjuster* a, uint32_t id);
 /* GetProjectionResidual(id): out11 = z(2), residual(2), weight, orig_weight, mahalanobis_distance,
  * x_meas_id, x_ref_id, landmark_id, cam_id */
 void ba_adjuster_get_projection_residual(const ba_adjuster* a, uint32_t id, double* out11);
+/* GetImuResidual(id): out19 = pose1_id, pose2_id, weight, number of measurements, residual(15: the
+ * first PoseSize entries are used); returns the number of measurements (0 for a bad id) */
+uint32_t ba_adjuster_get_imu_residual(const ba_adjuster* a, uint32_t id, double* out19);
 void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s);
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
 /* the engine behind the adjuster (valid after the first Solve) for the debug taps of ba_hip.h */

@@ -176,6 +176,10 @@ int ba_hip_get_proj_weights(ba_hip_engine* e, double* weight); /* per residual i
  * ProjectionResidual::residual holds after a Solve() (BundleAdjuster.cpp:155-181) */
 int ba_hip_get_proj_residuals(ba_hip_engine* e, double* residual2);
 int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
+/* Residual vectors of the inertial residuals at the current state (ImuResidualT::residual after
+ * EvaluateResiduals, BundleAdjuster.cpp:225-256): 15 doubles per residual in residual-id order,
+ * the first PoseSize of them used (9: translation, rotation, velocity; 15: + biases). */
+int ba_hip_get_imu_residuals(ba_hip_engine* e, double* residual15);
 /* cumulative Huber scale of every unary residual's cov^-1 (the reference multiplies
  * cov_inv in place every BuildProblem, BundleAdjuster.cpp:1469) */
 int ba_hip_get_unary_scales(ba_hip_engine* e, double* scale);

@@ -1602,6 +1602,11 @@ void orc_get_proj_residuals(const orc_ba* h, double* r2) {
     r2[2 * i + 1] = h->proj_residuals_[i].residual[1];
   }
 }
+void orc_get_imu_residuals(const orc_ba* h, double* r15) {
+  for (size_t i = 0; i < h->inertial_residuals_.size(); ++i)
+    for (int k = 0; k < 15; ++k) r15[15 * i + k] = h->inertial_residuals_[i].residual[k];
+}
+uint32_t orc_num_imu_residuals(const orc_ba* h) { return (uint32_t)h->inertial_residuals_.size(); }
 void orc_get_proj_jacobians(const orc_ba* h, double* j_meas, double* j_ref, double* j_lm) {
   const int L = h->kLmDim;
   for (size_t i = 0; i < h->proj_residuals_.size(); ++i) {

@@ -116,6 +116,8 @@ void orc_get_delta_p(const orc_ba* h, double* d);        /* applied pose step */
 void orc_get_delta_l(const orc_ba* h, double* d);
 void orc_get_proj_weights(const orc_ba* h, double* w);   /* per residual id */
 void orc_get_proj_residuals(const orc_ba* h, double* r2);/* per residual id, 2 each */
+void orc_get_imu_residuals(const orc_ba* h, double* r15);/* ImuResidualT::residual, 15 each (first PoseSize used) */
+uint32_t orc_num_imu_residuals(const orc_ba* h);
 /* per-residual Jacobians of the last BuildProblem (dz_dx_meas 2x6, dz_dx_ref 2x6,
    dz_dlm 2xLm), row-major, unmasked/unweighted as stored in the residual. */
 void orc_get_proj_jacobians(const orc_ba* h, double* j_meas, double* j_ref, double* j_lm);

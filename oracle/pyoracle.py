@@ -302,6 +302,11 @@ class OracleBundleAdjuster:
     def proj_residuals(self):
         return self._vec(self.L.orc_get_proj_residuals, 2 * self.GetNumProjResiduals()).reshape(-1, 2)
 
+    def imu_residuals(self):
+        self.L.orc_num_imu_residuals.restype = C.c_uint32
+        n = self.L.orc_num_imu_residuals(self.h)
+        return self._vec(self.L.orc_get_imu_residuals, 15 * n).reshape(-1, 15)
+
     def proj_jacobians(self):
         n = self.GetNumProjResiduals()
         jm, jr = np.zeros((n, 2, 6)), np.zeros((n, 2, 6))

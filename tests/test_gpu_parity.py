@@ -946,3 +946,37 @@ def test_per_pose_camera_parameters(oracle_lib, lm_dim):
     o.Solve(1)
     h.Solve(1)
     assert abs(h.summary().proj_error - o.summary().proj_error) < 1e-8 * o.summary().proj_error
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pose_dim", [9, 15])
+def test_get_imu_residual(oracle_lib, pose_dim):
+    """GetImuResidual(id) (reference BundleAdjuster.h:563-565): pose ids, measurements and weight
+    from the host graph, the residual vector (Types.h:654-689) read back from the device after an
+    accepted step — against the oracle's ImuResidualT::residual."""
+    po = oracle_lib
+    P = 14
+    sc = scene.make_scene(P, 60, 5, lm_dim=1, seed=53)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po)), (adjuster.BundleAdjuster, hip_options())):
+        b = cls(1, pose_dim)
+        b.Init(opts)
+        b.SetGravity(sc.gravity)
+        fill(b, sc)
+        for i in range(P - 1):
+            b.AddImuResidual(i, i + 1, sc.imu_meas[i], 1.0 + 0.5 * (i % 3))
+        objs.append(b)
+    o, h = objs
+    before = h.GetImuResidual(3)
+    assert before["pose1_id"] == 3 and before["pose2_id"] == 4 and before["weight"] == 1.0
+    assert before["num_measurements"] == len(sc.imu_meas[3]) and not before["residual"].any()
+    o.Solve(1)
+    h.Solve(1)
+    assert o.summary().result == h.summary().result == 0
+    ro = o.imu_residuals()
+    assert np.abs(ro[:, :pose_dim]).max() > 1e-6
+    for i in range(P - 1):
+        r = h.GetImuResidual(i)
+        assert r["pose1_id"] == i and r["pose2_id"] == i + 1 and r["weight"] == 1.0 + 0.5 * (i % 3)
+        assert np.abs(r["residual"][:pose_dim] - ro[i, :pose_dim]).max() < 1e-7 * max(1.0, np.abs(ro[i, :pose_dim]).max())
