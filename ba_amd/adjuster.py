@@ -57,7 +57,7 @@ SYMBOLS = [
     "ba_adjuster_add_landmark", "ba_adjuster_add_projection_residual",
     "ba_adjuster_add_unary_constraint", "ba_adjuster_add_binary_constraint",
     "ba_adjuster_add_imu_residual", "ba_adjuster_regularize_pose", "ba_adjuster_set_root_pose_id",
-    "ba_adjuster_set_pose_cam_params",
+    "ba_adjuster_set_pose_cam_params", "ba_adjuster_set_calculate_inertial_covariance_once",
     "ba_adjuster_add_poses", "ba_adjuster_add_landmarks", "ba_adjuster_add_projection_residuals",
     "ba_adjuster_solve", "ba_adjuster_num_poses", "ba_adjuster_num_landmarks",
     "ba_adjuster_num_proj_residuals", "ba_adjuster_get_poses", "ba_adjuster_get_landmarks",
@@ -164,6 +164,10 @@ class BundleAdjuster:
             rc = self.L.ba_adjuster_set_pose_cam_params(self.h, a.shape[0], _p(a, dp))
         if rc != 0:
             raise ValueError("SetPoseCamParams: one [fx, fy, u0, v0] per pose expected")
+
+    def SetCalculateInertialCovarianceOnce(self, on=True):
+        """Options::calculate_inertial_covariance_once (reference BundleAdjuster.h:106)."""
+        self.L.ba_adjuster_set_calculate_inertial_covariance_once(self.h, int(on))
 
     def SetUsePerPoseCamParams(self, on=True):
         if not on:

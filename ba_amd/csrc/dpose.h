@@ -531,9 +531,13 @@ struct ImuOut {
   double r[15];
   DM<15, 15> dz1, dz2, cov_inv;
 };
+// frozen_in / frozen_out (Options::calculate_inertial_covariance_once, parallel_algos.h:189-205):
+// 160 doubles = the integration covariance (10x10) and the bias Jacobian of the integration
+// (10x6).  frozen_in: integrate without Jacobians and take both from there; frozen_out: store
+// what this call computed.
 BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, int nmeas,
                         const double* g, const double* r6, const double* rb6, int RS, bool jac,
-                        ImuOut* o) {
+                        ImuOut* o, const double* frozen_in = nullptr, double* frozen_out = nullptr) {
   ImuState s;
   for (int i = 0; i < 3; ++i) { s.t[i] = p1[i]; s.v[i] = p1[7 + i]; }
   for (int i = 0; i < 4; ++i) s.q[i] = p1[3 + i];
@@ -543,9 +547,18 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
   DM<10, 10> dy_dy, cov;
   dpose_db.zero();
   cov.zero();
+  const bool ijac = jac && !frozen_in;
   for (int i = 1; i < nmeas; ++i) {
-    s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, jac, &dy_db, &dy_dy, &cov, r6);
-    if (jac) dpose_db = madd(dy_db, mm(dy_dy, dpose_db));  // Types.h:712-714
+    s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, ijac, &dy_db, &dy_dy, &cov, r6);
+    if (ijac) dpose_db = madd(dy_db, mm(dy_dy, dpose_db));  // Types.h:712-714
+  }
+  if (jac && frozen_in) {
+    for (int k = 0; k < 100; ++k) cov.m[k] = frozen_in[k];
+    for (int k = 0; k < 60; ++k) dpose_db.m[k] = frozen_in[100 + k];
+  }
+  if (jac && frozen_out) {
+    for (int k = 0; k < 100; ++k) frozen_out[k] = cov.m[k];
+    for (int k = 0; k < 60; ++k) frozen_out[100 + k] = dpose_db.m[k];
   }
   const Tq t_int = {{s.t[0], s.t[1], s.t[2]}, {s.q[0], s.q[1], s.q[2], s.q[3]}};
   const Tq t_w1 = tq_from7(p1), t_w2 = tq_from7(p2);

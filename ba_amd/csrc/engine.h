@@ -144,6 +144,12 @@ struct Engine {
   DBuf<uint32_t> bin_p1, bin_p2; DBuf<double> bin_t, bin_cov_inv, bin_cov_inv_sqrt, bin_w;
   DBuf<uint8_t> bin_rot;
   DBuf<uint32_t> imu_p1, imu_p2, imu_ptr; DBuf<double> imu_meas, imu_consts, imu_cov_inv;
+  // Options::calculate_inertial_covariance_once: per residual 10x10 integration covariance + 10x6
+  // bias Jacobian of its first linearisation, and a "done" flag
+  bool imu_cov_once = false;
+  DBuf<double> imu_frozen;
+  DBuf<uint8_t> imu_cov_done;
+  uint32_t imu_cov_count = 0;
   DBuf<double> pp_h, pp_g, pp_dz, pp_info, pp_err;
   DBuf<uint32_t> pp_ptr, pp_res_p1, pp_res_p2;
   DBuf<uint4> pp_ent;

@@ -644,7 +644,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(cam); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
   REL(obs_jrow_m); REL(obs_jrow_r); REL(obs_wrow_m); REL(obs_first); REL(lm_wrow_r);
-  REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent);
+  REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent); REL(imu_frozen); REL(imu_cov_done); REL(pose_cam);
   REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
@@ -791,6 +791,13 @@ int ba_hip_set_imu_residuals(ba_hip_engine* h, uint32_t n, const uint32_t* pose1
   if (weight) pb.imu_w.assign(weight, weight + n);
   else pb.imu_w.assign(n, 1.0);
   e->finalized = false;
+  return 0;
+}
+
+int ba_hip_set_inertial_covariance_once(ba_hip_engine* h, int on, int reset) {
+  ENG(h);
+  e->imu_cov_once = on != 0;
+  if (reset || !on) e->imu_cov_count = 0;
   return 0;
 }
 

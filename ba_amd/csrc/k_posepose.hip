@@ -121,7 +121,8 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
       const double* __restrict__ state, double* __restrict__ cov_inv_store,
       double* __restrict__ pp_h, double* __restrict__ pp_g, double* __restrict__ pp_dz,
       double* __restrict__ pp_info, uint32_t slot0, double* __restrict__ out_err,
-      double* __restrict__ res_out /* mode 2, optional: the residual vectors, 15 per residual */) {
+      double* __restrict__ res_out /* mode 2, optional: the residual vectors, 15 per residual */,
+      int cov_once, double* __restrict__ frozen, uint8_t* __restrict__ cov_done) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double* s1 = state + (size_t)p1[i] * kPoseState;
@@ -144,7 +145,16 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     out_err[i] = e;
     return;
   }
-  imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io);
+  if (cov_once) {
+    // calculate_inertial_covariance_once: the first linearisation of a residual freezes its
+    // integration covariance and bias Jacobian
+    double* fz = frozen + (size_t)i * 160;
+    if (cov_done[i]) imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, fz, nullptr);
+    else imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, nullptr, fz);
+    cov_done[i] = 1;
+  } else {
+    imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io);
+  }
   double w = 1.0;
   if (use_robust) {
     double md = 0.0;
@@ -315,12 +325,34 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, nb, e->pp_err.p + nu, &errs->binary_error))) return rc;
+  if (ni && e->imu_cov_once) {
+    // frozen integration covariances survive re-uploads of the same (append-only) residual list
+    if (ni < e->imu_cov_count) e->imu_cov_count = 0;  // the list was rebuilt: forget everything
+    if (e->imu_cov_done.n < ni) {
+      DBuf<double> fz; DBuf<uint8_t> dn;
+      BAE_HIP(fz.alloc((size_t)ni * 160));
+      BAE_HIP(dn.alloc(ni));
+      BAE_HIP(hipMemsetAsync(dn.p, 0, ni, e->stream));
+      if (e->imu_cov_count) {
+        BAE_HIP(hipMemcpyAsync(fz.p, e->imu_frozen.p, (size_t)e->imu_cov_count * 160 * sizeof(double),
+                               hipMemcpyDeviceToDevice, e->stream));
+        BAE_HIP(hipMemcpyAsync(dn.p, e->imu_cov_done.p, e->imu_cov_count, hipMemcpyDeviceToDevice, e->stream));
+      }
+      BAE_HIP(hipStreamSynchronize(e->stream));
+      e->imu_frozen.release(); e->imu_cov_done.release();
+      e->imu_frozen = fz; e->imu_cov_done = dn;
+    } else if (e->imu_cov_count == 0) {
+      BAE_HIP(hipMemsetAsync(e->imu_cov_done.p, 0, e->imu_cov_done.n, e->stream));
+    }
+    e->imu_cov_count = ni;
+  }
   if (ni) {
     hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 1, e->pose_dim,
                        e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
                        e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                        e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
-                       e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr);
+                       e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
+                       e->imu_frozen.p, e->imu_cov_done.p);
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
@@ -359,7 +391,8 @@ int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
     hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 2, e->pose_dim, 0,
                        0.0, e->imu_p1.p, e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p,
                        e->imu_consts.p + 3, e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p,
-                       e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr);
+                       e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, 0,
+                       (double*)nullptr, (uint8_t*)nullptr);
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
@@ -391,7 +424,8 @@ int launch_imu_residual_vectors(Engine* e, double* d_r15) {
   hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 2, e->pose_dim, 0, 0.0,
                      e->imu_p1.p, e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                      e->pose_active.p, (const double*)e->pose_state[e->cur].p, e->imu_cov_inv.p, e->pp_h.p,
-                     e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, d_r15);
+                     e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, d_r15, 0, (double*)nullptr,
+                     (uint8_t*)nullptr);
   BAE_HIP(hipGetLastError());
   return 0;
 }

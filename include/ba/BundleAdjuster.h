@@ -147,6 +147,7 @@ class BundleAdjuster {
     poses_.reserve(std::max(1u, num_poses)); landmarks_.reserve(std::max(1u, num_landmarks));
     pr_z_.clear(); pr_pose_.clear(); pr_lm_.clear(); pr_cam_.clear(); pr_w_.clear();
     proj_view_dirty_ = true; imu_view_dirty_ = true; uploaded_once_ = false;
+    imu_cov_reset_ = true;  // a new problem: forget the frozen inertial covariances
     pr_z_.reserve(2 * (size_t)std::max(1u, num_measurements));
     un_pose_.clear(); un_t_.clear(); un_cov_inv_.clear(); un_rot_.clear();
     bin_p1_.clear(); bin_p2_.clear(); bin_t_.clear(); bin_cov_inv_.clear(); bin_cov_inv_sqrt_.clear();
@@ -462,6 +463,7 @@ class BundleAdjuster {
   mutable std::vector<double> imu_view_r_;  // GetImuResidual cache
   mutable ImuResidual imu_view_;
   mutable bool imu_view_dirty_ = true;
+  bool imu_cov_reset_ = true;  // calculate_inertial_covariance_once: next upload starts afresh
   bool uploaded_once_ = false;
   std::vector<uint32_t> pr_pose_, pr_lm_, pr_cam_;
   std::vector<uint32_t> un_pose_; std::vector<double> un_t_, un_cov_inv_; std::vector<uint8_t> un_rot_;
@@ -574,6 +576,12 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   if (!Check(ba_hip_set_imu_residuals(engine_, (uint32_t)imu_p1_.size(), imu_p1_.data(), imu_p2_.data(),
                                       imu_ptr_.data(), imu_meas_.data(), imu_w_.data()),
              "ba_hip_set_imu_residuals")) return false;
+  // reference parallel_algos.h:189-205 (ImuResidualT::covariance_computed lives with the residual:
+  // it survives Solve() calls until the problem is rebuilt by Init())
+  if (!Check(ba_hip_set_inertial_covariance_once(engine_, options_.calculate_inertial_covariance_once ? 1 : 0,
+                                                 imu_cov_reset_ ? 1 : 0),
+             "ba_hip_set_inertial_covariance_once")) return false;
+  imu_cov_reset_ = false;
   const double g[3] = {imu_.g_vec[0], imu_.g_vec[1], imu_.g_vec[2]};
   if (!Check(ba_hip_set_gravity(engine_, g), "ba_hip_set_gravity")) return false;
   if (!Check(ba_hip_finalize(engine_), "ba_hip_finalize")) return false;

@@ -67,6 +67,8 @@ void ba_adjuster_set_root_pose_id(ba_adjuster* a, uint32_t id);
  * pinhole [fx,fy,u0,v0] for every pose added so far (n must equal the number of poses) and the
  * option switched on; n = 0 switches it off.  Returns 0 on success. */
 int ba_adjuster_set_pose_cam_params(ba_adjuster* a, uint32_t n, const double* params4);
+/* Options::calculate_inertial_covariance_once (reference BundleAdjuster.h:106); call after init */
+void ba_adjuster_set_calculate_inertial_covariance_once(ba_adjuster* a, int on);
 void ba_adjuster_add_poses(ba_adjuster* a, uint32_t n, const double* t_wp, const double* v_w,
                            const double* b, const uint8_t* is_active, const double* time);
 void ba_adjuster_add_landmarks(ba_adjuster* a, uint32_t n, const double* x_w,

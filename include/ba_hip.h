@@ -125,6 +125,11 @@ int ba_hip_set_binary_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* po
 int ba_hip_set_imu_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose1_id,
                              const uint32_t* pose2_id, const uint32_t* meas_ptr /* n+1 */,
                              const double* meas7, const double* weight);
+/* Options::calculate_inertial_covariance_once (BundleAdjuster.h:106, parallel_algos.h:189-205):
+ * the integration covariance and the bias Jacobian of an inertial residual are computed in its
+ * first linearisation and reused afterwards (they survive later ba_hip_set_imu_residuals calls
+ * as long as the residual list only grows).  reset != 0 forgets the stored ones (Init()). */
+int ba_hip_set_inertial_covariance_once(ba_hip_engine* e, int on, int reset);
 int ba_hip_set_gravity(ba_hip_engine* e, const double g3[3]); /* BundleAdjuster.h:243-252 */
 /* Build the device-side structure: observation list sorted by landmark (CSR),
  * pose-landmark incidences, per-pose-pair gather lists for the reduced matrix. */

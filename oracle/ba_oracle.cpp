@@ -107,6 +107,7 @@ struct ImuResidual {  // Types.h:300-321 (kResSize = PoseSize; 15x15 storage)
   Vec15 residual;
   Mat<10, 6> dintegration_db;
   Mat<10, 10> c_integration;
+  bool covariance_computed = false;  // Types.h:321
   double mahalanobis_distance = 0, weight = 1, orig_weight = 1;
 };
 
@@ -231,6 +232,7 @@ struct orc_ba {
            unary_residual_offset_ = 0, inertial_residual_offset_ = 0;
   bool is_param_mask_used_ = false;
   bool use_per_pose_cam_params_ = false;  // Options::use_per_pose_cam_params (BundleAdjuster.h:96)
+  bool calculate_inertial_covariance_once_ = false;  // Options::calculate_inertial_covariance_once (:106)
   // parallel_algos.h:54-57, BundleAdjuster.cpp:162-165: the camera model takes the intrinsics of
   // the MEASUREMENT pose for the duration of one residual (and is restored afterwards)
   Pinhole cam_for(const ProjectionResidual& res) const {
@@ -491,13 +493,18 @@ struct orc_ba {
     const Vec3 gravity = g_vec;
     const Pose& pose1 = poses_[res.pose1_id];
     const Pose& pose2 = poses_[res.pose2_id];
-    res.c_integration = Mat<10, 10>::Zero();
+    // parallel_algos.h:189-205: with Options::calculate_inertial_covariance_once the integration
+    // covariance and the bias Jacobian of the FIRST linearisation of this residual are kept
+    const bool compute_covariance = !calculate_inertial_covariance_once_ || !res.covariance_computed;
+    if (compute_covariance) res.c_integration = Mat<10, 10>::Zero();
     ImuPose start; start.t_wp = pose1.t_wp; start.v_w = pose1.v_w; start.time = pose1.time;
     Vec3 bg, ba;
     for (int i = 0; i < 3; ++i) { bg[i] = pose1.b[i]; ba[i] = pose1.b[3 + i]; }
     const ImuPose imu_pose = IntegrateResidual(start, res.measurements, bg, ba, gravity,
-                                               &res.dintegration_db, nullptr,
-                                               &res.c_integration, &imu_r);
+                                               compute_covariance ? &res.dintegration_db : nullptr, nullptr,
+                                               compute_covariance ? &res.c_integration : nullptr,
+                                               compute_covariance ? &imu_r : nullptr);
+    res.covariance_computed = true;
     const double total_dt = res.measurements.back().time - res.measurements.front().time;
     const SE3& t_w1 = pose1.t_wp;
     const SE3& t_w2 = pose2.t_wp;
@@ -1479,6 +1486,7 @@ void orc_set_pose_cam_params(orc_ba* h, uint32_t pose_id, const double params4[4
   for (int i = 0; i < 4; ++i) h->poses_[pose_id].cam_params[i] = params4[i];
   h->poses_[pose_id].has_cam_params = true;
 }
+void orc_set_calculate_inertial_covariance_once(orc_ba* h, int on) { h->calculate_inertial_covariance_once_ = on != 0; }
 int orc_set_use_per_pose_cam_params(orc_ba* h, int on) {
   if (on)
     for (const auto& p : h->poses_)

@@ -78,6 +78,8 @@ void orc_set_root_pose_id(orc_ba* h, uint32_t id);
  * BundleAdjuster.cpp:162-176): every projection residual is evaluated with the pinhole
  * intrinsics stored on its MEASUREMENT pose (AddPose overload with cam_params, BundleAdjuster.h:292).
  * orc_set_use_per_pose_cam_params returns 1 if a pose has no parameters. */
+/* Options::calculate_inertial_covariance_once (BundleAdjuster.h:106, parallel_algos.h:189-205) */
+void orc_set_calculate_inertial_covariance_once(orc_ba* h, int on);
 void orc_set_pose_cam_params(orc_ba* h, uint32_t pose_id, const double params4[4]);
 int orc_set_use_per_pose_cam_params(orc_ba* h, int on);
 void orc_add_poses(orc_ba* h, uint32_t n, const double* t_wp, const double* v_w,

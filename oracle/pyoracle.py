@@ -147,6 +147,10 @@ class OracleBundleAdjuster:
             row = np.ascontiguousarray(a[i])
             self.L.orc_set_pose_cam_params(self.h, i, _dp(row))
 
+    def SetCalculateInertialCovarianceOnce(self, on=True):
+        """Options::calculate_inertial_covariance_once (BundleAdjuster.h:106)."""
+        self.L.orc_set_calculate_inertial_covariance_once(self.h, int(on))
+
     def SetUsePerPoseCamParams(self, on=True):
         """Options::use_per_pose_cam_params (BundleAdjuster.h:96)."""
         if self.L.orc_set_use_per_pose_cam_params(self.h, int(on)) != 0:

@@ -980,3 +980,45 @@ def test_get_imu_residual(oracle_lib, pose_dim):
         r = h.GetImuResidual(i)
         assert r["pose1_id"] == i and r["pose2_id"] == i + 1 and r["weight"] == 1.0 + 0.5 * (i % 3)
         assert np.abs(r["residual"][:pose_dim] - ro[i, :pose_dim]).max() < 1e-7 * max(1.0, np.abs(ro[i, :pose_dim]).max())
+
+
+@pytest.mark.gpu
+def test_calculate_inertial_covariance_once(oracle_lib):
+    """Options::calculate_inertial_covariance_once (reference BundleAdjuster.h:106,
+    parallel_algos.h:189-205): the integration covariance and the bias Jacobian of every inertial
+    residual are frozen at its first linearisation — across iterations AND across Solve() calls.
+    Engine vs oracle over four Solve(1) calls; the option changes the result; residuals appended
+    later get their own first linearisation."""
+    po = oracle_lib
+    P = 16
+    sc = scene.make_scene(P, 60, 5, lm_dim=1, seed=57)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+
+    def make(cls, opts, once, n_imu):
+        b = cls(1, 15)
+        b.Init(opts)
+        b.SetGravity(sc.gravity)
+        fill(b, sc)
+        b.SetCalculateInertialCovarianceOnce(once)
+        for i in range(n_imu):
+            b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+        return b
+
+    o = make(po.OracleBundleAdjuster, gn_options(po, use_dogleg=1), True, P - 3)
+    h = make(adjuster.BundleAdjuster, hip_options(use_dogleg=1), True, P - 3)
+    h_off = make(adjuster.BundleAdjuster, hip_options(use_dogleg=1), False, P - 3)
+    for it in range(4):
+        if it == 2:  # two more residuals: linearised (and frozen) for the first time in this Solve
+            for b in (o, h, h_off):
+                for i in (P - 3, P - 2):
+                    b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+        o.Solve(1)
+        h.Solve(1)
+        h_off.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        assert abs(so.inertial_error - sh.inertial_error) <= 1e-6 * max(so.inertial_error, 1e-12)
+        assert abs(so.proj_error - sh.proj_error) <= 1e-6 * max(so.proj_error, 1e-12)
+    _state_close(o, h, 1e-6)
+    # the frozen covariances are not the re-computed ones
+    assert abs(h.summary().inertial_error - h_off.summary().inertial_error) > 1e-9 * h.summary().inertial_error
