@@ -57,7 +57,7 @@ SYMBOLS = [
     "ba_adjuster_add_landmark", "ba_adjuster_add_projection_residual",
     "ba_adjuster_add_unary_constraint", "ba_adjuster_add_binary_constraint",
     "ba_adjuster_add_imu_residual", "ba_adjuster_regularize_pose", "ba_adjuster_set_root_pose_id",
-    "ba_adjuster_set_pose_cam_params", "ba_adjuster_set_calculate_inertial_covariance_once",
+    "ba_adjuster_set_pose_cam_params", "ba_adjuster_set_calculate_inertial_covariance_once", "ba_adjuster_set_imu_noise",
     "ba_adjuster_add_poses", "ba_adjuster_add_landmarks", "ba_adjuster_add_projection_residuals",
     "ba_adjuster_solve", "ba_adjuster_num_poses", "ba_adjuster_num_landmarks",
     "ba_adjuster_num_proj_residuals", "ba_adjuster_get_poses", "ba_adjuster_get_landmarks",
@@ -164,6 +164,11 @@ class BundleAdjuster:
             rc = self.L.ba_adjuster_set_pose_cam_params(self.h, a.shape[0], _p(a, dp))
         if rc != 0:
             raise ValueError("SetPoseCamParams: one [fx, fy, u0, v0] per pose expected")
+
+    def SetImuNoise(self, r6, rb6):
+        """SetImuCalibration with other noise diagonals r / r_b (reference BundleAdjuster.h:566-567)."""
+        a, b = _d(r6), _d(rb6)
+        self.L.ba_adjuster_set_imu_noise(self.h, _p(a, dp), _p(b, dp))
 
     def SetCalculateInertialCovarianceOnce(self, on=True):
         """Options::calculate_inertial_covariance_once (reference BundleAdjuster.h:106)."""

@@ -42,6 +42,7 @@ struct Problem {  // host copies, reference ids
   uint32_t num_unary = 0, num_binary = 0, num_imu = 0;
   std::vector<double> cam_params, cam_tvs;                 // [C][4], [C][7]
   std::vector<double> pose_cam_params;                     // [P][4] or empty (use_per_pose_cam_params)
+  std::vector<double> imu_noise;                           // r(6) | r_b(6) or empty (from the option sigmas)
   std::vector<double> pose_state;                          // [P][16]
   std::vector<uint8_t> pose_active;
   std::vector<double> lm_xw;                               // [L][4]

@@ -489,6 +489,8 @@ static int build_structure(Engine* e) {
       c[9 + i] = e->opt.gyro_bias_sigma * e->opt.gyro_bias_sigma;
       c[12 + i] = e->opt.accel_bias_sigma * e->opt.accel_bias_sigma;
     }
+    if (pb.imu_noise.size() == 12)  // ImuCalibrationT::r / r_b given explicitly (SetImuCalibration)
+      for (int i = 0; i < 12; ++i) c[3 + i] = pb.imu_noise[i];
     if ((rc = upload(e, e->imu_consts, c))) return rc;
     const size_t nr1 = std::max<size_t>(nres, 1);
     BAE_HIP(e->pp_h.alloc(nr1 * 3 * 225)); BAE_HIP(e->pp_g.alloc(nr1 * 30));
@@ -790,6 +792,17 @@ int ba_hip_set_imu_residuals(ba_hip_engine* h, uint32_t n, const uint32_t* pose1
   pb.imu_meas.assign(meas7, meas7 + 7 * (size_t)(n ? meas_ptr[n] : 0));
   if (weight) pb.imu_w.assign(weight, weight + n);
   else pb.imu_w.assign(n, 1.0);
+  e->finalized = false;
+  return 0;
+}
+
+int ba_hip_set_imu_noise(ba_hip_engine* h, const double r6[6], const double rb6[6]) {
+  ENG(h);
+  e->prob.imu_noise.clear();
+  if (r6 && rb6) {
+    e->prob.imu_noise.assign(r6, r6 + 6);
+    e->prob.imu_noise.insert(e->prob.imu_noise.end(), rb6, rb6 + 6);
+  }
   e->finalized = false;
   return 0;
 }

@@ -69,6 +69,8 @@ void ba_adjuster_set_root_pose_id(ba_adjuster* a, uint32_t id);
 int ba_adjuster_set_pose_cam_params(ba_adjuster* a, uint32_t n, const double* params4);
 /* Options::calculate_inertial_covariance_once (reference BundleAdjuster.h:106); call after init */
 void ba_adjuster_set_calculate_inertial_covariance_once(ba_adjuster* a, int on);
+/* SetImuCalibration with the noise diagonals r / r_b replaced (reference BundleAdjuster.h:566-567) */
+void ba_adjuster_set_imu_noise(ba_adjuster* a, const double r6[6], const double rb6[6]);
 void ba_adjuster_add_poses(ba_adjuster* a, uint32_t n, const double* t_wp, const double* v_w,
                            const double* b, const uint8_t* is_active, const double* time);
 void ba_adjuster_add_landmarks(ba_adjuster* a, uint32_t n, const double* x_w,

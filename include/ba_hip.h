@@ -125,6 +125,11 @@ int ba_hip_set_binary_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* po
 int ba_hip_set_imu_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose1_id,
                              const uint32_t* pose2_id, const uint32_t* meas_ptr /* n+1 */,
                              const double* meas7, const double* weight);
+/* ImuCalibrationT::r and r_b (Types.h:112-159): diagonal of the IMU measurement noise (gyro x3,
+ * accelerometer x3) and of the bias random walk, as parallel_algos.h:204,288 read them from imu_.
+ * NULL pointers: derive both from the sigmas of ba_hip_options (what Init() does,
+ * BundleAdjuster.h:204-218).  Call before ba_hip_finalize. */
+int ba_hip_set_imu_noise(ba_hip_engine* e, const double r6[6], const double rb6[6]);
 /* Options::calculate_inertial_covariance_once (BundleAdjuster.h:106, parallel_algos.h:189-205):
  * the integration covariance and the bias Jacobian of an inertial residual are computed in its
  * first linearisation and reused afterwards (they survive later ba_hip_set_imu_residuals calls

@@ -1486,6 +1486,9 @@ void orc_set_pose_cam_params(orc_ba* h, uint32_t pose_id, const double params4[4
   for (int i = 0; i < 4; ++i) h->poses_[pose_id].cam_params[i] = params4[i];
   h->poses_[pose_id].has_cam_params = true;
 }
+void orc_set_imu_noise(orc_ba* h, const double r6[6], const double rb6[6]) {  // SetImuCalibration: imu_.r, imu_.r_b
+  for (int i = 0; i < 6; ++i) { h->imu_r[i] = r6[i]; h->imu_r_b[i] = rb6[i]; }
+}
 void orc_set_calculate_inertial_covariance_once(orc_ba* h, int on) { h->calculate_inertial_covariance_once_ = on != 0; }
 int orc_set_use_per_pose_cam_params(orc_ba* h, int on) {
   if (on)

@@ -79,6 +79,8 @@ void orc_set_root_pose_id(orc_ba* h, uint32_t id);
  * intrinsics stored on its MEASUREMENT pose (AddPose overload with cam_params, BundleAdjuster.h:292).
  * orc_set_use_per_pose_cam_params returns 1 if a pose has no parameters. */
 /* Options::calculate_inertial_covariance_once (BundleAdjuster.h:106, parallel_algos.h:189-205) */
+/* SetImuCalibration (BundleAdjuster.h:567): the noise diagonals imu_.r / imu_.r_b (after orc_init) */
+void orc_set_imu_noise(orc_ba* h, const double r6[6], const double rb6[6]);
 void orc_set_calculate_inertial_covariance_once(orc_ba* h, int on);
 void orc_set_pose_cam_params(orc_ba* h, uint32_t pose_id, const double params4[4]);
 int orc_set_use_per_pose_cam_params(orc_ba* h, int on);

@@ -147,6 +147,11 @@ class OracleBundleAdjuster:
             row = np.ascontiguousarray(a[i])
             self.L.orc_set_pose_cam_params(self.h, i, _dp(row))
 
+    def SetImuNoise(self, r6, rb6):
+        """SetImuCalibration with other noise diagonals imu_.r / imu_.r_b (BundleAdjuster.h:567)."""
+        a, b = _d(r6), _d(rb6)
+        self.L.orc_set_imu_noise(self.h, _dp(a), _dp(b))
+
     def SetCalculateInertialCovarianceOnce(self, on=True):
         """Options::calculate_inertial_covariance_once (BundleAdjuster.h:106)."""
         self.L.orc_set_calculate_inertial_covariance_once(self.h, int(on))

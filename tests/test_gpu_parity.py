@@ -649,7 +649,7 @@ def test_regularize_pose_and_root_pose(oracle_lib, pose_dim):
     assert np.array_equal(p_after[2, :3], p_before[2, :3])  # translation of pose 2 held fixed
 
 
-@pytest.mark.parametrize("variant", ["robust_inertial", "biases_in_batch", "imu_weights", "imu_sigmas"])
+@pytest.mark.parametrize("variant", ["robust_inertial", "biases_in_batch", "imu_weights", "imu_sigmas", "imu_noise_vectors"])
 def test_visual_inertial_options(oracle_lib, variant):
     """Options of the inertial path (BundleAdjuster.h:72-107, BundleAdjuster.cpp:1494-1541):
     Huber weighting of the IMU residuals, regularize_biases_in_batch, per-residual weights of
@@ -671,6 +671,9 @@ def test_visual_inertial_options(oracle_lib, variant):
         b.Init(opts)
         b.SetGravity(sc.gravity)
         fill(b, sc)
+        if variant == "imu_noise_vectors":  # SetImuCalibration: anisotropic r / r_b instead of the option sigmas
+            b.SetImuNoise(1e-9 * np.array([1.0, 2.0, 4.0, 900.0, 1500.0, 2500.0]),
+                          1e-12 * np.array([1.0, 3.0, 2.0, 50.0, 80.0, 20.0]))
         for i in range(P - 1):
             b.AddImuResidual(i, i + 1, sc.imu_meas[i], 0.25 + 0.1 * i if variant == "imu_weights" else 1.0)
         objs.append(b)
