@@ -63,7 +63,7 @@ SYMBOLS = [
     "ba_adjuster_num_proj_residuals", "ba_adjuster_get_poses", "ba_adjuster_get_landmarks",
     "ba_adjuster_is_landmark_reliable", "ba_adjuster_landmark_outlier_ratio",
     "ba_adjuster_get_projection_residual", "ba_adjuster_get_imu_residual",
-    "ba_adjuster_get_summary", "ba_adjuster_get_timers", "ba_adjuster_engine",
+    "ba_adjuster_get_summary", "ba_adjuster_get_cond_errors", "ba_adjuster_get_timers", "ba_adjuster_engine",
     "ba_adjuster_set_allreduce",
 ]
 
@@ -239,6 +239,12 @@ class BundleAdjuster:
         return {"z": o[0:2].copy(), "residual": o[2:4].copy(), "weight": o[4], "orig_weight": o[5],
                 "mahalanobis_distance": o[6], "x_meas_id": int(o[7]), "x_ref_id": int(o[8]),
                 "landmark_id": int(o[9]), "cam_id": int(o[10])}
+
+    def cond_errors(self):
+        """(cond_proj_error, cond_inertial_error) of the SolutionSummary (reference :680-704)."""
+        o = np.empty(2)
+        self.L.ba_adjuster_get_cond_errors(self.h, _p(o, dp))
+        return float(o[0]), float(o[1])
 
     def GetImuResidual(self, i):
         """dict view of ba::ImuResidualT (reference BundleAdjuster.h:563-565)."""

@@ -15,6 +15,7 @@ struct Iface {
   virtual uint32_t add_pose(const double* t, const double* v, const double* b, int act, double time) = 0;
   virtual int set_pose_cam_params(uint32_t n, const double* params4) = 0;
   virtual void set_cov_once(int on) = 0;
+  virtual void cond_errors(double* out2) const = 0;
   virtual void set_imu_noise(const double* r6, const double* rb6) = 0;
   virtual uint32_t add_landmark(const double* x, uint32_t rp, uint32_t rc, int act) = 0;
   virtual uint32_t add_proj(const double* z, uint32_t p, uint32_t l, uint32_t c, double w) = 0;
@@ -72,6 +73,10 @@ struct Impl : Iface {
     auto calib = ba.GetImuCalibration();
     for (int i = 0; i < 6; ++i) { calib.r[i] = r6[i]; calib.r_b[i] = rb6[i]; }
     ba.SetImuCalibration(calib);
+  }
+  void cond_errors(double* o) const override {
+    const auto& m = ba.GetSolutionSummary();
+    o[0] = m.cond_proj_error; o[1] = m.cond_inertial_error;
   }
   void set_cov_once(int on) override { ba.options().calculate_inertial_covariance_once = on != 0; }
   int set_pose_cam_params(uint32_t n, const double* params4) override {
@@ -234,6 +239,7 @@ void ba_adjuster_set_root_pose_id(ba_adjuster* a, uint32_t id) { a->p->set_root(
 int ba_adjuster_set_pose_cam_params(ba_adjuster* a, uint32_t n, const double* params4) { return a->p->set_pose_cam_params(n, params4); }
 void ba_adjuster_set_calculate_inertial_covariance_once(ba_adjuster* a, int on) { a->p->set_cov_once(on); }
 void ba_adjuster_set_imu_noise(ba_adjuster* a, const double r6[6], const double rb6[6]) { a->p->set_imu_noise(r6, rb6); }
+void ba_adjuster_get_cond_errors(const ba_adjuster* a, double out2[2]) { a->p->cond_errors(out2); }
 void ba_adjuster_add_poses(ba_adjuster* a, uint32_t n, const double* t_wp, const double* v_w, const double* b, const uint8_t* is_active, const double* time) {
   for (uint32_t i = 0; i < n; ++i)
     a->p->add_pose(t_wp + 7 * (size_t)i, v_w ? v_w + 3 * (size_t)i : nullptr, b ? b + 6 * (size_t)i : nullptr,

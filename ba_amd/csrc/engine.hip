@@ -1195,6 +1195,18 @@ int ba_hip_get_imu_residuals(ba_hip_engine* h, double* residual15) {
   return 0;
 }
 
+int ba_hip_get_imu_errors(ba_hip_engine* h, double* mahalanobis) {
+  ENG(h);
+  NEED_FINAL();
+  const Problem& pb = e->prob;
+  if (pb.num_imu == 0) return 0;
+  BAE_HIP(hipSetDevice(e->device));
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  BAE_HIP(hipMemcpy(mahalanobis, e->pp_err.p + pb.num_unary + pb.num_binary, (size_t)pb.num_imu * sizeof(double),
+                    hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int ba_hip_get_unary_scales(ba_hip_engine* h, double* scale) {
   ENG(h);
   NEED_FINAL();

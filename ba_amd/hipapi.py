@@ -71,7 +71,7 @@ SYMBOLS = [
     "ba_hip_rollback", "ba_hip_eval_residuals", "ba_hip_end_solve", "ba_hip_get_poses",
     "ba_hip_get_landmarks", "ba_hip_get_landmark_flags", "ba_hip_num_pose_params",
     "ba_hip_num_lm_params", "ba_hip_get_S", "ba_hip_get_rhs", "ba_hip_get_delta_gn",
-    "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_proj_residuals", "ba_hip_get_imu_residuals", "ba_hip_get_timers", "ba_hip_get_unary_scales", "ba_hip_device_buffer",
+    "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_proj_residuals", "ba_hip_get_imu_residuals", "ba_hip_get_imu_errors", "ba_hip_get_timers", "ba_hip_get_unary_scales", "ba_hip_device_buffer",
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
     "ba_hip_get_kernel_stats",
 ]

@@ -864,6 +864,19 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
   summary_.num_cond_proj_residuals = (uint32_t)conditioning_proj_residuals_.size();
   summary_.num_proj_residuals = (uint32_t)pr_pose_.size();
   summary_.proj_error_ = proj_error_;
+  // the conditioning sums (:680-704) are read back only when there is something to sum
+  summary_.cond_inertial_error = 0;
+  summary_.cond_proj_error = 0;
+  if (!conditioning_inertial_residuals_.empty()) {
+    std::vector<double> md(imu_p1_.size(), 0.0);
+    if (Check(ba_hip_get_imu_errors(engine_, md.data()), "ba_hip_get_imu_errors"))
+      for (uint32_t id : conditioning_inertial_residuals_) summary_.cond_inertial_error += md[id];
+  }
+  for (uint32_t id : conditioning_proj_residuals_) {
+    // res.mahalanobis_distance / res.weight = |residual|^2 (:700-703)
+    const ProjectionResidual& r = GetProjectionResidual(id);
+    summary_.cond_proj_error += r.residual[0] * r.residual[0] + r.residual[1] * r.residual[1];
+  }
 }
 
 }  // namespace ba

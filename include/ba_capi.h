@@ -95,6 +95,8 @@ void ba_adjuster_get_projection_residual(const ba_adjuster* a, uint32_t id, doub
  * first PoseSize entries are used); returns the number of measurements (0 for a bad id) */
 uint32_t ba_adjuster_get_imu_residual(const ba_adjuster* a, uint32_t id, double* out19);
 void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s);
+/* SolutionSummary::cond_proj_error, cond_inertial_error (reference BundleAdjuster.cpp:680-704) */
+void ba_adjuster_get_cond_errors(const ba_adjuster* a, double out2[2]);
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
 /* the engine behind the adjuster (valid after the first Solve) for the debug taps of ba_hip.h */
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a);

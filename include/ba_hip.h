@@ -190,6 +190,10 @@ int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
  * EvaluateResiduals, BundleAdjuster.cpp:225-256): 15 doubles per residual in residual-id order,
  * the first PoseSize of them used (9: translation, rotation, velocity; 15: + biases). */
 int ba_hip_get_imu_residuals(ba_hip_engine* e, double* residual15);
+/* Mahalanobis distance of every inertial residual at the last evaluation (ImuResidualT::
+ * mahalanobis_distance, BundleAdjuster.cpp:252-254), residual-id order; summed over the
+ * conditioning residuals by SolutionSummary::cond_inertial_error (:680-690). */
+int ba_hip_get_imu_errors(ba_hip_engine* e, double* mahalanobis);
 /* cumulative Huber scale of every unary residual's cov^-1 (the reference multiplies
  * cov_inv in place every BuildProblem, BundleAdjuster.cpp:1469) */
 int ba_hip_get_unary_scales(ba_hip_engine* e, double* scale);

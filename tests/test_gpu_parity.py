@@ -1025,3 +1025,38 @@ def test_calculate_inertial_covariance_once(oracle_lib):
     _state_close(o, h, 1e-6)
     # the frozen covariances are not the re-computed ones
     assert abs(h.summary().inertial_error - h_off.summary().inertial_error) > 1e-9 * h.summary().inertial_error
+
+
+@pytest.mark.gpu
+def test_conditioning_error_sums(oracle_lib):
+    """SolutionSummary::cond_proj_error / cond_inertial_error (reference BundleAdjuster.cpp:680-704):
+    sums over the residuals that tie an active pose to an inactive one (BundleAdjuster.h:503-510,
+    538-545) — |r|^2 of the projection residuals, Mahalanobis distance of the inertial ones."""
+    po = oracle_lib
+    P = 14
+    sc = scene.make_scene(P, 60, 5, lm_dim=1, seed=53)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    pa = np.ones(P, dtype=np.uint8)
+    pa[[0, 1]] = 0  # inactive start: its landmarks' residuals and the IMU residual 1 -> 2 condition
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, use_dogleg=1)), (adjuster.BundleAdjuster, hip_options(use_dogleg=1))):
+        b = cls(1, 15)
+        b.Init(opts)
+        b.SetGravity(sc.gravity)
+        fill(b, sc, active=pa)
+        for i in range(P - 1):
+            b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+        objs.append(b)
+    o, h = objs
+    for _ in range(2):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        assert so.num_cond_proj_residuals == sh.num_cond_proj_residuals > 0
+        assert so.num_cond_inertial_residuals == sh.num_cond_inertial_residuals == 1
+        cp, ci = h.cond_errors()
+        assert so.cond_proj_error > 0 and so.cond_inertial_error > 0
+        if so.result == 0:  # after a rejected step the reference's per-residual values are those of the rejected state
+            assert abs(cp - so.cond_proj_error) <= 1e-6 * so.cond_proj_error
+            assert abs(ci - so.cond_inertial_error) <= 1e-6 * so.cond_inertial_error
