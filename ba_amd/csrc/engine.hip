@@ -14,6 +14,7 @@
 #include <numeric>
 
 #include "dmath.h"
+#include "dpose.h"
 
 namespace bae {
 
@@ -793,6 +794,28 @@ int ba_hip_set_imu_residuals(ba_hip_engine* h, uint32_t n, const uint32_t* pose1
   if (weight) pb.imu_w.assign(weight, weight + n);
   else pb.imu_w.assign(n, 1.0);
   e->finalized = false;
+  return 0;
+}
+
+// Host-side RK4 integration of IMU samples with the code the device kernels use (dpose.h):
+// ImuResidualT::IntegrateResidual without Jacobians (Types.h:662-738).
+int ba_hip_integrate_imu(const double t_wp7[7], const double v_w3[3], const double bg3[3], const double ba3[3],
+                         const double g3[3], const double* meas7, uint32_t nmeas, double* states10) {
+  if (!t_wp7 || !v_w3 || !bg3 || !ba3 || !g3 || !states10 || (nmeas && !meas7)) return -1;
+  bad::ImuState s;
+  for (int i = 0; i < 3; ++i) { s.t[i] = t_wp7[i]; s.v[i] = v_w3[i]; }
+  for (int i = 0; i < 4; ++i) s.q[i] = t_wp7[3 + i];
+  auto put = [&](uint32_t k) {
+    double* o = states10 + 10 * (size_t)k;
+    for (int i = 0; i < 3; ++i) { o[i] = s.t[i]; o[7 + i] = s.v[i]; }
+    for (int i = 0; i < 4; ++i) o[3 + i] = s.q[i];
+  };
+  put(0);
+  for (uint32_t i = 1; i < nmeas; ++i) {
+    s = bad::integrate_imu(s, meas7 + 7 * (size_t)(i - 1), meas7 + 7 * (size_t)i, bg3, ba3, g3, false, nullptr,
+                           nullptr, nullptr, nullptr);
+    put(i);
+  }
   return 0;
 }
 

@@ -65,7 +65,7 @@ SYMBOLS = [
     "ba_hip_create", "ba_hip_destroy", "ba_hip_last_error", "ba_hip_set_options",
     "ba_hip_set_cameras", "ba_hip_set_pose_cam_params", "ba_hip_set_poses", "ba_hip_set_landmarks",
     "ba_hip_set_projection_residuals", "ba_hip_set_unary_residuals",
-    "ba_hip_set_binary_residuals", "ba_hip_set_imu_residuals", "ba_hip_set_inertial_covariance_once", "ba_hip_set_imu_noise", "ba_hip_set_gravity",
+    "ba_hip_set_binary_residuals", "ba_hip_set_imu_residuals", "ba_hip_set_inertial_covariance_once", "ba_hip_set_imu_noise", "ba_hip_integrate_imu", "ba_hip_set_gravity",
     "ba_hip_finalize", "ba_hip_begin_solve", "ba_hip_set_pose_masks", "ba_hip_linearize",
     "ba_hip_solve_gn", "ba_hip_dogleg_terms", "ba_hip_compose_step", "ba_hip_apply_step",
     "ba_hip_rollback", "ba_hip_eval_residuals", "ba_hip_end_solve", "ba_hip_get_poses",

@@ -110,6 +110,7 @@ class BundleAdjuster {
   typedef ProjectionResidualT<Scalar, LmSize> ProjectionResidual;
   typedef ImuMeasurementT<Scalar> ImuMeasurement;
   typedef ImuResidualT<Scalar, kPoseDim, kPoseDim> ImuResidual;  // reference :142
+  typedef ImuPoseT<Scalar> ImuPose;  // reference :144
   typedef ImuCalibrationT<Scalar> ImuCalibration;
   typedef ba::Vector2t Vector2t;
   typedef ba::Vector3t Vector3t;

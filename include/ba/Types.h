@@ -8,6 +8,7 @@
 // application code that passes Sophus::SE3d / Eigen vectors keeps compiling when those
 // headers are present.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -178,12 +179,74 @@ struct ProjectionResidualT {
   bool is_conditioning = false;
 };
 
+// reference Types.h:160-197
+template <typename Scalar = double>
+struct ImuPoseT {
+  ImuPoseT() : time(0) {}
+  ImuPoseT(const PoseT<Scalar>& pose) : t_wp(pose.t_wp), v_w(pose.v_w), time(pose.time) {}
+  ImuPoseT(const SE3& twp, const Vector3t& v, const Vector3t& w, const double time_)
+      : t_wp(twp), v_w(v), w_w(w), time(time_) {}
+  SE3 t_wp;       // pose in world coordinates
+  Vector3t v_w;   // velocity in world coordinates
+  Vector3t w_w;   // angular rates in world coordinates
+  double time;    // seconds
+};
+
+extern "C" int ba_hip_integrate_imu(const double t_wp7[7], const double v_w3[3], const double bg3[3],
+                                    const double ba3[3], const double g3[3], const double* meas7,
+                                    uint32_t nmeas, double* states10);
+
 // reference Types.h:300-321, the host-visible part (the Jacobian / covariance blocks dz_dx1, dz_dx2,
-// cov_inv ... and the integrated trajectory `poses` live only on the device)
+// cov_inv ... live only on the device)
 template <typename Scalar = double, int ResidualSize = 15, int PoseSize = 15>
 struct ImuResidualT {
   typedef ImuMeasurementT<Scalar> ImuMeasurement;
+  typedef ImuPoseT<Scalar> ImuPose;
   static const uint32_t kResSize = ResidualSize;
+
+  // reference Types.h:643-738: RK4 integration of the samples from `pose` (the Jacobian outputs of
+  // the reference's signature are device-only here); `poses` receives the start state and the
+  // state at every later sample.  Runs on the host with the code the device kernels use
+  // (ba_hip_integrate_imu in libba_hip.so).
+  static ImuPose IntegrateResidual(const ImuPose& pose, const std::vector<ImuMeasurement>& measurements,
+                                   const Vector3t& bg, const Vector3t& ba, const Vector3t& g,
+                                   std::vector<ImuPose>& poses) {
+    const size_t n = measurements.size();
+    std::vector<double> m(7 * std::max<size_t>(n, 1)), st(10 * std::max<size_t>(n, 1));
+    for (size_t i = 0; i < n; ++i) {
+      for (int k = 0; k < 3; ++k) { m[7 * i + k] = measurements[i].w[k]; m[7 * i + 3 + k] = measurements[i].a[k]; }
+      m[7 * i + 6] = measurements[i].time;
+    }
+    double t7[7];
+    pose.t_wp.to7(t7);
+    const double v[3] = {pose.v_w[0], pose.v_w[1], pose.v_w[2]}, b1[3] = {bg[0], bg[1], bg[2]},
+                 b2[3] = {ba[0], ba[1], ba[2]}, gg[3] = {g[0], g[1], g[2]};
+    ba_hip_integrate_imu(t7, v, b1, b2, gg, m.data(), (uint32_t)n, st.data());
+    poses.clear();
+    const size_t rows = std::max<size_t>(n, 1);
+    for (size_t i = 0; i < rows; ++i) {
+      ImuPose p;
+      p.t_wp = SE3::from7(&st[10 * i]);
+      for (int k = 0; k < 3; ++k) p.v_w[k] = st[10 * i + 7 + k];
+      p.w_w = pose.w_w;
+      p.time = (i < n) ? measurements[i].time : pose.time;
+      poses.push_back(p);
+    }
+    return poses.back();
+  }
+  static ImuPose IntegrateResidual(const PoseT<Scalar>& pose, const std::vector<ImuMeasurement>& measurements,
+                                   const Vector3t& bg, const Vector3t& ba, const Vector3t& g,
+                                   std::vector<ImuPose>& poses) {
+    return IntegrateResidual(ImuPose(pose), measurements, bg, ba, g, poses);
+  }
+  // reference Types.h:419-643, state only: one RK4 step between two samples
+  static ImuPose IntegrateImu(const ImuPose& pose, const ImuMeasurement& z_start, const ImuMeasurement& z_end,
+                              const Vector3t& bg, const Vector3t& ba, const Vector3t& g) {
+    std::vector<ImuMeasurement> two = {z_start, z_end};
+    std::vector<ImuPose> out;
+    return IntegrateResidual(pose, two, bg, ba, g, out);
+  }
+
   uint32_t residual_id = 0, residual_offset = 0;
   uint32_t pose1_id = 0, pose2_id = 0;
   Scalar mahalanobis_distance = 0;

@@ -125,6 +125,13 @@ int ba_hip_set_binary_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* po
 int ba_hip_set_imu_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose1_id,
                              const uint32_t* pose2_id, const uint32_t* meas_ptr /* n+1 */,
                              const double* meas7, const double* weight);
+/* ImuResidualT::IntegrateResidual without Jacobians (Types.h:662-738): RK4 integration of `nmeas`
+ * IMU samples [wx,wy,wz,ax,ay,az,time] from the state (t_wp7, v_w3) with biases bg3 / ba3 and
+ * gravity g3 — host code, the same source as the device kernels (no engine, no GPU needed).
+ * states10 receives max(nmeas, 1) rows [t(3) q(4) v(3)]: the start state, then the state at every
+ * later sample (the reference's `poses` vector).  Returns 0, or -1 on a NULL argument. */
+int ba_hip_integrate_imu(const double t_wp7[7], const double v_w3[3], const double bg3[3], const double ba3[3],
+                         const double g3[3], const double* meas7, uint32_t nmeas, double* states10);
 /* ImuCalibrationT::r and r_b (Types.h:112-159): diagonal of the IMU measurement noise (gyro x3,
  * accelerometer x3) and of the bias random walk, as parallel_algos.h:204,288 read them from imu_.
  * NULL pointers: derive both from the sigmas of ba_hip_options (what Init() does,

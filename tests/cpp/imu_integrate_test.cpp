@@ -1,0 +1,45 @@
+// ImuResidualT::IntegrateResidual / IntegrateImu of include/ba/Types.h (reference Types.h:419-738,
+// state only) through the BundleAdjuster typedefs: constant-acceleration motion against the
+// closed form, the `poses` trajectory, and IntegrateImu == a two-sample IntegrateResidual.
+#include <cmath>
+#include <cstdio>
+#include <ba/BundleAdjuster.h>
+
+typedef ba::BundleAdjuster<double, 1, 15, 0> BA;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { printf("FAIL line %d: %s\n", __LINE__, #c); ++fails; } } while (0)
+
+int main() {
+  const ba::Vector3t g({0.0, 0.0, -9.8007}), zero({0.0, 0.0, 0.0});
+  // no rotation; the reference's model is v' = R (a + b_a) - g (GetPoseDerivative, Types.h:376-400): a constant
+  // world acceleration of (1, 0, 0) needs the reading (1, 0, 0) + g
+  std::vector<BA::ImuMeasurement> meas;
+  for (int i = 0; i <= 20; ++i)
+    meas.push_back(BA::ImuMeasurement(zero, ba::Vector3t({1.0, 0.0, -9.8007}), 0.05 * i));
+  BA::ImuPose start(ba::SE3(), ba::Vector3t({0.5, 0.0, 0.0}), zero, 0.0);
+  std::vector<BA::ImuPose> poses;
+  const BA::ImuPose end = BA::ImuResidual::IntegrateResidual(start, meas, zero, zero, g, poses);
+  const double T = 1.0;
+  CHECK(poses.size() == meas.size());
+  CHECK(std::fabs(end.t_wp.t[0] - (0.5 * T + 0.5 * T * T)) < 1e-12);
+  CHECK(std::fabs(end.t_wp.t[1]) < 1e-12 && std::fabs(end.t_wp.t[2]) < 1e-12);
+  CHECK(std::fabs(end.v_w[0] - 1.5) < 1e-12 && std::fabs(end.v_w[2]) < 1e-12);
+  CHECK(std::fabs(poses[10].t_wp.t[0] - (0.25 + 0.125)) < 1e-12 && poses[10].time == 0.5);
+  CHECK(poses[0].t_wp.t[0] == 0.0 && poses[0].v_w[0] == 0.5);
+  // one step at a time reproduces the trajectory
+  BA::ImuPose p = start;
+  for (size_t i = 1; i < meas.size(); ++i) p = BA::ImuResidual::IntegrateImu(p, meas[i - 1], meas[i], zero, zero, g);
+  CHECK(std::fabs(p.t_wp.t[0] - end.t_wp.t[0]) < 1e-13 && std::fabs(p.v_w[0] - end.v_w[0]) < 1e-13);
+  // the bias is ADDED to the reading: -1 along x cancels the acceleration
+  const BA::ImuPose biased = BA::ImuResidual::IntegrateResidual(start, meas, zero, ba::Vector3t({-1.0, 0.0, 0.0}), g, poses);
+  CHECK(std::fabs(biased.v_w[0] - 0.5) < 1e-12);
+  // from a PoseT
+  BA::Pose pose;
+  pose.v_w = ba::Vector3t({0.5, 0.0, 0.0});
+  pose.time = 0.0;
+  const BA::ImuPose e2 = BA::ImuResidual::IntegrateResidual(pose, meas, zero, zero, g, poses);
+  CHECK(e2.t_wp.t[0] == end.t_wp.t[0]);
+  printf(fails ? "imu integrate: %d failures\n" : "imu integrate: ok\n", fails);
+  return fails ? 1 : 0;
+}
