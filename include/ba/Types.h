@@ -179,6 +179,21 @@ struct ProjectionResidualT {
   bool is_conditioning = false;
 };
 
+// reference Types.h:91-110: the 3d gravity vector from the 2d direction (pitch, roll) vector
+template <typename Scalar = double>
+inline Vector3t GetGravityVector(const Vector2t& dir, const Scalar g = (Scalar)Gravity) {
+  const double sp = std::sin(dir[0]), cp = std::cos(dir[0]), sq = std::sin(dir[1]), cq = std::cos(dir[1]);
+  return Vector3t({-g * cp * sq, g * sp, -g * cp * cq});
+}
+// reference Types.h:161-180: its 3x2 Jacobian with respect to the direction
+template <typename Scalar = double>
+inline Mat<3, 2> dGravity_dDirection(const Vector2t& dir, const Scalar g = (Scalar)Gravity) {
+  const double sp = std::sin(dir[0]), cp = std::cos(dir[0]), sq = std::sin(dir[1]), cq = std::cos(dir[1]);
+  Mat<3, 2> v({-sp * sq, cp * cq, -cp, 0.0, -cq * sp, -cp * sq});
+  for (int i = 0; i < 6; ++i) v[i] *= -g;
+  return v;
+}
+
 // reference Types.h:160-197
 template <typename Scalar = double>
 struct ImuPoseT {

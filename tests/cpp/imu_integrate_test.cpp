@@ -40,6 +40,20 @@ int main() {
   pose.time = 0.0;
   const BA::ImuPose e2 = BA::ImuResidual::IntegrateResidual(pose, meas, zero, zero, g, poses);
   CHECK(e2.t_wp.t[0] == end.t_wp.t[0]);
+  // GetGravityVector / dGravity_dDirection (reference Types.h:91-110,161-180)
+  {
+    const ba::Vector3t g0 = ba::GetGravityVector(ba::Vector2t({0.0, 0.0}));
+    CHECK(g0[0] == 0.0 && g0[1] == 0.0 && std::fabs(g0[2] + ba::Gravity) < 1e-15);
+    const ba::Vector2t d({0.3, -0.2});
+    const auto J = ba::dGravity_dDirection(d);
+    for (int k = 0; k < 2; ++k) {
+      ba::Vector2t dp = d, dm = d;
+      dp[k] += 1e-6; dm[k] -= 1e-6;
+      const ba::Vector3t gp = ba::GetGravityVector(dp), gm = ba::GetGravityVector(dm);
+      for (int r = 0; r < 3; ++r) CHECK(std::fabs((gp[r] - gm[r]) / 2e-6 - J(r, k)) < 1e-7);
+    }
+    CHECK(std::fabs(ba::GetGravityVector(d).norm() - ba::Gravity) < 1e-12);
+  }
   printf(fails ? "imu integrate: %d failures\n" : "imu integrate: ok\n", fails);
   return fails ? 1 : 0;
 }
