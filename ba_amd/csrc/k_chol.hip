@@ -1103,7 +1103,10 @@ static void launch_next_panel_update(hipStream_t s, double* dA, uint32_t ld, uin
                                      int* colneg, int* flags, const uint8_t* nz) {
   static const bool no128 = getenv("BA_HIP_NO128") != nullptr;
   const uint32_t r0 = c0 + ncols;
-  if (!no128 && r0 + 16 <= nblk && ncols % 2u == 0 && c0 % 2u == 0) {
+  // (a second launch on the serial chain: only where the chain is not the bottleneck)
+  static const uint32_t min_rows =
+      getenv("BA_HIP_BULK_FULL_M") ? (uint32_t)std::max(16, atoi(getenv("BA_HIP_BULK_FULL_M"))) : 128u;
+  if (!no128 && r0 + min_rows <= nblk && ncols % 2u == 0 && c0 % 2u == 0) {
     const uint32_t m = nblk - r0, m2 = m / 2, rect_cols = ncols / 2;
     hipLaunchKernelGGL(k_step_update, dim3(ncols, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn, opbuf,
                        colneg, flags, nz, r0);
