@@ -98,6 +98,35 @@ class CameraInterface {
   template <typename V> void SetParams(const V& v) { for (int i = 0; i < 4; ++i) p_[i] = v[i]; }
   const SE3& Pose() const { return t_vs_; }
   void SetPose(const SE3& t) { t_vs_ = t; }
+  // the pinhole (calibu::LinearCamera) model itself, for callers that synthesise or check
+  // measurements on the host (semantics of the calibu calls at parallel_algos.h:59-62,73-74)
+  Vector2t Project(const Vector3t& P) const {
+    return Vector2t({p_[0] * P[0] / P[2] + p_[2], p_[1] * P[1] / P[2] + p_[3]});
+  }
+  Vector3t Unproject(const Vector2t& pix) const {  // the ray with z = 1
+    return Vector3t({(pix[0] - p_[2]) / p_[0], (pix[1] - p_[3]) / p_[1], 1.0});
+  }
+  // Transfer3d(T_ba, ray, rho) = Project(R ray + rho t)
+  Vector2t Transfer3d(const SE3& t_ba, const Vector3t& ray, const Scalar rho) const {
+    const Matrix3t R = t_ba.rotationMatrix();
+    Vector3t P;
+    for (int r = 0; r < 3; ++r) P[r] = R(r, 0) * ray[0] + R(r, 1) * ray[1] + R(r, 2) * ray[2] + rho * t_ba.t[r];
+    return Project(P);
+  }
+  // dTransfer3d_dray(T_ba, ray, rho) = [dProject R, dProject t]  (2 x 4)
+  Mat<2, 4> dTransfer3d_dray(const SE3& t_ba, const Vector3t& ray, const Scalar rho) const {
+    const Matrix3t R = t_ba.rotationMatrix();
+    Vector3t P;
+    for (int r = 0; r < 3; ++r) P[r] = R(r, 0) * ray[0] + R(r, 1) * ray[1] + R(r, 2) * ray[2] + rho * t_ba.t[r];
+    const double d[2][3] = {{p_[0] / P[2], 0.0, -p_[0] * P[0] / (P[2] * P[2])},
+                            {0.0, p_[1] / P[2], -p_[1] * P[1] / (P[2] * P[2])}};
+    Mat<2, 4> J;
+    for (int r = 0; r < 2; ++r) {
+      for (int c = 0; c < 3; ++c) J(r, c) = d[r][0] * R(0, c) + d[r][1] * R(1, c) + d[r][2] * R(2, c);
+      J(r, 3) = d[r][0] * t_ba.t[0] + d[r][1] * t_ba.t[1] + d[r][2] * t_ba.t[2];
+    }
+    return J;
+  }
  private:
   double p_[4];
   SE3 t_vs_;

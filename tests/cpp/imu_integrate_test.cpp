@@ -54,6 +54,27 @@ int main() {
     }
     CHECK(std::fabs(ba::GetGravityVector(d).norm() - ba::Gravity) < 1e-12);
   }
+  // the pinhole stand-in for calibu::LinearCamera: Project / Unproject / Transfer3d / dTransfer3d_dray
+  {
+    const double q[4] = {0.1, -0.2, 0.05, 0.0};
+    double qq[4]; const double nn = std::sqrt(0.01 + 0.04 + 0.0025 + 0.9);
+    for (int i = 0; i < 3; ++i) qq[i] = q[i] / nn; qq[3] = std::sqrt(0.9) / nn;
+    const double tt[3] = {0.3, -0.1, 0.2};
+    const ba::SE3 T(tt, qq);
+    const ba::CameraInterface<double> cam(198.969, 198.1284, 329.9368, 240.1017);
+    const ba::Vector2t pix({400.0, 200.0});
+    const ba::Vector3t ray = cam.Unproject(pix);
+    const ba::Vector2t back = cam.Project(ray);
+    CHECK(std::fabs(back[0] - pix[0]) < 1e-12 && std::fabs(back[1] - pix[1]) < 1e-12 && ray[2] == 1.0);
+    const double rho = 0.25;
+    const auto J = cam.dTransfer3d_dray(T, ray, rho);
+    for (int c = 0; c < 4; ++c) {
+      ba::Vector3t rp = ray, rm = ray; double hp = rho, hm = rho;
+      if (c < 3) { rp[c] += 1e-6; rm[c] -= 1e-6; } else { hp += 1e-6; hm -= 1e-6; }
+      const ba::Vector2t a = cam.Transfer3d(T, rp, hp), b = cam.Transfer3d(T, rm, hm);
+      for (int r = 0; r < 2; ++r) CHECK(std::fabs((a[r] - b[r]) / 2e-6 - J(r, c)) < 1e-5);
+    }
+  }
   printf(fails ? "imu integrate: %d failures\n" : "imu integrate: ok\n", fails);
   return fails ? 1 : 0;
 }
