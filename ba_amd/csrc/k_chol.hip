@@ -389,6 +389,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 // The blocks cover the even part of the trailing matrix; the rhs row and an odd last tile row are
 // 64-tiles taken by the first workgroups of the same launch.
 static const int NB2 = 128;
+template <bool RECT>  // RECT: the rectangle variant (separate kernel name in profiles)
 __global__ void __launch_bounds__(256, 2)
 k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t m2, uint32_t kb0,
             uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, uint32_t sbl,
@@ -403,7 +404,7 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   // or the rectangle rows >= r0 x the rect_cols 128-column blocks from c0 on (the next panel's
   // columns below the panel itself).
   if (blockIdx.x < nrow64) {
-    const uint32_t mcols = rect_cols ? 2 * rect_cols : nblk - c0, y = blockIdx.x / mcols;
+    const uint32_t mcols = RECT ? 2 * rect_cols : nblk - c0, y = blockIdx.x / mcols;
     const uint32_t c = c0 + blockIdx.x % mcols, i = nblk - y;
     if (y > ((nblk - r0) & 1u) || c > i || c >= nblk) return;  // (nrow64 is rounded up to a multiple of 8)
     if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
@@ -413,7 +414,7 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   }
   const uint32_t b = blockIdx.x - nrow64;
   uint32_t R, C;
-  if (rect_cols) {
+  if (RECT) {
     // consecutive workgroups (= the XCDs, round-robin) take the column blocks of one row block:
     // an XCD keeps "its" column operands in L2 for all rows
     R = b / rect_cols;
@@ -1180,7 +1181,7 @@ static void launch_next_panel_update(hipStream_t s, double* dA, uint32_t ld, uin
     hipLaunchKernelGGL(k_step_update, dim3(ncols, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn, opbuf,
                        colneg, flags, nz, r0);
     const uint32_t nrow64 = (ncols * (1 + (m & 1u)) + 7) / 8 * 8;
-    hipLaunchKernelGGL(k_update128, dim3(nrow64 + m2 * rect_cols), dim3(256), 0, s, dA, ld, nblk, c0, m2, kb0, kb1,
+    hipLaunchKernelGGL(k_update128<true>, dim3(nrow64 + m2 * rect_cols), dim3(256), 0, s, dA, ld, nblk, c0, m2, kb0, kb1,
                        (const double*)dsgn, (const int*)colneg, 0u, nz, 0u, 1u, 1u, nrow64, r0, rect_cols);
     return;
   }
@@ -1207,7 +1208,7 @@ static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld
     // leftover 64-tiles first (a multiple of 8 workgroups keeps the XCD phase of the blocks)
     const uint32_t nrow64 = (m * (1 + (m & 1u)) + 7) / 8 * 8;
     if (e) e->prof_begin(e->ev_syrk, s);
-    hipLaunchKernelGGL(k_update128, dim3(nrow64 + ((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk,
+    hipLaunchKernelGGL(k_update128<false>, dim3(nrow64 + ((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk,
                        a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own_rank, own_n, own_kout, nrow64, a_end, 0u);
     if (e) e->prof_end(e->ev_syrk, s);
     return;

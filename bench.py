@@ -204,11 +204,11 @@ def main():
         traffic = None
         pmc = {}
         # 128x128 blocks on trailing matrices of >= 128 tiles, the capped 64-tile kernel below
-        bulk_kernel = "k_update128" if n >= 128 * 64 else "k_update2<true>"
+        bulk_kernel = "k_update128<false>" if n >= 128 * 64 else "k_update2<true>"
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg%d.json" % args.config)) as f:
                 pmc = json.load(f)["kernels"]
-            bulk = "bae::k_update128" if n >= 128 * 64 else "bae::k_update2<true>"
+            bulk = "bae::k_update128<false>" if n >= 128 * 64 else "bae::k_update2<true>"
             traffic = pmc[bulk]["traffic_bytes_per_launch_corrected"]
         except (OSError, KeyError, ValueError):
             pass
