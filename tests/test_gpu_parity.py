@@ -66,7 +66,9 @@ def test_dense_cholesky_solve_matches_numpy():
         assert rel_err(x, np.linalg.solve(a, b)) < 1e-11
     # symmetric indefinite (quasi-definite) systems factor as L D L^T like the reference's
     # un-pivoted LDLT (BundleAdjuster.cpp:752-761)
-    for n in (10, 130, 500):
+    # (2100: 33 tiles — with BA_HIP_BULK_FULL_M=16 (test_blocked_128_trailing_update_on_small_systems)
+    # the negative pivots send k_update128's blocks through its generic 64-tile fallback)
+    for n in (10, 130, 500, 2100):
         m = rng.normal(size=(n, n))
         a = m @ m.T + n * np.eye(n)
         a[n // 2:, n // 2:] -= 2.5 * (m @ m.T + n * np.eye(n))[n // 2:, n // 2:]
