@@ -1150,13 +1150,24 @@ k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restric
 static const uint32_t KIN = 4;
 static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t Jend,
                                double* dsgn, double* opbuf, int* colneg, int* flags, const uint8_t* nz) {
-  for (uint32_t sub = J; sub < Jend; sub += KIN) {
-    const uint32_t sub_end = std::min(sub + KIN, Jend);
+  // Large systems (the chain's tile updates are bandwidth-bound there and cost the bulk update their
+  // full duration): sub-panels of 8, left-looking inside — every column is read and written once
+  // per sub-panel instead of once per earlier column.  Small systems are latency-bound on the
+  // diagonal tile: right-looking keeps its update shallow (K = 64).
+  const bool left = nblk >= 512;
+  const uint32_t KINv = left ? 2 * KIN : KIN;
+  for (uint32_t sub = J; sub < Jend; sub += KINv) {
+    const uint32_t sub_end = std::min(sub + KINv, Jend);
     for (uint32_t jj = sub; jj < sub_end; ++jj) {
       hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s, dA, ld, jj, nblk, (const double*)opbuf, nz);
-      if (jj + 1 < sub_end)
-        hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
-                           nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
+      if (jj + 1 < sub_end) {
+        if (left)  // column jj + 1 alone, with every earlier column of the sub-panel at once
+          hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, 1), dim3(256), 0, s, dA, ld, nblk, jj + 1, sub,
+                             jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
+        else       // the rest of the sub-panel with column jj
+          hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
+                             nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
+      }
     }
     if (sub_end < Jend)
       hipLaunchKernelGGL(k_step_update, dim3(nblk - sub_end + 1, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk,

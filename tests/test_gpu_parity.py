@@ -1062,3 +1062,28 @@ def test_conditioning_error_sums(oracle_lib):
         if so.result == 0:  # after a rejected step the reference's per-residual values are those of the rejected state
             assert abs(cp - so.cond_proj_error) <= 1e-6 * so.cond_proj_error
             assert abs(ci - so.cond_inertial_error) <= 1e-6 * so.cond_inertial_error
+
+
+@pytest.mark.gpu
+def test_dense_solve_with_1024_column_panels():
+    """n = 33 000 (516 tiles): the schedule of BASELINE.json configs[3] — outer panels of 16 tiles,
+    left-looking sub-panels of 8, k_update128 for the bulk and for the rectangle under the next
+    panel — on a dense diagonally dominant matrix, checked through the residual of the solve and
+    bitwise repeatability."""
+    n = 33000
+    rng = np.random.default_rng(9)
+    a = rng.random((n, n), dtype=np.float32).astype(np.float64)
+    a -= 0.5
+    a = np.tril(a)
+    a[np.diag_indices(n)] = 0.3 * n          # strictly diagonally dominant: SPD
+    b = rng.normal(size=n)
+    eng = hipapi.Engine(1, 6)
+    x, rc = eng.dense_solve(a, b)
+    assert rc == 0
+    x2, rc2 = eng.dense_solve(a, b)
+    assert rc2 == 0 and np.array_equal(x, x2)
+    # A x with the symmetric matrix stored as its lower triangle
+    ax = a @ x
+    ax += a.T @ x
+    ax -= a.diagonal() * x
+    assert rel_err(ax, b) < 1e-11
