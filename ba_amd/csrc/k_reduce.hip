@@ -15,70 +15,57 @@
 namespace bae {
 
 // ---------------------------------------------------------------------------------
-// One wavefront per pose pair (i <= j).  Lane (r,c), r = lane / 6, c = lane % 6 < 36
-// owns element (r,c) of the 6x6 block; the entry list is wave-uniform (scalar loads),
-// the factor rows are 48-byte gathers served by L2 / Infinity Cache (rows are laid out
-// pose-major, so one pair touches two contiguous row ranges).
-// Output: lower storage of the symmetric S, row-major with leading dimension ld:
-// block (i,j), i<j, is written transposed at rows j*D.., cols i*D..; diagonal blocks in
-// full.  Masked parameters: S(idx,idx) = 1e6 (BundleAdjuster.cpp:587-598) — their rows
-// and columns are already zero because k_landmarks zeroed the Jacobian columns.
+// Off-diagonal blocks of S from the static gather lists.  Lane (r, c0): r = row of the 6x6 block,
+// c0 = 0 or 3; the factor rows are 48-byte gathers served by L2 / Infinity Cache (rows are laid
+// out pose-major, so one pair touches two contiguous row ranges).
+// Output: lower storage of the symmetric S, row-major with leading dimension ld: block (i,j),
+// i<j, is written transposed at rows j*D.., cols i*D..  Masked parameters: S(idx,idx) = 1e6
+// (BundleAdjuster.cpp:587-598) is written by k_gather_S_diag — their rows and columns are
+// already zero because k_landmarks zeroed the Jacobian columns.
+// Five pose pairs per wavefront, one per 12-lane slot: a lane owns 3 elements (r, c0..c0+2) of
+// its pair's 6x6 block and walks that pair's entry list alone — no partial blocks, no LDS, no
+// barrier.  Short lists (configs[3]: 2.3 entries per pair on average) no longer leave four of the
+// five slots idle, and for long lists the five pairs of a wave (neighbours in the sorted order:
+// similar co-visibility, similar length) keep all slots busy just as the five-way split of one
+// list did.  The terms of a block are added in entry order.
 __global__ void __launch_bounds__(256)
 k_gather_S(uint32_t npairs, const uint32_t* __restrict__ pair_ptr,
-           const uint2* __restrict__ pair_ij, const uint2* __restrict__ pair_ent,
-           const double* __restrict__ frow, int D, uint32_t ld,
-           const uint16_t* __restrict__ mask_opt, int write_fixed, double* __restrict__ A) {
-  // 60 lanes work: 5 entry slots x 12 lanes; a lane owns 3 elements (r, c0..c0+2) of the
-  // 6x6 block for the entries of its slot (entry index = slot mod 5); the 5 partial
-  // blocks are added in a fixed order through LDS.
-  __shared__ double red[4][5][36];
+            const uint2* __restrict__ pair_ij, const uint2* __restrict__ pair_ent,
+            const double* __restrict__ frow, int D, uint32_t ld, double* __restrict__ A) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t pair = blockIdx.x * 4 + w;
-  const bool valid = pair < npairs;
+  if (lane >= 60) return;
   const int slot = lane / 12, t = lane - 12 * slot;
+  const uint32_t pair = (blockIdx.x * 4 + w) * 5 + slot;
+  if (pair >= npairs) return;
   const int r = t >> 1, c0 = (t & 1) * 3;
+  const uint32_t e0 = pair_ptr[pair], e1 = pair_ptr[pair + 1];
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  if (valid && lane < 60) {
-    const uint32_t e0 = pair_ptr[pair], e1 = pair_ptr[pair + 1];
-    uint32_t e = e0 + slot;
-    for (; e + 5 < e1; e += 10) {
-      const uint2 p0 = pair_ent[e], p1 = pair_ent[e + 5];
-      const double* ra0 = frow + (size_t)p0.x * kRow;
-      const double* rb0 = frow + (size_t)p0.y * kRow + c0;
-      const double* ra1 = frow + (size_t)p1.x * kRow;
-      const double* rb1 = frow + (size_t)p1.y * kRow + c0;
-      const double a0 = ra0[r], b00 = rb0[0], b01 = rb0[1], b02 = rb0[2];
-      const double a1 = ra1[r], b10 = rb1[0], b11 = rb1[1], b12 = rb1[2];
-      acc0 += a0 * b00; acc1 += a0 * b01; acc2 += a0 * b02;
-      acc0 += a1 * b10; acc1 += a1 * b11; acc2 += a1 * b12;
-    }
-    for (; e < e1; e += 5) {
-      const uint2 p0 = pair_ent[e];
-      const double a0 = frow[(size_t)p0.x * kRow + r];
-      const double* rb0 = frow + (size_t)p0.y * kRow + c0;
-      acc0 += a0 * rb0[0]; acc1 += a0 * rb0[1]; acc2 += a0 * rb0[2];
-    }
+  uint32_t e = e0;
+  for (; e + 1 < e1; e += 2) {
+    const uint2 p0 = pair_ent[e], p1 = pair_ent[e + 1];
+    const double a0 = frow[(size_t)p0.x * kRow + r], a1 = frow[(size_t)p1.x * kRow + r];
+    const double* rb0 = frow + (size_t)p0.y * kRow + c0;
+    const double* rb1 = frow + (size_t)p1.y * kRow + c0;
+    const double b00 = rb0[0], b01 = rb0[1], b02 = rb0[2], b10 = rb1[0], b11 = rb1[1], b12 = rb1[2];
+    acc0 += a0 * b00; acc1 += a0 * b01; acc2 += a0 * b02;
+    acc0 += a1 * b10; acc1 += a1 * b11; acc2 += a1 * b12;
   }
-  if (lane < 60) {
-    red[w][slot][r * 6 + c0] = acc0;
-    red[w][slot][r * 6 + c0 + 1] = acc1;
-    red[w][slot][r * 6 + c0 + 2] = acc2;
+  if (e < e1) {
+    const uint2 p0 = pair_ent[e];
+    const double a0 = frow[(size_t)p0.x * kRow + r];
+    const double* rb0 = frow + (size_t)p0.y * kRow + c0;
+    acc0 += a0 * rb0[0]; acc1 += a0 * rb0[1]; acc2 += a0 * rb0[2];
   }
-  __syncthreads();
-  if (!valid) return;
   const uint2 ij = pair_ij[pair];
   const uint32_t i = ij.x, j = ij.y;
-  if (lane < 36) {
-    const int rr = lane / 6, cc = lane - 6 * rr;
-    double acc = ((red[w][0][lane] + red[w][1][lane]) + (red[w][2][lane] + red[w][3][lane])) +
-                 red[w][4][lane];
-    if (i == j) {
-      // only the cross terms of observations whose two sides sit on the same pose come here;
-      // the block itself was written by k_gather_S_diag (stream order), single writer
-      A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] += acc;
-    } else {
-      A[((size_t)j * D + cc) * ld + (size_t)i * D + rr] = acc;
-    }
+  if (i == j) {
+    // cross terms of observations whose two sides sit on the same pose; the block itself was
+    // written by k_gather_S_diag (stream order), single writer
+    double* o = A + ((size_t)i * D + r) * ld + (size_t)i * D + c0;
+    o[0] += acc0; o[1] += acc1; o[2] += acc2;
+  } else {
+    double* o = A + ((size_t)j * D + c0) * ld + (size_t)i * D + r;
+    o[0] = acc0; o[ld] = acc1; o[2 * (size_t)ld] = acc2;
   }
 }
 
@@ -272,10 +259,8 @@ int launch_gather_S(Engine* e) {
   }
   if (st.n_pairs > 0) {
     e->prof_begin(e->ev_gather);
-    hipLaunchKernelGGL(k_gather_S, dim3((st.n_pairs + 3) / 4), dim3(256), 0, e->stream, st.n_pairs,
-                       e->pair_ptr.p, e->pair_ij.p, e->pair_ent.p, e->frow.p, e->pose_dim, ld,
-                       e->pose_mask.p + st.P /* masks by opt id live after the by-id masks */,
-                       write_fixed, e->A.p);
+    hipLaunchKernelGGL(k_gather_S, dim3((st.n_pairs + 19) / 20), dim3(256), 0, e->stream, st.n_pairs,
+                       e->pair_ptr.p, e->pair_ij.p, e->pair_ent.p, e->frow.p, e->pose_dim, ld, e->A.p);
     e->prof_end(e->ev_gather);
     BAE_HIP(hipGetLastError());
   }
