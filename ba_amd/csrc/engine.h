@@ -82,6 +82,7 @@ struct Engine {
   int lm_dim = 1, pose_dim = 6, device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // bulk trailing updates of the factorisation (look-ahead)
+  const double* A_cleared = nullptr;  // the allocation of A whose whole square has been zeroed once
   std::vector<hipEvent_t> ev_panel, ev_bulk;
   bool own_stream = false;
   std::string err;

@@ -555,6 +555,7 @@ static int build_structure(Engine* e) {
   BAE_HIP(e->lm_vinv.alloc(L1 * LM1 * LM1)); BAE_HIP(e->lm_bl.alloc(L1 * LM1));
   BAE_HIP(hipMemsetAsync(e->lm_vinv.p, 0, e->lm_vinv.bytes(), e->stream));
   BAE_HIP(hipMemsetAsync(e->lm_bl.p, 0, e->lm_bl.bytes(), e->stream));
+  e->A_cleared = nullptr;  // new structure (possibly a new allocation / leading dimension): clear the square once
   BAE_HIP(e->A.alloc((size_t)(st.ld + 1) * st.ld));
   BAE_HIP(e->rhs_p.alloc(st.ld)); BAE_HIP(e->rhs_sc.alloc(st.ld));
   BAE_HIP(e->gn_p.alloc(st.ld)); BAE_HIP(e->step_p.alloc(st.ld));

@@ -232,11 +232,38 @@ int launch_pack_lower(Engine* e, int unpack) {
   return 0;
 }
 
+// Zeroes the 64x64 tiles of the lower triangle (tile row >= tile column) of the row-major
+// storage: half the bytes of clearing the square.  Nothing reads or writes the strictly upper
+// tiles except the corner of a diagonal D x D block that straddles a tile boundary, and that
+// corner is rewritten in full by k_gather_S_diag every iteration.
+__global__ void __launch_bounds__(256)
+k_zero_lower_tiles(double* __restrict__ A, uint32_t ld, uint32_t nblk) {
+  const uint32_t t = blockIdx.x;
+  uint32_t i = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((uint64_t)(i + 1) * (i + 2) / 2 <= t) ++i;
+  while ((uint64_t)i * (i + 1) / 2 > t) --i;
+  const uint32_t c = t - (uint32_t)((uint64_t)i * (i + 1) / 2);
+  if (i >= nblk) return;
+  double2* base = reinterpret_cast<double2*>(A + ((size_t)i * 64) * ld + (size_t)c * 64);
+  const int tid = threadIdx.x, col2 = tid & 31, r0 = tid >> 5;  // 32 double2 per row, 8 rows per pass
+#pragma unroll
+  for (int r = r0; r < 64; r += 8) base[(size_t)r * (ld / 2) + col2] = make_double2(0.0, 0.0);
+}
+
 int launch_gather_S(Engine* e) {
   const Structure& st = e->st;
   const uint32_t n = st.n, ld = st.ld, n_pad = ld;
-  // zero the whole lower storage + rhs row, then identity on the padding
-  BAE_HIP(hipMemsetAsync(e->A.p, 0, (size_t)(n_pad + 1) * ld * sizeof(double), e->stream));
+  // zero the lower storage + rhs row (the whole square once per structure, so that the unused
+  // upper tiles never hold garbage), then identity on the padding
+  if (e->A_cleared != e->A.p) {
+    BAE_HIP(hipMemsetAsync(e->A.p, 0, (size_t)(n_pad + 1) * ld * sizeof(double), e->stream));
+    e->A_cleared = e->A.p;
+  } else {
+    const uint32_t nblk = n_pad / 64;
+    hipLaunchKernelGGL(k_zero_lower_tiles, dim3(nblk * (nblk + 1) / 2), dim3(256), 0, e->stream, e->A.p, ld, nblk);
+    BAE_HIP(hipGetLastError());
+    BAE_HIP(hipMemsetAsync(e->A.p + (size_t)n_pad * ld, 0, (size_t)ld * sizeof(double), e->stream));
+  }
   // fixed entries (padding identity, 1e6 on masked parameters) are written by shard 0
   // only, so that the cross-shard sum of S leaves them exact
   const int write_fixed = (e->rank == 0) ? 1 : 0;
