@@ -6,17 +6,19 @@
 // multiple of 64), tile-sparse at 64x64 granularity, three blocking levels, with look-ahead:
 //
 //   for every outer panel J of KOUT tile columns (4; 8 for n >= 16k; 16 for n >= 32k)
-//     for every sub-panel of 4 tile columns, for every 64-column tile jj of it      [stream s0]
+//     for every sub-panel of 4 (8 for n >= 32k) tile columns, for every 64-column tile jj  [stream s0]
 //       k_trsm_op      rows below the diagonal tile: X = A L_jj^-T D (blocked substitution on
 //                      the matrix cores from the "factor packet" of tile jj)
-//       k_step_update  update of the sub-panel's remaining tile columns with column jj (K = 64);
-//                      its workgroup (0,0) also factorises the next diagonal tile in LDS and
-//                      publishes that tile's factor packet
-//     k_step_update    after a sub-panel: the rest of the outer panel with its 4 columns (K = 256)
-//     k_step_update    (a) the next panel's columns, K = 64 KOUT, + its first diagonal tile
-//     k_update128 / k_update2   (b) everything right of the next panel, K = 64 KOUT  [stream s1]
-//                      concurrently with the next panel's serial chain
-//   k_linvT, k_backward   L^T x = y, one tile row per launch
+//       k_step_update  update of the sub-panel's remaining tile columns with column jj (K = 64)
+//                      [n >= 32k, left-looking: of column jj + 1 with all earlier columns of the
+//                      sub-panel]; its workgroup (0,0) also factorises the next diagonal tile in
+//                      LDS and publishes that tile's factor packet
+//     k_step_update    after a sub-panel: the rest of the outer panel with its columns
+//     k_step_update (+ k_update128<true> for the rows below the panel when there are >= 128)
+//                      (a) the next panel's columns, K = 64 KOUT, + its first diagonal tile
+//     k_update128<false> / k_update2   (b) everything right of the next panel, K = 64 KOUT
+//                      concurrently with the next panel's serial chain               [stream s1]
+//   k_linvT, k_backward2  L^T x = y, two tile rows per launch
 //
 // All products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64 — the one true dense
 // contraction of the path).  L carries sqrt|pivot| and D the pivot signs: for SPD systems it
