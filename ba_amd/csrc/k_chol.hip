@@ -5,7 +5,7 @@
 // right-looking L D L^T, D = diag(+-1), on the LOWER storage (row-major, leading dimension ld, a
 // multiple of 64), tile-sparse at 64x64 granularity, three blocking levels, with look-ahead:
 //
-//   for every outer panel J of KOUT tile columns (4; 8 for n >= 16k; 16 for n >= 32k)
+//   for every outer panel J of KOUT tile columns (4; 8 for n >= 16k; 16 for n >= 25k)
 //     for every sub-panel of 4 (8 for n >= 32k) tile columns, for every 64-column tile jj  [stream s0]
 //       k_trsm_op      rows below the diagonal tile: X = A L_jj^-T D (blocked substitution on
 //                      the matrix cores from the "factor packet" of tile jj)
@@ -1092,7 +1092,7 @@ int factor_tile_pattern(Engine* e) {
 
 uint32_t choose_kout(uint32_t nblk) {
   static const uint32_t kout_env = getenv("BA_HIP_KOUT") ? (uint32_t)atoi(getenv("BA_HIP_KOUT")) : 0;
-  return kout_env ? kout_env : (nblk >= 512 ? 16u : nblk >= 256 ? 8u : 4u);
+  return kout_env ? kout_env : (nblk >= 400 ? 16u : nblk >= 256 ? 8u : 4u);  // measured at 94 / 282 / 469 / 938 tiles
 }
 
 // ---------------------------------------------------------------------------------
