@@ -1065,12 +1065,13 @@ def test_conditioning_error_sums(oracle_lib):
 
 
 @pytest.mark.gpu
-def test_dense_solve_with_1024_column_panels():
+@pytest.mark.parametrize("n", [26000, 33000])
+def test_dense_solve_with_1024_column_panels(n):
     """n = 33 000 (516 tiles): the schedule of BASELINE.json configs[3] — outer panels of 16 tiles,
     left-looking sub-panels of 8, k_update128 for the bulk and for the rectangle under the next
     panel — on a dense diagonally dominant matrix, checked through the residual of the solve and
-    bitwise repeatability."""
-    n = 33000
+    bitwise repeatability.  n = 26 000 (407 tiles): 16-tile panels with right-looking sub-panels
+    of 4."""
     rng = np.random.default_rng(9)
     a = rng.random((n, n), dtype=np.float32).astype(np.float64)
     a -= 0.5
