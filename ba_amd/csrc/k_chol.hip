@@ -942,7 +942,7 @@ k_linvT(const double* __restrict__ opbuf, const double* __restrict__ dsgn, doubl
 // Workgroup 0 also stores x_i.
 __global__ void __launch_bounds__(256)
 k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
-           const double* __restrict__ linvT, double* __restrict__ x) {
+           const double* __restrict__ linvT, double* __restrict__ x, const uint8_t* __restrict__ nz) {
   __shared__ double xi[NB];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x;
@@ -963,7 +963,7 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
   }
   __syncthreads();
   const uint32_t col = blockIdx.x * 256 + tid;
-  if (col < i * NB) {
+  if (col < i * NB && (!nz || nz[(size_t)i * nblk + (col >> 6)])) {  // structurally zero tiles of L: nothing to subtract
     const double* Li = A + ((size_t)i * NB) * ld + col;
     double s = 0.0;
 #pragma unroll 16
@@ -987,7 +987,7 @@ __device__ __forceinline__ void matvec64(const double* __restrict__ M, size_t st
 }
 __global__ void __launch_bounds__(256)
 k_backward2(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
-            const double* __restrict__ linvT, double* __restrict__ x) {
+            const double* __restrict__ linvT, double* __restrict__ x, const uint8_t* __restrict__ nz) {
   __shared__ double x1[NB], x0[NB], y0[NB];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x;
@@ -1020,24 +1020,32 @@ k_backward2(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
     const double* L1 = A + ((size_t)(i + 1) * NB) * ld + col;
     const double* L0 = A + ((size_t)i * NB) * ld + col;
     double s1 = 0.0, s0 = 0.0;
+    const bool on1 = !nz || nz[(size_t)(i + 1) * nblk + (col >> 6)], on0 = !nz || nz[(size_t)i * nblk + (col >> 6)];
+    if (on1) {
 #pragma unroll 16
-    for (int r = 0; r < NB; ++r) { s1 += L1[(size_t)r * ld] * x1[r]; s0 += L0[(size_t)r * ld] * x0[r]; }
-    A[((size_t)nblk * NB) * ld + col] -= (s1 + s0);
+      for (int r = 0; r < NB; ++r) s1 += L1[(size_t)r * ld] * x1[r];
+    }
+    if (on0) {
+#pragma unroll 16
+      for (int r = 0; r < NB; ++r) s0 += L0[(size_t)r * ld] * x0[r];
+    }
+    if (on1 || on0) A[((size_t)nblk * NB) * ld + col] -= (s1 + s0);
   }
 }
 
 // the whole backward substitution: pairs of block rows, a single one first if the count is odd
-static void launch_backward(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, const double* linvT, double* dx) {
+static void launch_backward(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, const double* linvT, double* dx,
+                            const uint8_t* nz) {
   uint32_t ii = nblk;
   if (ii & 1u) {
     --ii;
     const uint32_t cols = ii * NB, grid = cols == 0 ? 1 : (cols + 255) / 256;
-    hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx);
+    hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx, nz);
   }
   while (ii >= 2) {
     ii -= 2;
     const uint32_t cols = ii * NB, grid = cols == 0 ? 1 : (cols + 255) / 256;
-    hipLaunchKernelGGL(k_backward2, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx);
+    hipLaunchKernelGGL(k_backward2, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx, nz);
   }
 }
 
@@ -1432,7 +1440,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
   BAE_HIP(hipGetLastError());
   BAE_HIP(hipStreamSynchronize(s1));
   hipLaunchKernelGGL(k_linvT, dim3(nblk), dim3(256), 0, s0, (const double*)opbuf, (const double*)dsgn, linvT);
-  launch_backward(s0, dA, ld, nblk, (const double*)linvT, dx);
+  launch_backward(s0, dA, ld, nblk, (const double*)linvT, dx, nz);
   BAE_HIP(hipGetLastError());
   // the pivot status of every owner
   int st = 0;
@@ -1522,7 +1530,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   BAE_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_linvT, dim3(nblk), dim3(256), 0, s0, (const double*)opbuf, (const double*)dsgn,
                        linvT);
-  launch_backward(s0, dA, ld, nblk, (const double*)linvT, dx);
+  launch_backward(s0, dA, ld, nblk, (const double*)linvT, dx, nz);
   BAE_HIP(hipGetLastError());
   int st = 0;
   BAE_HIP(hipMemcpyAsync(&st, e->flags.p, sizeof(int), hipMemcpyDeviceToHost, s0));
