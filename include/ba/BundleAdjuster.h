@@ -720,8 +720,10 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SolveInternal(
         coef_rhs = factor * trust_region_size_ / delta_sd_norm;  // :947-950
       } else {
         if (!gn_computed) {
-          if (num_active_poses_ > 0) {
-            summary_.result = Success;
+          {
+            // CalculateGn only with active poses (:959-964); GetLandmarkDelta always (:966-967) —
+            // the engine skips the factorisation itself when n == 0 and still back-substitutes
+            if (num_active_poses_ > 0) summary_.result = Success;
             const int rc = ba_hip_solve_gn(engine_);
             if (rc < 0) { Check(rc, "ba_hip_solve_gn"); return false; }
             if (rc == BA_HIP_FACTORIZATION_ERROR) { summary_.result = FactorizationError; return false; }
@@ -769,8 +771,9 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SolveInternal(
       }
     }
   } else {
-    if (num_active_poses_ > 0) {
-      summary_.result = Success;
+    {
+      // :1089-1094 CalculateGn only with active poses; :1105-1106 GetLandmarkDelta always
+      if (num_active_poses_ > 0) summary_.result = Success;
       const int rc = ba_hip_solve_gn(engine_);
       if (rc < 0) { Check(rc, "ba_hip_solve_gn"); return false; }
       if (rc == BA_HIP_FACTORIZATION_ERROR) { summary_.result = FactorizationError; return false; }

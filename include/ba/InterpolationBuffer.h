@@ -8,12 +8,15 @@
 //
 // ElementType must provide `time`, `operator*(ScalarType)` and `operator+(ElementType)`.
 //
-// Difference from the reference: the element AT OR BEFORE a query time is found by binary
-// search instead of an index guess from the average sampling interval followed by a walk.
-// Results are identical except when a query time coincides exactly with a stored sample: the
-// reference's answer then depends on which side its guess started from (it may report the
-// previous index and make GetRange emit that sample twice, once as a zero-length interval);
-// here the coinciding sample is always reported once.
+// Behaviour is pinned against the reference's own header (it compiles stand-alone): the outputs
+// of /root/reference/include/ba/InterpolationBuffer.h for a few hundred queries are committed as
+// tests/golden/interp_buffer.json and this header must reproduce them bit for bit, including the
+// index it reports when a query time coincides with a stored sample (the bracketing interval is
+// found from an index guess, time / average interval, followed by a walk; a coinciding sample k
+// is reported as interval k-1 with weight 1 when the guess started left of it, and GetRange
+// then emits that sample twice — :147-191).  Inside [start_time, end_time] only: outside it the
+// reference's index guess is a negative double converted to size_t (undefined); callers are told
+// to check HasElement first (:118-121), and GetRange trims to the covered span.
 #ifndef BA_AMD_INTERPOLATION_BUFFER_H
 #define BA_AMD_INTERPOLATION_BUFFER_H
 
@@ -59,22 +62,33 @@ struct InterpolationBufferT {
     return GetElement(time, &index);
   }
 
-  // value at `time` (clamped to the first / last sample outside the covered span);
-  // *index = the stored sample at or before `time`
+  // value at `time`; *index = left end of the interval the value was interpolated in.
+  // Search as the reference does it (:147-191): start at floor((time - start_time) / average_dt),
+  // clamped to the stored range, then walk towards `time`.  A walk from the right stops at the
+  // first interval whose left sample is <= time, a walk from the left at the first interval whose
+  // right sample is >= time — the two differ exactly when `time` is a stored sample.
   ElementType GetElement(const ScalarType time, std::size_t* index) const {
     assert(!elements.empty());
     const std::size_t n = elements.size();
-    if (!(time > elements.front().time)) { *index = 0; return elements.front(); }
-    if (!(time < elements.back().time)) { *index = n - 1; return elements.back(); }
-    // first sample strictly after `time`
-    std::size_t lo = 0, hi = n - 1;  // invariant: elements[lo].time <= time < elements[hi].time
-    while (hi - lo > 1) {
-      const std::size_t mid = lo + (hi - lo) / 2;
-      if (elements[mid].time <= time) lo = mid; else hi = mid;
+    const ScalarType pos = (time - start_time) / average_dt;
+    std::size_t k = pos > ScalarType(0) ? (std::size_t)pos : 0;  // (NaN / negative -> 0: out-of-span input)
+    if (k > n - 1) k = n - 1;
+    std::size_t left;  // interpolate between elements[left] and elements[left + 1]
+    if (elements[k].time > time) {
+      if (k == 0) { *index = 0; return elements.front(); }
+      while (k > 1 && elements[k - 1].time > time) --k;
+      left = k - 1;
+    } else {
+      if (k == n - 1) { *index = k; return elements.back(); }
+      while (k + 1 < n && elements[k + 1].time < time) ++k;
+      if (k == n - 1) { *index = k; return elements.back(); }  // time beyond the last sample
+      left = k;
     }
-    *index = lo;
-    const ScalarType u = ScalarType(time - elements[lo].time) / ScalarType(elements[hi].time - elements[lo].time);
-    ElementType res = elements[lo] * (ScalarType(1) - u) + elements[hi] * u;
+    *index = left;
+    const ElementType& e0 = elements[left];
+    const ElementType& e1 = elements[left + 1];
+    const ScalarType u = (time - e0.time) / (e1.time - e0.time);
+    ElementType res = e0 * (1 - u) + e1 * u;
     res.time = time;
     return res;
   }

@@ -1088,3 +1088,29 @@ def test_dense_solve_with_1024_column_panels(n):
     ax += a.T @ x
     ax -= a.diagonal() * x
     assert rel_err(ax, b) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lm_dim", [1, 3])
+@pytest.mark.parametrize("use_dogleg", [0, 1])
+def test_landmarks_only_solve_with_all_poses_fixed(oracle_lib, lm_dim, use_dogleg):
+    """Every pose inactive, landmarks active: the reference skips CalculateGn but still calls
+    GetLandmarkDelta (BundleAdjuster.cpp:959-967, 1089-1106), so the landmarks move by
+    delta_l = V^-1 rhs_l.  (Round-1 finding: the host class skipped the back-substitution too.)"""
+    po = oracle_lib
+    sc = scene.make_scene(20, 80, 6, lm_dim=lm_dim, seed=33)
+    pa = np.zeros(sc.num_poses, dtype=np.uint8)
+    o, h = both(po, sc, lm_dim, active=pa, use_dogleg=use_dogleg)
+    lm0 = np.array(sc.landmarks, dtype=float)
+    for _ in range(3):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        assert abs(so.proj_error - sh.proj_error) < 1e-9 * so.proj_error
+        assert abs(so.delta_norm - sh.delta_norm) < 1e-8 * max(so.delta_norm, 1e-12)
+        assert rel_err(h.delta_l(), o.delta_l()) < 1e-10
+    assert np.abs(np.asarray(h.landmarks()) - lm0).max() > 1e-6   # the landmarks did move
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-10
+    th, _, _ = h.poses()
+    assert rel_err(th, sc.poses) < 1e-15                          # the poses did not

@@ -1,0 +1,171 @@
+"""Device math compiled for the host vs the oracle, no GPU needed.
+
+`ba_amd/lib/libba_hostcheck.so` is a host build of the very headers the gfx950 kernels include
+(`ba_amd/csrc/dmath.h`: closed-form projection Jacobians; `dpose.h`: unary / binary / IMU
+residual blocks).  The oracle evaluates the reference's literal matrix chains
+(/root/reference/include/ba/parallel_algos.h:35-152, 178-358; src/BundleAdjuster.cpp:1392-1482).
+Agreement here is the CPU-side gate on the kernels' arithmetic; the `-m gpu` tests repeat it
+on the device through the C-ABI.
+
+Tolerance: both sides are FP64 evaluations of the same derivative with different
+association order; 1e-11 relative to the block's norm (observed 1e-14..1e-13).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from ba_amd import scene
+from helpers import accepted_obs, fill, gn_options, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "ba_amd", "lib", "libba_hostcheck.so")
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+@pytest.fixture(scope="module")
+def hc():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(LIB)
+
+
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_projection_jacobians_of_the_kernels_match_the_oracle(oracle_lib, hc, lm_dim):
+    po = oracle_lib
+    sc = scene.make_scene(30, 60, 5, lm_dim=lm_dim, seed=17)
+    t_vs = np.array([0.05, -0.02, 0.1, 0.0, 0.0, 0.0, 1.0])
+    t_vs[3:] = scene.quat_exp(np.array([0.02, -0.03, 0.01]))
+    o = po.OracleBundleAdjuster(lm_dim, 6)
+    o.Init(gn_options(po, apply_results=0))
+    o.AddCamera(sc.cam_params, t_vs)
+    o.add_poses(sc.poses)
+    o.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    o.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    # x_s (LmSize 1) as Solve() forms it (BundleAdjuster.cpp:288-296): T_sw(ref) x_w, normalised
+    o.Solve(1)
+    jm_o, jr_o, jl_o = o.proj_jacobians()
+    r_o = o.proj_residuals()
+    acc = accepted_obs(sc)
+    cam = np.asarray(sc.cam_params, dtype=np.float64)
+    nsel = sc.obs_per_landmark + (1 if lm_dim == 1 else 0)
+    zs = [sc.obs_z[i] for i in range(len(sc.obs_pose)) if not (lm_dim == 1 and i % nsel == 0)]
+    worst = 0.0
+    for rid, (pm, pr, l) in enumerate(acc):
+        xw = np.asarray(sc.landmarks[l], dtype=np.float64)
+        if lm_dim == 1:
+            t_ws = po.se3_mul(np.asarray(sc.poses[pr], dtype=np.float64), t_vs)
+            t_sw = po.se3_inv(t_ws)
+            R = scene.quat_to_rot(t_sw[3:])
+            p = R @ xw[:3] + t_sw[:3] * xw[3]
+            nrm = np.linalg.norm(p)
+            x = np.concatenate([p / nrm, [xw[3] / nrm]])
+        else:
+            x = xw
+        r2 = np.zeros(2); jm = np.zeros(12); jr = np.zeros(12); jl = np.zeros(2 * lm_dim)
+        z = np.asarray(zs[rid], dtype=np.float64)
+        hc.ba_hostcheck_proj_jacobians(
+            lm_dim, _dp(cam), _dp(z), _dp(x), _dp(np.asarray(sc.poses[pm], dtype=np.float64)), _dp(t_vs),
+            _dp(np.asarray(sc.poses[pr], dtype=np.float64)), _dp(t_vs), int(lm_dim == 1 and pm == pr),
+            _dp(r2), _dp(jm), _dp(jr), _dp(jl))
+        worst = max(worst, rel_err(r2, r_o[rid]), rel_err(jm, jm_o[rid].ravel()),
+                    rel_err(jl, jl_o[rid].ravel()))
+        if lm_dim == 1:
+            worst = max(worst, rel_err(jr, jr_o[rid].ravel()))
+    assert len(acc) > 100
+    assert worst < 1e-11, worst
+
+
+def test_unary_and_binary_blocks_of_the_kernels_match_the_oracle(oracle_lib, hc):
+    po = oracle_lib
+    rng = np.random.default_rng(5)
+    gt, _ = scene.trajectory(8)
+    init = gt.copy()
+    for i in range(8):
+        init[i] = po.exp_decoupled(init[i], rng.normal(0, 0.03, 6))
+    o = po.OracleBundleAdjuster(0, 6)
+    o.Init(gn_options(po, apply_results=0))
+    o.add_poses(init)
+    priors, bins = [], []
+    for i in range(0, 8, 2):
+        m = rng.normal(size=(6, 6))
+        cov = 1e-3 * (m @ m.T + 6 * np.eye(6))
+        prior = po.exp_decoupled(gt[i], rng.normal(0, 0.01, 6))
+        rot = bool(i % 4 == 0)
+        o.AddUnaryConstraint(i, prior, cov, rot)
+        priors.append((i, prior, rot))
+    for i in range(7):
+        m = rng.normal(size=(6, 6))
+        cov = 1e-4 * (m @ m.T + 6 * np.eye(6))
+        t12 = po.exp_decoupled(po.se3_mul(po.se3_inv(gt[i]), gt[i + 1]), rng.normal(0, 0.003, 6))
+        w = float(rng.uniform(0.5, 2.0))
+        rot = bool(i % 3 != 0)
+        o.AddBinaryConstraint(i, i + 1, t12, cov, w, rot)
+        bins.append((i, i + 1, t12, cov, w, rot))
+    o.Solve(1)
+    for k, (i, prior, rot) in enumerate(priors):
+        J_o, r_o = o.unary_jacobian(k)
+        r6 = np.zeros(6); J = np.zeros(36)
+        hc.ba_hostcheck_unary(_dp(np.ascontiguousarray(init[i])), _dp(np.ascontiguousarray(prior)), int(rot),
+                              _dp(r6), _dp(J))
+        assert rel_err(r6, r_o) < 1e-11
+        assert rel_err(J, np.asarray(J_o).ravel()) < 1e-11
+    for k, (p1, p2, t12, cov, w, rot) in enumerate(bins):
+        dz1, dz2, r_o = o.binary_jacobians(k)
+        ci = np.linalg.inv(cov)
+        ev, evec = np.linalg.eigh(ci)
+        cis = (evec * np.sqrt(ev)) @ evec.T
+        h11 = np.zeros(225); h12 = np.zeros(225); h22 = np.zeros(225)
+        g1 = np.zeros(15); g2 = np.zeros(15)
+        eb = ctypes.c_double(); ee = ctypes.c_double()
+        hc.ba_hostcheck_binary(_dp(np.ascontiguousarray(init[p1])), _dp(np.ascontiguousarray(init[p2])),
+                               _dp(np.ascontiguousarray(t12)), _dp(np.ascontiguousarray(ci)),
+                               _dp(np.ascontiguousarray(cis)), ctypes.c_double(w), int(rot), _dp(h11), _dp(h12),
+                               _dp(h22), _dp(g1), _dp(g2), ctypes.byref(eb), ctypes.byref(ee))
+        # the kernels accumulate J^T (w Sigma^-1) J directly (jt_pp_ * j_pp_, BundleAdjuster.cpp:357-372
+        # with :1662-1668): compare with the oracle's un-whitened Jacobians
+        dz1 = np.asarray(dz1).reshape(6, 6); dz2 = np.asarray(dz2).reshape(6, 6)
+        H11 = dz1.T @ (w * ci) @ dz1
+        H12 = dz1.T @ (w * ci) @ dz2
+        H22 = dz2.T @ (w * ci) @ dz2
+        assert rel_err(h11.reshape(15, 15)[:6, :6], H11) < 1e-10
+        assert rel_err(h12.reshape(15, 15)[:6, :6], H12) < 1e-10
+        assert rel_err(h22.reshape(15, 15)[:6, :6], H22) < 1e-10
+
+
+@pytest.mark.parametrize("pose_dim", [9, 15])
+def test_imu_residual_blocks_of_the_kernels_match_the_oracle(oracle_lib, hc, pose_dim):
+    po = oracle_lib
+    P = 30
+    sc = scene.make_scene(P, 60, 5, lm_dim=1, seed=3)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    o = po.OracleBundleAdjuster(1, pose_dim)
+    opt = gn_options(po, apply_results=0)
+    o.Init(opt)
+    o.SetGravity(sc.gravity)
+    fill(o, sc)
+    for i in range(P - 1):
+        o.AddImuResidual(i, i + 1, sc.imu_meas[i])
+    o.Solve(1)
+    g = np.asarray(sc.gravity, dtype=np.float64)
+    r6 = np.array([opt.gyro_sigma ** 2] * 3 + [opt.accel_sigma ** 2] * 3)
+    rb6 = np.array([opt.gyro_bias_sigma ** 2] * 3 + [opt.accel_bias_sigma ** 2] * 3)
+    for i in range(0, P - 1, 4):
+        dz1_o, dz2_o, ci_o, r_o = o.imu_jacobians(i)
+        p1 = np.concatenate([sc.poses[i], sc.init_vel[i], sc.init_bias[i]]).astype(np.float64)
+        p2 = np.concatenate([sc.poses[i + 1], sc.init_vel[i + 1], sc.init_bias[i + 1]]).astype(np.float64)
+        meas = np.ascontiguousarray(np.asarray(sc.imu_meas[i], dtype=np.float64))
+        r15 = np.zeros(15); dz1 = np.zeros(225); dz2 = np.zeros(225); ci = np.zeros(225)
+        hc.ba_hostcheck_imu(_dp(p1), _dp(p2), _dp(meas), int(meas.shape[0]), _dp(g), _dp(r6), _dp(rb6),
+                            int(pose_dim), _dp(r15), _dp(dz1), _dp(dz2), _dp(ci))
+        R = pose_dim
+        sl = np.s_[:R, :R]
+        assert rel_err(r15[:R], np.asarray(r_o)[:R]) < 1e-10
+        assert rel_err(dz1.reshape(15, 15)[sl], np.asarray(dz1_o).reshape(15, 15)[sl]) < 1e-9
+        assert rel_err(dz2.reshape(15, 15)[sl], np.asarray(dz2_o).reshape(15, 15)[sl]) < 1e-9
+        assert rel_err(ci.reshape(15, 15)[sl], np.asarray(ci_o).reshape(15, 15)[sl]) < 1e-8
