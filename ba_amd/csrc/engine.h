@@ -183,7 +183,7 @@ struct Engine {
   // optional per-kernel timing (ba_hip_set_profiling)
   bool profiling = false;
   ba_hip_kernel_stats kstats = {};
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_syrk, ev_gather, ev_landmarks;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_syrk, ev_gather, ev_landmarks, ev_imu;
   void prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s = nullptr) {
     if (!profiling) return;
     hipEvent_t a, b;
@@ -233,6 +233,7 @@ uint32_t choose_kout(uint32_t nblk);
 bool dist_solve_enabled(const Engine* e);
 int dist_reduce_scatter_S(Engine* e);
 int launch_imu_residual_vectors(Engine* e, double* d_r15);
+int check_solve_residual(Engine* e, const double* dS, const double* dx, const double* db, double* out2);
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz);
 
 }  // namespace bae

@@ -36,6 +36,7 @@ void Engine::prof_collect() {
   drain(ev_syrk, kstats.syrk_ms, kstats.syrk_launches);
   drain(ev_gather, kstats.gather_ms, kstats.gather_launches);
   drain(ev_landmarks, kstats.landmarks_ms, kstats.landmarks_launches);
+  drain(ev_imu, kstats.imu_ms, kstats.imu_launches);
 }
 int Engine::fail_msg(const char* what) {
   err = what;
@@ -77,6 +78,24 @@ static unsigned host_threads() {
   if (const char* v = getenv("BA_HIP_HOST_THREADS")) return (unsigned)std::max(1, atoi(v));
   const unsigned hc = std::thread::hardware_concurrency();
   return std::min(16u, std::max(1u, hc));
+}
+
+// gravity | measurement noise diag (gyro^2 x3, accel^2 x3) | bias random walk.  Not part of the
+// structure: refreshed by every ba_hip_begin_solve, so SetGravity / SetImuCalibration / new option
+// sigmas between two Solve() calls need no ba_hip_finalize.
+static int upload_imu_consts(Engine* e) {
+  const Problem& pb = e->prob;
+  std::vector<double> c(15);
+  for (int i = 0; i < 3; ++i) {
+    c[i] = pb.gravity[i];
+    c[3 + i] = e->opt.gyro_sigma * e->opt.gyro_sigma;
+    c[6 + i] = e->opt.accel_sigma * e->opt.accel_sigma;
+    c[9 + i] = e->opt.gyro_bias_sigma * e->opt.gyro_bias_sigma;
+    c[12 + i] = e->opt.accel_bias_sigma * e->opt.accel_bias_sigma;
+  }
+  if (pb.imu_noise.size() == 12)  // ImuCalibrationT::r / r_b given explicitly (SetImuCalibration)
+    for (int i = 0; i < 12; ++i) c[3 + i] = pb.imu_noise[i];
+  return upload(e, e->imu_consts, c);
 }
 
 // Build everything that depends only on the problem graph (not on the state).
@@ -481,18 +500,7 @@ static int build_structure(Engine* e) {
   {
     std::vector<double> ones(std::max<uint32_t>(nu, 1), 1.0);
     if ((rc = upload(e, e->un_scale, ones))) return rc;
-    // gravity | measurement noise diag (gyro^2 x3, accel^2 x3) | bias random walk
-    std::vector<double> c(15);
-    for (int i = 0; i < 3; ++i) {
-      c[i] = pb.gravity[i];
-      c[3 + i] = e->opt.gyro_sigma * e->opt.gyro_sigma;
-      c[6 + i] = e->opt.accel_sigma * e->opt.accel_sigma;
-      c[9 + i] = e->opt.gyro_bias_sigma * e->opt.gyro_bias_sigma;
-      c[12 + i] = e->opt.accel_bias_sigma * e->opt.accel_bias_sigma;
-    }
-    if (pb.imu_noise.size() == 12)  // ImuCalibrationT::r / r_b given explicitly (SetImuCalibration)
-      for (int i = 0; i < 12; ++i) c[3 + i] = pb.imu_noise[i];
-    if ((rc = upload(e, e->imu_consts, c))) return rc;
+    if ((rc = upload_imu_consts(e))) return rc;
     const size_t nr1 = std::max<size_t>(nres, 1);
     BAE_HIP(e->pp_h.alloc(nr1 * 3 * 225)); BAE_HIP(e->pp_g.alloc(nr1 * 30));
     BAE_HIP(e->pp_dz.alloc(nr1 * 2 * 225)); BAE_HIP(e->pp_info.alloc(nr1 * 225));
@@ -827,8 +835,7 @@ int ba_hip_set_imu_noise(ba_hip_engine* h, const double r6[6], const double rb6[
     e->prob.imu_noise.assign(r6, r6 + 6);
     e->prob.imu_noise.insert(e->prob.imu_noise.end(), rb6, rb6 + 6);
   }
-  e->finalized = false;
-  return 0;
+  return 0;  // not structural: uploaded by the next ba_hip_begin_solve
 }
 
 int ba_hip_set_inertial_covariance_once(ba_hip_engine* h, int on, int reset) {
@@ -865,7 +872,9 @@ int ba_hip_begin_solve(ba_hip_engine* h) {
   BAE_HIP(hipSetDevice(e->device));
   if (!e->prob.pose_cam_params.empty() && e->prob.pose_cam_params.size() != 4 * (size_t)e->prob.num_poses)
     return e->fail_msg("per-pose camera parameters: one [fx,fy,u0,v0] per pose expected");
-  int rc = launch_pose_prep(e);
+  int rc = upload_imu_consts(e);
+  if (rc) return rc;
+  rc = launch_pose_prep(e);
   if (rc) return rc;
   rc = launch_begin_solve(e);
   if (rc) return rc;
@@ -1240,9 +1249,47 @@ int ba_hip_get_unary_scales(ba_hip_engine* h, double* scale) {
   return 0;
 }
 
+int ba_hip_check_solve(ba_hip_engine* h, double* residual_norm, double* rhs_norm) {
+  ENG(h);
+  NEED_FINAL();
+  BAE_HIP(hipSetDevice(e->device));
+  if (!(e->factored && e->opt.keep_reduced_system && e->A_keep.p))
+    return e->fail_msg("ba_hip_check_solve needs keep_reduced_system and a finished ba_hip_solve_gn");
+  if (e->allreduce && e->nranks > 1) return e->fail_msg("ba_hip_check_solve: single shard only");
+  double o[2];
+  int rc = check_solve_residual(e, e->A_keep.p, e->gn_p.p, e->rhs_sc.p, o);
+  if (rc) return rc;
+  if (residual_norm) *residual_norm = o[0];
+  if (rhs_norm) *rhs_norm = o[1];
+  return 0;
+}
+
 int ba_hip_get_timers(ba_hip_engine* h, ba_hip_timers* t) {
   ENG(h);
   *t = e->timers;
+  return 0;
+}
+
+int ba_hip_get_structure_stats(ba_hip_engine* h, ba_hip_structure_stats* out) {
+  ENG(h);
+  NEED_FINAL();
+  const Structure& st = e->st;
+  memset(out, 0, sizeof(*out));
+  out->poses_active = st.Pact; out->landmarks_active = st.Lact; out->observations = st.O;
+  out->incidences = st.n_inc; out->factor_rows = st.n_rows;
+  out->pair_blocks = st.n_pairs; out->pair_entries = st.n_pair_entries;
+  const uint64_t nt = st.ld / 64;
+  out->tiles_lower = nt * (nt + 1) / 2;
+  if (!e->nzL_valid && !(e->allreduce && e->nranks > 1)) {
+    int rc = factor_tile_pattern(e);
+    if (rc) return rc;
+  }
+  if (e->nzL_valid && e->nzL_host.size() == nt * nt && e->nzS_host.size() == nt * nt)
+    for (uint64_t i = 0; i < nt; ++i)
+      for (uint64_t k = 0; k <= i; ++k) {
+        out->tiles_S += e->nzS_host[i * nt + k] ? 1 : 0;
+        out->tiles_L += e->nzL_host[i * nt + k] ? 1 : 0;
+      }
   return 0;
 }
 

@@ -347,12 +347,14 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
     e->imu_cov_count = ni;
   }
   if (ni) {
+    e->prof_begin(e->ev_imu);
     hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 1, e->pose_dim,
                        e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
                        e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                        e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
                        e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
                        e->imu_frozen.p, e->imu_cov_done.p);
+    e->prof_end(e->ev_imu);
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;

@@ -301,6 +301,79 @@ int launch_gather_S(Engine* e) {
 }
 
 // ---------------------------------------------------------------------------------
+// Test tap (ba_hip_check_solve): y = S x for the symmetric S kept in lower storage (the copy taken
+// before the in-place factorisation), without downloading it — S is 28.8 GB at configs[3].
+//   k_symv_rows: y[r]  = sum_{c <= r} A[r][c] x[c]      one workgroup per row, coalesced row read
+//   k_symv_cols: y[c] += sum_{r >  c} A[r][c] x[r]      one workgroup per 64-column tile; a wave
+//                reads 64 consecutive doubles of one row per step, lane = column; fixed order
+__global__ void __launch_bounds__(256)
+k_symv_rows(uint32_t n, uint32_t ld, const double* __restrict__ A, const double* __restrict__ x,
+            double* __restrict__ y) {
+  __shared__ double red[4];
+  const uint32_t r = blockIdx.x;
+  const double* row = A + (size_t)r * ld;
+  double s = 0.0;
+  for (uint32_t c = threadIdx.x; c <= r; c += 256) s += row[c] * x[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) y[r] = (red[0] + red[1]) + (red[2] + red[3]);
+  (void)n;
+}
+__global__ void __launch_bounds__(256)
+k_symv_cols(uint32_t n, uint32_t ld, const double* __restrict__ A, const double* __restrict__ x,
+            double* __restrict__ y) {
+  __shared__ double red[4][64];
+  const uint32_t c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  double s = 0.0;
+  if (c < n)
+    for (uint32_t r = blockIdx.x * 64 + w; r < n; r += 4)
+      if (r > c) s += A[(size_t)r * ld + c] * x[r];
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < n) y[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// partial sums of |y - b|^2 and |b|^2
+__global__ void __launch_bounds__(256)
+k_resid_norms(uint32_t n, const double* __restrict__ y, const double* __restrict__ b, double* __restrict__ partials,
+              uint32_t nparts) {
+  __shared__ double red[2][256];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double d = 0, bb = 0;
+  if (i < n) { d = y[i] - b[i]; bb = b[i]; }
+  red[0][threadIdx.x] = d * d; red[1][threadIdx.x] = bb * bb;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) { red[0][threadIdx.x] += red[0][threadIdx.x + k]; red[1][threadIdx.x] += red[1][threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partials[blockIdx.x] = red[0][0]; partials[nparts + blockIdx.x] = red[1][0]; }
+}
+
+int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard);
+
+// |S x - b| and |b| for the kept copy of S (lower storage, ld), x and b device vectors of n doubles
+int check_solve_residual(Engine* e, const double* dS, const double* dx, const double* db, double* out2) {
+  const uint32_t n = e->st.n, ld = e->st.ld;
+  out2[0] = out2[1] = 0.0;
+  if (n == 0) return 0;
+  DBuf<double> y;
+  BAE_HIP(y.alloc(n));
+  hipLaunchKernelGGL(k_symv_rows, dim3(n), dim3(256), 0, e->stream, n, ld, dS, dx, y.p);
+  hipLaunchKernelGGL(k_symv_cols, dim3((n + 63) / 64), dim3(256), 0, e->stream, n, ld, dS, dx, y.p);
+  const uint32_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_resid_norms, dim3(nb), dim3(256), 0, e->stream, n, (const double*)y.p, db, e->partials.p, nb);
+  hipError_t err = hipGetLastError();
+  int rc = err == hipSuccess ? sum_partials(e, nb, 2, out2, false) : e->fail(err, "check_solve kernels");
+  y.release();
+  if (rc) return rc;
+  out2[0] = sqrt(out2[0]); out2[1] = sqrt(out2[1]);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // Fixed-order sum of `ncomp` rows of `nparts` partial sums (one block).
 __global__ void k_sum_partials(uint32_t nparts, uint32_t ncomp, const double* __restrict__ parts,
                                double* __restrict__ out) {

@@ -52,9 +52,15 @@ class Timers(C.Structure):
 
 class KernelStats(C.Structure):
     _fields_ = [("syrk_launches", C.c_uint32), ("gather_launches", C.c_uint32),
-                ("landmarks_launches", C.c_uint32), ("reserved", C.c_uint32),
+                ("landmarks_launches", C.c_uint32), ("imu_launches", C.c_uint32),
                 ("syrk_ms", C.c_double), ("gather_ms", C.c_double), ("landmarks_ms", C.c_double),
-                ("syrk_flops", C.c_double)]
+                ("syrk_flops", C.c_double), ("imu_ms", C.c_double)]
+
+
+class StructureStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("poses_active", "landmarks_active", "observations", "incidences",
+                                          "factor_rows", "pair_blocks", "pair_entries", "tiles_lower",
+                                          "tiles_S", "tiles_L")]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
@@ -73,7 +79,7 @@ SYMBOLS = [
     "ba_hip_num_lm_params", "ba_hip_get_S", "ba_hip_get_rhs", "ba_hip_get_delta_gn",
     "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_proj_residuals", "ba_hip_get_imu_residuals", "ba_hip_get_imu_errors", "ba_hip_get_timers", "ba_hip_get_unary_scales", "ba_hip_device_buffer",
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
-    "ba_hip_get_kernel_stats",
+    "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats",
 ]
 
 
@@ -297,6 +303,17 @@ class Engine:
         t = Timers()
         self._chk(self.L.ba_hip_get_timers(self.h, C.byref(t)))
         return {n: getattr(t, n) for n, _ in Timers._fields_}
+
+    def check_solve(self):
+        """(|S delta_gn - rhs|, |rhs|) formed on the device from the kept copy of S."""
+        a, b = C.c_double(), C.c_double()
+        self._chk(self.L.ba_hip_check_solve(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def structure_stats(self):
+        st = StructureStats()
+        self._chk(self.L.ba_hip_get_structure_stats(self.h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in StructureStats._fields_}
 
     def set_profiling(self, on):
         self._chk(self.L.ba_hip_set_profiling(self.h, int(on)))

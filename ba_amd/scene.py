@@ -319,3 +319,38 @@ def add_inertial(sc, period=60.0, samples_per_interval=10, seed=0, vel_sigma=0.0
     sc.pose_time = tp
     sc.gravity = g
     return sc
+
+
+def relative_pose(a, b):
+    """T_ab = T_wa^-1 T_wb for poses [t, q(xyzw)]."""
+    ra, rb = quat_to_rot(np.asarray(a)[3:7]), quat_to_rot(np.asarray(b)[3:7])
+    return np.concatenate([ra.T @ (np.asarray(b)[:3] - np.asarray(a)[:3]), rot_to_quat(ra.T @ rb)])
+
+
+def populate(ba, sc, active=None, imu=False, priors=False, unary_every=100, seed=4):
+    """Feed a Scene through a reference-style API object (the oracle's or ba_amd.adjuster's
+    BundleAdjuster — same method names): camera, poses, landmarks, projection residuals;
+    imu: one inertial residual per consecutive pose pair (needs add_inertial);
+    priors: a unary prior on every `unary_every`-th pose (cov diag(1e-2 I3, 1e-3 I3)) and a binary
+    odometry constraint between consecutive poses from the ground truth + 1 cm noise, identity
+    covariance — the configs[4] recipe of SURVEY.md §8d."""
+    if hasattr(sc, "gravity") and imu:
+        ba.SetGravity(sc.gravity)
+    ba.AddCamera(sc.cam_params)
+    ba.add_poses(sc.poses, v_w=getattr(sc, "init_vel", None), b=getattr(sc, "init_bias", None),
+                 is_active=active, time=getattr(sc, "pose_time", None))
+    ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    n = ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    P = sc.num_poses
+    if imu:
+        for i in range(P - 1):
+            ba.AddImuResidual(i, i + 1, sc.imu_meas[i])
+    if priors:
+        rng = np.random.default_rng(seed)
+        for i in range(0, P, unary_every):
+            ba.AddUnaryConstraint(i, sc.gt_poses[i], np.diag([1e-2] * 3 + [1e-3] * 3), True)
+        for i in range(P - 1):
+            t12 = relative_pose(sc.gt_poses[i], sc.gt_poses[i + 1])
+            t12[:3] += 0.01 * rng.normal(size=3)
+            ba.AddBinaryConstraint(i, i + 1, t12)
+    return n

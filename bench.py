@@ -1,31 +1,38 @@
 #!/usr/bin/env python3
 """Gauss-Newton iterations/sec of the MI355X BundleAdjuster path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4]
 
-A "step" is one full Gauss-Newton iteration of ba::BundleAdjuster::Solve
+A "step" is one full iteration of ba::BundleAdjuster::Solve
 (/root/reference/src/BundleAdjuster.cpp:298-663) on a synthetic scene already resident in
-HBM: linearise (residuals, Huber median, Jacobians, V/W, gather S and rhs) -> dense
-Cholesky solve -> landmark back-substitution -> EvaluateResiduals -> ApplyUpdate ->
+HBM: linearise (residuals, Huber median, Jacobians, V/W, reduced system S and rhs) -> dense
+LDL^T solve -> landmark back-substitution -> EvaluateResiduals -> ApplyUpdate ->
 EvaluateResiduals -> accept / roll back.  Exit tests are disabled (fixed step count).
 
-Workload (default, `--config 3`): the scene BASELINE.json's metric is quoted on — configs[3],
-10k poses / 1M landmarks / 10M reprojection residuals, pinhole camera, inverse-depth landmarks
-(LmSize = 1), n = 59 988 reduced unknowns; it fits one MI355X (S is 28.8 GB of the 288 GB).
-`--config 1` selects configs[1] (1k poses / 100k landmarks / 1M residuals).  For N > 1 the SAME
-scene is sharded by landmark across the ranks (every rank holds all poses); the partial
-reduced pose systems are reduce-scattered (RCCL over xGMI) onto the owners of S's column
-panels, every panel is factorised by its owner and broadcast, and each rank applies the
-trailing updates to the panels it owns; the right-hand side and a few scalars/histograms
-are all-reduced ("scaling": "strong").
+Workloads (`--config` = index into BASELINE.json `configs`):
+  3 (default) 10k poses / 1M landmarks / 10M reprojection residuals, LmSize 1, PoseSize 6, GN —
+              the scene the metric is quoted on; n = 59 988, S = 28.8 GB: fits one MI355X
+  1           1k / 100k / 1M, same shape
+  2           5k / 500k / 5M + IMU pre-integration residuals, PoseSize 15 (n = 75 000), GN
+  4           10k / 1M / 10M + IMU + unary priors + binary odometry, PoseSize 15 (n = 150 000,
+              S = 180 GB on ONE GPU), dogleg trust region
+Drivers: configs 1 / 3 time the phase calls of the C-ABI (include/ba_hip.h) — `value` — and, at
+N = 1, additionally `api_solve_ms`: wall time of ba::BundleAdjuster::Solve(1) on a warm object,
+the number a user of the C++ class sees.  Configs 2 / 4 are timed through that C++ API path
+only (Solve(1) per step on a warm object).
 
-Rank 0 prints one JSON line with the driver's contract keys plus `roofline` (dominant
-kernel, measured live with HIP events on the engine's stream) and `cpu_baseline` (the
-oracle — a CPU restatement of the reference — timed on the host cores for ONE iteration
-of the same scene).
+For N > 1 the SAME scene (config 1 / 3) is sharded by landmark across the ranks (every rank
+holds all poses); the partial reduced pose systems are reduce-scattered (RCCL over xGMI) onto the
+owners of S's column panels, every panel is factorised by its owner and broadcast, and each rank
+applies the trailing updates to the panels it owns; the right-hand side and a few
+scalars/histograms are all-reduced ("scaling": "strong").
+
+Rank 0 prints one JSON line with the driver's contract keys plus `roofline` (dominant kernel,
+measured live with HIP events on the stream it runs on) and `cpu_baseline` (the oracle — a CPU
+restatement of the reference — timed on the host cores on a bounded sample of the workload).
 """
 import argparse
-import ctypes
+import glob
 import json
 import os
 import sys
@@ -36,14 +43,40 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from ba_amd import hipapi, scene, sharding  # noqa: E402
+from ba_amd import adjuster, hipapi, scene, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md chip table: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6   # AMD datasheet FP64 matrix peak (not listed in the local guide)
 
+CONFIGS = {
+    # poses, landmarks, pose_dim, imu, priors, dogleg, default steps, warmup, CPU-sample poses / landmarks
+    1: dict(P=1000, L=100000, D=6, imu=False, priors=False, dogleg=False, steps=20, warmup=3, sP=1000, sL=100000),
+    2: dict(P=5000, L=500000, D=15, imu=True, priors=False, dogleg=False, steps=4, warmup=1, sP=500, sL=50000),
+    3: dict(P=10000, L=1000000, D=6, imu=False, priors=False, dogleg=False, steps=5, warmup=1, sP=1000, sL=100000),
+    4: dict(P=10000, L=1000000, D=15, imu=True, priors=True, dogleg=True, steps=2, warmup=1, sP=500, sL=50000),
+}
+
+
+def make_workload(cfg, P, L, K, lm_dim):
+    sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=2)
+    if cfg["imu"]:
+        scene.add_inertial(sc, period=60.0 * P / 100.0)
+    return sc
+
+
+def active_mask(cfg, sc):
+    """configs 1 / 3: two anchor poses inactive fix the monocular gauge; the visual-inertial
+    scenes are all-active (gravity + velocities observable; root pose auto-regularised,
+    BundleAdjuster.cpp:1285-1330) or carry priors."""
+    if cfg["imu"]:
+        return None
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    return pa
+
 
 def build_engine(sc, lm_dim, lo, hi, device, stream=None):
-    """Upload poses (all) and the landmark shard [lo, hi) with its accepted residuals."""
+    """C-ABI driver: upload poses (all) and the landmark shard [lo, hi) with its accepted residuals."""
     nsel = sc.obs_per_landmark + (1 if lm_dim == 1 else 0)
     keep = np.ones(len(sc.obs_pose), dtype=bool)
     if lm_dim == 1:
@@ -78,29 +111,97 @@ def gn_step(eng):
     return post.total(), True
 
 
-def cpu_baseline(sc, lm_dim):
-    """The oracle (CPU restatement of the reference, 1 thread as the reference runs its
-    projection loop serially, BundleAdjuster.cpp:1345-1347) on ONE iteration of the scene `sc`."""
-    from oracle import pyoracle as po
-    po.build()
-    ba = po.OracleBundleAdjuster(lm_dim, 6)
-    o = po.default_options()
-    o.use_dogleg = 0
+def api_options(mod, cfg):
+    o = mod.default_options()
+    o.use_dogleg = 1 if cfg["dogleg"] else 0
     o.error_change_threshold = 0
     o.param_change_threshold = 0
-    ba.Init(o)
-    pa = np.ones(sc.num_poses, dtype=np.uint8)
-    pa[sc.anchor_poses] = 0
-    ba.AddCamera(sc.cam_params)
-    ba.add_poses(sc.poses, is_active=pa)
-    ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
-    ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    return o
+
+
+def build_adjuster(cfg, sc, lm_dim):
+    """C++ API driver: ba::BundleAdjuster<double, LmSize, PoseSize> through include/ba_capi.h."""
+    h = adjuster.BundleAdjuster(lm_dim, cfg["D"])
+    h.Init(api_options(adjuster, cfg))
+    scene.populate(h, sc, active=active_mask(cfg, sc), imu=cfg["imu"], priors=cfg["priors"])
+    return h
+
+
+def cpu_baseline(cfg, K, lm_dim, threads):
+    """The oracle (CPU restatement of the reference) on ONE iteration of a bounded sample of the
+    workload: the same generator and densities at cfg['sP'] poses / cfg['sL'] landmarks.
+    threads = 1: reference-faithful (projection loop and LDL^T are serial in the reference,
+    BundleAdjuster.cpp:1345-1347, 752-799); threads > 1: best-effort CPU mode (dense LDL^T on all
+    cores, BASELINE.md §3 ii)."""
+    from oracle import pyoracle as po
+    po.build()
+    po.set_num_threads(threads)
+    sc = make_workload(cfg, cfg["sP"], cfg["sL"], K, lm_dim)
+    ba = po.OracleBundleAdjuster(lm_dim, cfg["D"])
+    ba.Init(api_options(po, cfg))
+    scene.populate(ba, sc, active=active_mask(cfg, sc), imu=cfg["imu"], priors=cfg["priors"])
     t0 = time.time()
     ba.Solve(1)
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "iterations/sec", "cores": 1, "kind": "port",
-            "sample": "1 Gauss-Newton iteration of the same scene (%.1f s)" % dt,
-            "phases_s": {k: round(v, 3) for k, v in ba.timers().items()}}
+    po.set_num_threads(1)
+    return dt, {k: round(v, 3) for k, v in ba.timers().items()}, ba.num_pose_params()
+
+
+def cpu_ldlt_rate(n, threads):
+    """FP64 GFLOP/s of the oracle's dense LDL^T at size n from the committed three-point fit
+    (profiles/r02_cpu_ldlt_fit.json, measured on the GPU box's host cores by scratch/cpu_ldlt_fit.py),
+    or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_cpu_ldlt_fit.json")) as f:
+            fit = json.load(f)
+        pts = fit["threads_%d" % threads] if ("threads_%d" % threads) in fit else fit["all_cores" if threads > 1 else "threads_1"]
+        ns = np.array([p["n"] for p in pts], dtype=float)
+        gf = np.array([p["gflops"] for p in pts], dtype=float)
+        return float(np.interp(min(n, ns.max()), ns, gf)), fit.get("cpu_model", "")
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_baseline_record(cfg, args, n_full, O_full, threads):
+    dt, ph, n_s = cpu_baseline(cfg, args.obs_per_landmark, args.lm_dim, threads)
+    O_s = cfg["sL"] * args.obs_per_landmark
+    rec = {"unit": "iterations/sec", "cores": threads, "kind": "port", "phases_s": ph,
+           "mode": "reference-faithful (1 thread)" if threads == 1 else "best-effort (dense LDL^T on %d threads)" % threads}
+    if cfg["sP"] == args.poses and cfg["sL"] == args.landmarks:
+        rec["value"] = 1.0 / dt
+        rec["sample"] = "1 iteration of the same scene (%.1f s)" % dt
+        return rec
+    # extrapolation to the full scene: O(residuals) phases by the residual count, the dense LDL^T
+    # by its flop count at the CPU's measured LDL^T rate (three-point fit under profiles/, else the
+    # rate of this sample's own solve)
+    lin = ph["total"] - ph["solve"]
+    f_lin = float(O_full) / O_s
+    rate_sample = (n_s ** 3 / 3.0) / max(ph["solve"], 1e-9) / 1e9
+    fit = cpu_ldlt_rate(n_full, threads)
+    rate = fit[0] if fit else rate_sample
+    t_solve = (float(n_full) ** 3 / 3.0) / (rate * 1e9)
+    est = lin * f_lin + t_solve
+    rec["value"] = 1.0 / est
+    rec["measured_sample_iterations_per_sec"] = 1.0 / dt
+    rec["extrapolated"] = True
+    rec["sample"] = ("1 iteration of a %d-pose / %d-landmark / %d-residual scene of the same generator (n = %d, %.1f s "
+                     "measured), extrapolated: linear phases x%.0f (residual count), dense LDL^T n^3/3 = %.2e flop at "
+                     "%.1f GFLOP/s (%s) -> %.0f s per iteration"
+                     % (cfg["sP"], cfg["sL"], O_s, n_s, dt, f_lin, float(n_full) ** 3 / 3.0, rate,
+                        "profiles/r02_cpu_ldlt_fit.json" if fit else "this sample's solve", est))
+    return rec
+
+
+def newest_pmc(config):
+    """Committed rocprofv3 --pmc summary for this configuration (profiles/rNN_pmc_traffic_cfgC.json)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_cfg%d.json" % config)))
+    if not files:
+        return {}, None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)["kernels"], os.path.relpath(files[-1], ROOT)
+    except (OSError, KeyError, ValueError):
+        return {}, None
 
 
 def main():
@@ -108,30 +209,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=3, choices=[1, 3],
-                    help="BASELINE.json configs index: 3 = 10k poses / 1M landmarks / 10M residuals "
-                         "(the metric's scene, default), 1 = 1k / 100k / 1M")
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs index (3 = the metric's scene, default)")
     ap.add_argument("--poses", type=int, default=None)
     ap.add_argument("--landmarks", type=int, default=None)
     ap.add_argument("--obs-per-landmark", type=int, default=10)
     ap.add_argument("--lm-dim", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the api_solve_ms pass of configs 1 / 3")
     args = ap.parse_args()
-    preset = {1: (1000, 100000, 20, 3), 3: (10000, 1000000, 5, 1)}[args.config]
+    cfg = CONFIGS[args.config]
     if args.poses is None:
-        args.poses = preset[0]
+        args.poses = cfg["P"]
     if args.landmarks is None:
-        args.landmarks = preset[1]
+        args.landmarks = cfg["L"]
     if args.steps is None:
-        args.steps = preset[2]
+        args.steps = cfg["steps"]
     if args.warmup is None:
-        args.warmup = preset[3]
+        args.warmup = cfg["warmup"]
+    api_driver = cfg["imu"] or cfg["priors"]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world != 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and api_driver:
+        raise SystemExit("configs 2 / 4 are single-GPU benchmarks (pose-pose residuals live on one rank)")
     dist = torch = None
     if world > 1:
         import torch
@@ -145,73 +249,115 @@ def main():
         dist.init_process_group(backend=backend)
 
     P, L, K, lm_dim = args.poses, args.landmarks, args.obs_per_landmark, args.lm_dim
-    sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=2)
-    # landmark shards: contiguous, equal counts (every landmark has K residuals, so the
-    # Schur work  sum k(k+1)/2  is balanced too)
-    lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
-    t_setup = time.perf_counter()
-    eng, n_obs_local = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
-    t_setup = time.perf_counter() - t_setup  # host -> device uploads + structure build (once per Solve())
-    if world > 1:
-        eng.set_allreduce(sharding.torch_allreduce_hook(dist, "cuda"), rank, world)
-        # distributed reduced solve: reduce-scatter of S to the panel owners, per-panel
-        # factorisation + broadcast (BA_BENCH_REPLICATED_SOLVE=1 keeps the replicated solve)
-        if not os.environ.get("BA_BENCH_REPLICATED_SOLVE"):
-            eng.set_collectives(sharding.torch_collectives_hook(dist, "cuda"))
+    sc = make_workload(cfg, P, L, K, lm_dim)
 
     def barrier():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        gn_step(eng)
-    eng.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
+    api_ms = first_solve_s = None
     accepted = 0
     err = 0.0
-    for _ in range(args.steps):
-        err, ok = gn_step(eng)
-        accepted += int(ok)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ks = eng.kernel_stats()
-    timers = eng.get_timers()
-    eng.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    eng.end_solve()
+    if not api_driver:
+        # landmark shards: contiguous, equal counts (every landmark has K residuals, so the
+        # Schur work  sum k(k+1)/2  is balanced too)
+        lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
+        t_setup = time.perf_counter()
+        eng, _ = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
+        t_setup = time.perf_counter() - t_setup  # host -> device uploads + structure build (once per graph)
+        if world > 1:
+            eng.set_allreduce(sharding.torch_allreduce_hook(dist, "cuda"), rank, world)
+            # distributed reduced solve: reduce-scatter of S to the panel owners, per-panel
+            # factorisation + broadcast (BA_BENCH_REPLICATED_SOLVE=1 keeps the replicated solve)
+            if not os.environ.get("BA_BENCH_REPLICATED_SOLVE"):
+                eng.set_collectives(sharding.torch_collectives_hook(dist, "cuda"))
+        for _ in range(args.warmup):
+            gn_step(eng)
+        eng.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            err, ok = gn_step(eng)
+            accepted += int(ok)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ks = eng.kernel_stats()
+        timers = eng.get_timers()
+        stats = eng.structure_stats() if world == 1 else {}
+        eng.set_profiling(False)
+        n = eng.num_pose_params()
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        eng.end_solve()
+        eng.close()
+        if world == 1 and not args.no_api:
+            # the same scene through ba::BundleAdjuster::Solve(1): first call = upload + structure
+            # build + one iteration; later calls on the warm object must not rebuild anything
+            h = build_adjuster(cfg, sc, lm_dim)
+            t1 = time.perf_counter()
+            h.Solve(1)
+            first_solve_s = time.perf_counter() - t1
+            h.Solve(1)
+            reps = max(2, min(args.steps, 5))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                h.Solve(1)
+            api_ms = 1e3 * (time.perf_counter() - t1) / reps
+            del h
+    else:
+        h = build_adjuster(cfg, sc, lm_dim)
+        t_setup = time.perf_counter()
+        h.Solve(1)       # upload + structure build + the first iteration
+        t_setup = time.perf_counter() - t_setup
+        first_solve_s = t_setup
+        for _ in range(max(args.warmup - 1, 0)):
+            h.Solve(1)
+        ev = h.engine()
+        ev.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            h.Solve(1)
+            s = h.summary()
+            accepted += int(adjuster.RESULT_NAMES[s.result] == "Success")
+            err = s.post_solve_norm if cfg["dogleg"] else s.proj_error + s.inertial_error + s.unary_error + s.binary_error
+        elapsed = time.perf_counter() - t0
+        ks = ev.kernel_stats()
+        timers = ev.get_timers()
+        stats = ev.structure_stats()
+        ev.set_profiling(False)
+        n = ev.num_pose_params()
+        api_ms = 1e3 * elapsed / args.steps
+        t_setup -= api_ms * 1e-3
 
     if rank == 0:
-        n = eng.num_pose_params()
         O = L * K
         ms = 1e3 * elapsed / args.steps
         # dominant kernel: the trailing update of the dense LDL^T factorisation (FP64 MFMA);
         # timed with HIP events on the stream it is launched on (the engine's second stream)
         syrk_tf = ks.syrk_flops / (ks.syrk_ms * 1e-3) / 1e12 if ks.syrk_ms > 0 else 0.0
-        # HBM-bound kernels, algorithmic bytes per launch (DESIGN.md §Roofline accounting)
+        # HBM-bound kernels, algorithmic bytes per launch: every input read once,
+        # every output written once.  Linearisation: observation records, landmarks, poses in;
+        # factor rows + landmark blocks out.  Gather: the rank-1 term lists and the two 48-byte rows
+        # of every term in; the nonzero pose-pair blocks out (NOT the whole lower triangle: the
+        # zero-fill of the remaining tiles belongs to the clear kernel).
         ell = lm_dim
-        b_landmarks = O / world * 32 + (L / world) * 36 + P * 56 + (L / world) * 8 * (ell * ell + ell)
-        b_gather = 8.0 * n * (n + 1) / 2 + 8 * n
+        b_landmarks = (O / world * 32 + (L / world) * 36 + P * 56 + (L / world) * 8 * (ell * ell + ell)
+                       + (stats.get("factor_rows", 0) * 48 if stats else 0))
+        if stats:
+            b_gather = stats["pair_entries"] * (8 + 96) + stats["pair_blocks"] * (288 + 12)
+        else:
+            b_gather = 0.0
         lm_gbs = b_landmarks * ks.landmarks_launches / (ks.landmarks_ms * 1e-3) / 1e9 if ks.landmarks_ms > 0 else 0.0
         ga_gbs = b_gather * ks.gather_launches / (ks.gather_ms * 1e-3) / 1e9 if ks.gather_ms > 0 else 0.0
         # HBM-side traffic of the dominant kernel: not measurable live; taken from the committed
         # rocprofv3 --pmc passes of this same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
-        # per launch), null if the summary is absent
-        traffic = None
-        pmc = {}
+        # per launch), null if no summary exists for this configuration
+        pmc, pmc_file = newest_pmc(args.config)
         # 128x128 blocks on trailing matrices of >= 128 tiles, the capped 64-tile kernel below
         bulk_kernel = "k_update128<false>" if n >= 128 * 64 else "k_update2<true>"
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg%d.json" % args.config)) as f:
-                pmc = json.load(f)["kernels"]
-            bulk = "bae::k_update128<false>" if n >= 128 * 64 else "bae::k_update2<true>"
-            traffic = pmc[bulk]["traffic_bytes_per_launch_corrected"]
-        except (OSError, KeyError, ValueError):
-            pass
 
         def pmc_bytes(name):
             try:
@@ -231,22 +377,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[%d]: %d poses / %d landmarks / %d reprojection "
-                                   "residuals, pinhole, LmSize=%d, PoseSize=6, Gauss-Newton (no dogleg), "
-                                   "2 anchor poses inactive" % (args.config, P, L, O, lm_dim),
+            "config": {"workload": "BASELINE.json configs[%d]: %d poses / %d landmarks / %d reprojection residuals%s%s, "
+                                   "pinhole, LmSize=%d, PoseSize=%d, %s%s"
+                                   % (args.config, P, L, O, " + %d IMU pre-integration residuals" % (P - 1) if cfg["imu"] else "",
+                                      " + unary priors every 100th pose + %d binary odometry constraints" % (P - 1) if cfg["priors"] else "",
+                                      lm_dim, cfg["D"], "dogleg trust region" if cfg["dogleg"] else "Gauss-Newton (no dogleg)",
+                                      "" if cfg["imu"] else ", 2 anchor poses inactive"),
                        "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
+                       "driver": ("ba::BundleAdjuster::Solve(1) per step on a warm object (C++ API path, include/ba_capi.h)"
+                                  if api_driver else "phase calls of the C-ABI (include/ba_hip.h)"),
                        "parallelism": ("landmark-sharded x%d, reduce-scatter of S to panel owners, distributed LDL^T "
                                        "(panel broadcast)" % world) if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "%s (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)" % bulk_kernel,
                          "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic_cfg%d.json (rocprofv3 --pmc, bytes per launch)" % args.config,
+                         "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": pmc_bytes("bae::" + bulk_kernel),
+                         "traffic_source": ("%s (rocprofv3 --pmc, bytes per launch)" % pmc_file) if pmc_file else None,
                          "flops_per_launch": ks.syrk_flops / max(ks.syrk_launches, 1),
                          "launches": ks.syrk_launches,
                          "avg_launch_us": 1e3 * ks.syrk_ms / max(ks.syrk_launches, 1)},
             "hbm_kernels": {
-                # achieved_GBs: compulsory (algorithmic) bytes / time; pmc_traffic_bytes: what the
-                # kernel really moved (factor rows are materialised), from the committed PMC passes
+                # achieved_GBs: algorithmic bytes / time; pmc_traffic_bytes: what the kernel really
+                # moved, from the committed PMC passes
                 "k_landmarks": {"achieved_GBs": lm_gbs, "frac_of_8TBs": lm_gbs / HBM_PEAK_GBS,
                                 "avg_launch_us": 1e3 * ks.landmarks_ms / max(ks.landmarks_launches, 1),
                                 "algorithmic_bytes": b_landmarks,
@@ -256,40 +407,44 @@ def main():
                                "algorithmic_bytes": b_gather,
                                "pmc_traffic_bytes": pmc_bytes("bae::k_gather_S")}},
             "phase_ms_last_step": {k: round(v, 4) for k, v in timers.items()},
-            # one-off per Solve(): PCIe uploads of the scene + host-side structure build (gather
+            "structure": stats,
+            # one-off per graph: PCIe uploads of the scene + host-side structure build (gather
             # lists, tile pattern); NOT part of `value` (inputs are resident when the timed region starts)
             "setup_s_rank0": round(t_setup, 3),
             "accepted_steps": accepted,
             "final_error": err,
         }
+        if cfg["imu"] and ks.imu_launches:
+            # per residual: two pose states and the samples in; 3 blocks of 15x15, two gradients, two
+            # Jacobians, the information matrix out (one lane per residual: latency-bound, not HBM-bound)
+            M = sc.imu_meas.shape[1]
+            b_imu = (P - 1) * (2 * 16 * 8 + M * 56 + (3 * 225 + 30 + 2 * 225 + 225) * 8)
+            us = 1e3 * ks.imu_ms / ks.imu_launches
+            out["hbm_kernels"]["k_imu"] = {"avg_launch_us": us, "algorithmic_bytes": b_imu, "residuals": P - 1,
+                                           "achieved_GBs": b_imu / (us * 1e-6) / 1e9,
+                                           "frac_of_8TBs": b_imu / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                           "pmc_traffic_bytes": pmc_bytes("bae::k_imu")}
+        if api_ms is not None:
+            # wall time of adjuster.Solve(1) on a warm object (graph unchanged since the last call)
+            out["api_solve_ms"] = api_ms
+            out["api_first_solve_s"] = round(first_solve_s, 3)
         for hk in out["hbm_kernels"].values():  # real (PMC) traffic over the live launch time
             if hk.get("pmc_traffic_bytes") and hk["avg_launch_us"] > 0:
                 hk["pmc_GBs"] = hk["pmc_traffic_bytes"] / (hk["avg_launch_us"] * 1e-6) / 1e9
                 hk["pmc_frac_of_8TBs"] = hk["pmc_GBs"] / HBM_PEAK_GBS
         if not args.no_cpu_baseline and world == 1:
-            if P <= 1000:
-                out["cpu_baseline"] = cpu_baseline(sc, lm_dim)
-            else:
-                # One oracle iteration of THIS scene needs a dense n = 60k LDL^T on one core
-                # (~72 TFLOP: over an hour).  Bounded sample: one oracle iteration of the
-                # 10x smaller configs[1] scene (same generator, same densities); its O(N)
-                # phases are scaled by the residual count, its dense solve by n^3.
-                small = scene.make_scene(1000, 100000, K, lm_dim=lm_dim, seed=2)
-                cb = cpu_baseline(small, lm_dim)
-                ph = cb["phases_s"]
-                lin = ph["total"] - ph["solve"]
-                f_lin = float(O) / (100000 * K)
-                f_sol = (float(n) / (6.0 * 998)) ** 3
-                est = lin * f_lin + ph["solve"] * f_sol
-                cb["sample"] = ("1 Gauss-Newton iteration of the configs[1] scene (1k poses / 100k landmarks / "
-                                "1M residuals, %.1f s measured), extrapolated to this scene: linear phases "
-                                "x%.0f (residual count), dense LDL^T x%.0f (n^3) -> %.0f s per iteration"
-                                % (ph["total"], f_lin, f_sol, est))
-                cb["measured_sample_iterations_per_sec"] = cb["value"]
-                cb["value"] = 1.0 / est
-                out["cpu_baseline"] = cb
+            out["cpu_baseline"] = cpu_baseline_record(cfg, args, n, O, 1)
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if ncpu > 1:
+                out["cpu_baseline_all_cores"] = cpu_baseline_record(cfg, args, n, O, ncpu)
+            try:
+                with open("/proc/cpuinfo") as f:
+                    model = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+                out["cpu_baseline"]["cpu_model"] = model[0] if model else ""
+                out["cpu_baseline"]["nproc"] = ncpu
+            except OSError:
+                pass
         print(json.dumps(out), flush=True)
-    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -158,6 +158,9 @@ class BundleAdjuster {
     proj_error_ = binary_error_ = unary_error_ = inertial_error_ = 0;
     summary_ = SolutionSummary<Scalar>();
     structure_dirty_ = true;
+    host_state_stale_ = false;  // a new problem: whatever the engine still holds is obsolete
+    last_step_stale_ = false;
+    uploaded_poses_ = uploaded_landmarks_ = 0;
   }
 
   void SetGravity(const Vector3t& g) { imu_.g_vec = g; }          // reference :243-252
@@ -364,10 +367,11 @@ class BundleAdjuster {
   }
   uint32_t GetNumLandmarks() const { return (uint32_t)landmarks_.size(); }
   uint32_t GetNumUnaryResiduals() const { return (uint32_t)un_pose_.size(); }
-  const ImuCalibration& GetImuCalibration() const { return imu_; }
+  const ImuCalibration& GetImuCalibration() const { EnsureHostState(); return imu_; }
   void SetImuCalibration(const ImuCalibration& calib) { imu_ = calib; }
 
   const Pose& GetPose(const uint32_t id) const {  // reference :573-582
+    EnsureHostState();
     if (id >= poses_.size()) {
       std::cerr << "Attempted to get pose with id " << id << " from BA.  when poses_.size() is only "
                 << poses_.size() << "Aborting..." << std::endl;
@@ -375,10 +379,11 @@ class BundleAdjuster {
     }
     return poses_[id];
   }
-  const Landmark& GetLandmarkObj(const uint32_t id) const { return landmarks_[id]; }
-  const Vector4t& GetLandmark(const uint32_t id) const { return landmarks_[id].x_w; }
-  bool IsLandmarkReliable(const uint32_t id) const { return landmarks_[id].is_reliable; }
+  const Landmark& GetLandmarkObj(const uint32_t id) const { EnsureHostState(); return landmarks_[id]; }
+  const Vector4t& GetLandmark(const uint32_t id) const { EnsureHostState(); return landmarks_[id].x_w; }
+  bool IsLandmarkReliable(const uint32_t id) const { EnsureHostState(); return landmarks_[id].is_reliable; }
   double LandmarkOutlierRatio(const uint32_t id) const {  // reference BundleAdjuster.cpp:1805-1812
+    EnsureHostState();
     const Landmark& l = landmarks_[id];
     return l.num_proj_residuals == 0 ? 0 : (double)l.num_outlier_residuals / l.num_proj_residuals;
   }
@@ -400,6 +405,7 @@ class BundleAdjuster {
 
   // reference :608-631 (the rotation flag masks indices 2,4,5 — kept as is)
   void RegularizePose(uint32_t pose_id, bool translation, bool gravity, bool bias, bool rotation) {
+    EnsureHostState();
     Pose& pose = poses_[pose_id];
     pose.is_param_mask_used = true;
     pose.param_mask.assign(kPoseDim, true);
@@ -412,7 +418,15 @@ class BundleAdjuster {
 
   // ---- additions for tests / benchmarks (not in the reference) ------------------------
   ba_hip_engine* engine() { return engine_; }
-  const Delta& GetLastStep() const { return last_step_; }
+  const Delta& GetLastStep() const {  // fetched from the device on first use after a Solve()
+    if (last_step_stale_ && engine_) {
+      const uint32_t n = ba_hip_num_pose_params(engine_), nl = ba_hip_num_lm_params(engine_);
+      last_step_.delta_p.assign(n, 0); last_step_.delta_l.assign(nl, 0);
+      ba_hip_get_step(engine_, last_step_.delta_p.data(), last_step_.delta_l.data());
+      last_step_stale_ = false;
+    }
+    return last_step_;
+  }
   Scalar trust_region_size() const { return trust_region_size_; }
   const ba_hip_timers& GetLastTimers() const { return last_timers_; }
   uint32_t iterations_run() const { return iterations_run_; }
@@ -448,6 +462,13 @@ class BundleAdjuster {
     return false;
   }
   bool UploadProblem();
+  bool SyncEngine();
+  // The solution stays on the device when Solve() returns; the host copies (poses_, landmarks_,
+  // imu_ biases) are refreshed by the first getter that needs them — a SLAM loop that calls
+  // Solve(1) repeatedly does not pay a PCIe round trip of the whole state per call.
+  void EnsureHostState() const {
+    if (host_state_stale_) const_cast<BundleAdjuster*>(this)->DownloadState();
+  }
   void ComputeMasks(std::vector<uint16_t>& masks);
   void WriteReducedCameraMatrix();
   bool SolveInternal(const Scalar gn_damping, const bool error_increase_allowed, const bool use_dogleg);
@@ -481,7 +502,11 @@ class BundleAdjuster {
   uint32_t root_pose_id_ = 0, num_active_poses_ = 0, num_active_landmarks_ = 0;
   uint32_t iterations_run_ = 0;
   bool structure_dirty_ = true;
-  Delta last_step_;
+  bool host_state_stale_ = false;          // the device holds a newer state than poses_ / landmarks_
+  uint32_t uploaded_poses_ = 0, uploaded_landmarks_ = 0;  // sizes of the engine's copy of the graph
+  std::vector<double> un_scale_seen_;      // cumulative Huber scale already folded into un_cov_inv_
+  mutable Delta last_step_;
+  mutable bool last_step_stale_ = false;
   ba_hip_timers last_timers_ = {};
 
   ba_hip_engine* engine_ = nullptr;
@@ -489,6 +514,9 @@ class BundleAdjuster {
   ba_hip_allreduce_fn allreduce_ = nullptr;
   void* allreduce_ctx_ = nullptr;
   int rank_ = 0, nranks_ = 1;
+  ba_hip_allreduce_fn engine_allreduce_ = nullptr;  // what the engine currently has installed
+  void* engine_allreduce_ctx_ = nullptr;
+  bool engine_per_pose_cam_ = false;
 };
 
 template <typename Scalar>
@@ -497,10 +525,14 @@ template <typename Scalar>
 using VisualInertialBundleAdjuster = BundleAdjuster<Scalar, 1, 15, 0>;  // reference :762-763
 
 // ======================================================================================
-// Marshal the graph into the engine (once per Solve, or when the graph changed).
+// Engine creation + everything that is cheap to refresh on every Solve(): options, IMU noise,
+// gravity, the all-reduce hook.  The graph itself is uploaded (and ba_hip_finalize run) only when
+// an Add* / Init call changed it since the last Solve — "Solve may be called repeatedly"
+// (reference BundleAdjuster.h:549-551) then costs no rebuild.
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
-bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem() {
+bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
   if (!engine_ || engine_device_ != options_.device) {
+    EnsureHostState();  // a live engine on another device holds the current solution
     ReleaseEngine();
     const int rc = ba_hip_create(LmSize, PoseSize, options_.device, nullptr, &engine_);
     if (rc != 0) {
@@ -511,6 +543,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
       return false;
     }
     engine_device_ = options_.device;
+    structure_dirty_ = true;
   }
   ba_hip_options o;
   std::memset(&o, 0, sizeof(o));
@@ -522,8 +555,24 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   o.gyro_sigma = options_.gyro_sigma; o.accel_sigma = options_.accel_sigma;
   o.gyro_bias_sigma = options_.gyro_bias_sigma; o.accel_bias_sigma = options_.accel_bias_sigma;
   if (!Check(ba_hip_set_options(engine_, &o), "ba_hip_set_options")) return false;
-  ba_hip_set_allreduce(engine_, allreduce_, allreduce_ctx_, rank_, nranks_);
+  if (structure_dirty_ || allreduce_ != engine_allreduce_ || allreduce_ctx_ != engine_allreduce_ctx_) {
+    ba_hip_set_allreduce(engine_, allreduce_, allreduce_ctx_, rank_, nranks_);
+    engine_allreduce_ = allreduce_; engine_allreduce_ctx_ = allreduce_ctx_;
+  }
+  if (structure_dirty_) {
+    EnsureHostState();  // the graph is re-marshalled from poses_ / landmarks_: they must be current
+    if (!UploadProblem()) return false;
+  } else if (options_.use_per_pose_cam_params != engine_per_pose_cam_) {
+    structure_dirty_ = true;  // (rare) option flip: simplest is a full upload
+    EnsureHostState();
+    if (!UploadProblem()) return false;
+  }
+  return true;
+}
 
+// Marshal the graph into the engine (only when the graph changed since the last Solve).
+template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
+bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem() {
   const uint32_t C = rig_->NumCams(), P = (uint32_t)poses_.size(), L = (uint32_t)landmarks_.size();
   std::vector<double> cam_p(4 * (size_t)C), cam_t(7 * (size_t)C);
   for (uint32_t c = 0; c < C; ++c) {
@@ -577,23 +626,11 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   if (!Check(ba_hip_set_imu_residuals(engine_, (uint32_t)imu_p1_.size(), imu_p1_.data(), imu_p2_.data(),
                                       imu_ptr_.data(), imu_meas_.data(), imu_w_.data()),
              "ba_hip_set_imu_residuals")) return false;
-  // reference parallel_algos.h:189-205 (ImuResidualT::covariance_computed lives with the residual:
-  // it survives Solve() calls until the problem is rebuilt by Init())
-  if (!Check(ba_hip_set_inertial_covariance_once(engine_, options_.calculate_inertial_covariance_once ? 1 : 0,
-                                                 imu_cov_reset_ ? 1 : 0),
-             "ba_hip_set_inertial_covariance_once")) return false;
-  imu_cov_reset_ = false;
-  {
-    // the noise diagonals come from imu_ (Init() fills them from the option sigmas; a caller may
-    // have replaced them with SetImuCalibration) — reference parallel_algos.h:204,288
-    double r6[6], rb6[6];
-    for (int i = 0; i < 6; ++i) { r6[i] = (double)imu_.r[i]; rb6[i] = (double)imu_.r_b[i]; }
-    if (!Check(ba_hip_set_imu_noise(engine_, r6, rb6), "ba_hip_set_imu_noise")) return false;
-  }
-  const double g[3] = {imu_.g_vec[0], imu_.g_vec[1], imu_.g_vec[2]};
-  if (!Check(ba_hip_set_gravity(engine_, g), "ba_hip_set_gravity")) return false;
   if (!Check(ba_hip_finalize(engine_), "ba_hip_finalize")) return false;
   structure_dirty_ = false;
+  engine_per_pose_cam_ = options_.use_per_pose_cam_params;
+  uploaded_poses_ = P; uploaded_landmarks_ = L;
+  un_scale_seen_.assign(un_pose_.size(), 1.0);  // the engine's cumulative Huber scales restart at 1
   return true;
 }
 
@@ -668,10 +705,16 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::ComputeMasks(st
 
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
 bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::DownloadState() {
-  const uint32_t P = (uint32_t)poses_.size(), L = (uint32_t)landmarks_.size();
-  std::vector<double> pt(7 * (size_t)P), pv(3 * (size_t)P), pb(6 * (size_t)P), lx(4 * (size_t)L);
-  std::vector<uint8_t> rel(L);
-  std::vector<uint32_t> outl(L);
+  host_state_stale_ = false;
+  if (!engine_) return false;
+  // the engine's copy of the graph may be older than poses_ / landmarks_ (Add* calls since the
+  // last Solve append at the end): only the objects it knows are refreshed
+  const uint32_t P = std::min<uint32_t>(uploaded_poses_, (uint32_t)poses_.size());
+  const uint32_t L = std::min<uint32_t>(uploaded_landmarks_, (uint32_t)landmarks_.size());
+  std::vector<double> pt(7 * (size_t)uploaded_poses_), pv(3 * (size_t)uploaded_poses_), pb(6 * (size_t)uploaded_poses_),
+      lx(4 * (size_t)uploaded_landmarks_);
+  std::vector<uint8_t> rel(uploaded_landmarks_);
+  std::vector<uint32_t> outl(uploaded_landmarks_);
   if (!Check(ba_hip_get_poses(engine_, pt.data(), pv.data(), pb.data()), "ba_hip_get_poses")) return false;
   if (!Check(ba_hip_get_landmarks(engine_, lx.data()), "ba_hip_get_landmarks")) return false;
   if (!Check(ba_hip_get_landmark_flags(engine_, rel.data(), outl.data()), "ba_hip_get_landmark_flags")) return false;
@@ -683,9 +726,13 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::DownloadState()
   for (uint32_t l = 0; l < L; ++l) {
     for (int i = 0; i < 4; ++i) landmarks_[l].x_w[i] = lx[4 * (size_t)l + i];
     // is_reliable persists across Solve() calls in the reference (the Landmark objects live on,
-    // BundleAdjuster.cpp:127-134); the engine starts every Solve() with clean flags
+    // BundleAdjuster.cpp:127-134); so do the engine's flags while the graph is unchanged, and a
+    // re-upload starts them afresh — hence the conjunction with the host's copy
     landmarks_[l].is_reliable = landmarks_[l].is_reliable && rel[l] != 0;
     landmarks_[l].num_outlier_residuals = outl[l];
+  }
+  if (kBiasInState && P > 0 && P == poses_.size()) {  // :666-669
+    for (int i = 0; i < 3; ++i) { imu_.b_g[i] = poses_.back().b[i]; imu_.b_a[i] = poses_.back().b[3 + i]; }
   }
   return true;
 }
@@ -804,17 +851,20 @@ template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
 void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     const uint32_t uMaxIter, const Scalar gn_damping, const bool error_increase_allowed) {
   if (pr_pose_.empty() && bin_p1_.empty() && un_pose_.empty() && imu_p1_.empty()) return;
-  // the engine keeps the previous solution only on the device: re-upload the (possibly
-  // edited) host graph every Solve — AoS -> SoA once per Solve
-  if (!UploadProblem()) return;
+  // AoS -> SoA once per graph: the graph is uploaded and the static structure
+  // rebuilt only if an Add* / Init call changed it since the last Solve; otherwise the engine
+  // already holds the current state
+  if (!SyncEngine()) return;
   iterations_run_ = 0;
   if (!Check(ba_hip_begin_solve(engine_), "ba_hip_begin_solve")) return;  // :288-296
+  const bool host_was_stale = host_state_stale_;
+  host_state_stale_ = true;  // from here on the device holds the state; getters fetch it lazily (:666-678)
   std::vector<uint16_t> masks;
   for (uint32_t kk = 0; kk < uMaxIter; ++kk) {
     // masks may depend on the current root orientation (gravity axis): refresh per
     // iteration as BuildProblem does
-    if (kVelInState && kk > 0) {
-      std::vector<double> pt(7 * poses_.size());
+    if (kVelInState && (kk > 0 || host_was_stale) && root_pose_id_ < uploaded_poses_) {
+      std::vector<double> pt(7 * (size_t)uploaded_poses_);
       if (!Check(ba_hip_get_poses(engine_, pt.data(), nullptr, nullptr), "ba_hip_get_poses")) return;
       poses_[root_pose_id_].t_wp = SE3::from7(&pt[7 * (size_t)root_pose_id_]);
     }
@@ -841,25 +891,22 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     }
   }
   if (!Check(ba_hip_end_solve(engine_), "ba_hip_end_solve")) return;  // :672-678
-  {
-    const uint32_t n = ba_hip_num_pose_params(engine_), nl = ba_hip_num_lm_params(engine_);
-    last_step_.delta_p.assign(n, 0); last_step_.delta_l.assign(nl, 0);
-    ba_hip_get_step(engine_, last_step_.delta_p.data(), last_step_.delta_l.data());
-  }
-  if (!DownloadState()) return;
+  last_step_stale_ = true;
   uploaded_once_ = true;
   proj_view_dirty_ = true;  // GetProjectionResidual re-reads the device on its next call
   imu_view_dirty_ = true;
   if (!un_pose_.empty()) {
     // the reference scales each unary cov_inv in place every BuildProblem
-    // (BundleAdjuster.cpp:1469), so the compounded weights survive across Solve() calls
+    // (BundleAdjuster.cpp:1469), so the compounded weights survive across Solve() calls: on the
+    // device as a cumulative scale per residual, on the host folded into un_cov_inv_ (used by the
+    // next full upload, which restarts the device scales at 1)
     std::vector<double> sc(un_pose_.size(), 1.0);
     if (Check(ba_hip_get_unary_scales(engine_, sc.data()), "ba_hip_get_unary_scales"))
-      for (size_t i = 0; i < sc.size(); ++i)
-        for (int k = 0; k < 36; ++k) un_cov_inv_[36 * i + k] *= sc[i];
-  }
-  if (kBiasInState && !poses_.empty()) {  // :666-669
-    for (int i = 0; i < 3; ++i) { imu_.b_g[i] = poses_.back().b[i]; imu_.b_a[i] = poses_.back().b[3 + i]; }
+      for (size_t i = 0; i < sc.size(); ++i) {
+        const double ratio = sc[i] / un_scale_seen_[i];
+        for (int k = 0; k < 36; ++k) un_cov_inv_[36 * i + k] *= ratio;
+        un_scale_seen_[i] = sc[i];
+      }
   }
   // :680-704
   summary_.num_cond_inertial_residuals = (uint32_t)conditioning_inertial_residuals_.size();

@@ -135,7 +135,8 @@ int ba_hip_integrate_imu(const double t_wp7[7], const double v_w3[3], const doub
 /* ImuCalibrationT::r and r_b (Types.h:112-159): diagonal of the IMU measurement noise (gyro x3,
  * accelerometer x3) and of the bias random walk, as parallel_algos.h:204,288 read them from imu_.
  * NULL pointers: derive both from the sigmas of ba_hip_options (what Init() does,
- * BundleAdjuster.h:204-218).  Call before ba_hip_finalize. */
+ * BundleAdjuster.h:204-218).  Like the gravity vector it is not part of the structure: it takes
+ * effect at the next ba_hip_begin_solve, no ba_hip_finalize needed. */
 int ba_hip_set_imu_noise(ba_hip_engine* e, const double r6[6], const double rb6[6]);
 /* Options::calculate_inertial_covariance_once (BundleAdjuster.h:106, parallel_algos.h:189-205):
  * the integration covariance and the bias Jacobian of an inertial residual are computed in its
@@ -148,7 +149,10 @@ int ba_hip_set_gravity(ba_hip_engine* e, const double g3[3]); /* BundleAdjuster.
 int ba_hip_finalize(ba_hip_engine* e);
 
 /* ---- one Solve() ------------------------------------------------------------------ */
-/* BundleAdjuster.cpp:288-296: x_s = T_sw(ref) x_w, normalised (lm_dim == 1) */
+/* BundleAdjuster.cpp:288-296: x_s = T_sw(ref) x_w, normalised (lm_dim == 1).  May be called
+ * again on a finalized engine whose graph did not change (the reference's "Solve may be called
+ * repeatedly", BundleAdjuster.h:549-551): the state, Huber-compounded unary weights, reliability
+ * flags and frozen inertial covariances the previous Solve() left on the device are kept. */
 int ba_hip_begin_solve(ba_hip_engine* e);
 /* BundleAdjuster.cpp:1237-1330 decides the masks on the host; bit i of masks[p] set =
  * parameter i of pose p is regularised (Jacobian column zeroed, S(idx,idx) = 1e6,
@@ -193,6 +197,12 @@ int ba_hip_get_proj_weights(ba_hip_engine* e, double* weight); /* per residual i
  * ProjectionResidual::residual holds after a Solve() (BundleAdjuster.cpp:155-181) */
 int ba_hip_get_proj_residuals(ba_hip_engine* e, double* residual2);
 int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
+/* Test tap for systems too large to download (S is 28.8 GB at BASELINE.json configs[3]): forms
+ * || S delta_gn - rhs_p_sc || and || rhs_p_sc || ON THE DEVICE from the copy of S kept before the
+ * in-place factorisation (needs ba_hip_options.keep_reduced_system) and the Gauss-Newton pose
+ * step of the last ba_hip_solve_gn — i.e. checks what CalculateGn promises,
+ * S delta = rhs (BundleAdjuster.cpp:748-833).  Single shard only. */
+int ba_hip_check_solve(ba_hip_engine* e, double* residual_norm, double* rhs_norm);
 /* Residual vectors of the inertial residuals at the current state (ImuResidualT::residual after
  * EvaluateResiduals, BundleAdjuster.cpp:225-256): 15 doubles per residual in residual-id order,
  * the first PoseSize of them used (9: translation, rotation, velocity; 15: + biases). */
@@ -209,10 +219,22 @@ int ba_hip_get_unary_scales(ba_hip_engine* e, double* scale);
  * the engine's stream around every launch of the three hot kernels (used by bench.py's
  * roofline; costs two events per launch, so it is off by default). */
 typedef struct {
-  uint32_t syrk_launches, gather_launches, landmarks_launches, reserved;
+  uint32_t syrk_launches, gather_launches, landmarks_launches, imu_launches;
   double syrk_ms, gather_ms, landmarks_ms;
   double syrk_flops;       /* algorithmic flops of those k_syrk launches */
+  double imu_ms;           /* k_imu, the BuildProblem launch (parallel_algos.h:178-358) */
 } ba_hip_kernel_stats;
+/* Sizes of the static structure ba_hip_finalize built (for byte accounting in benchmarks). */
+typedef struct {
+  uint64_t poses_active, landmarks_active, observations;
+  uint64_t incidences;        /* (active pose, active landmark) pairs */
+  uint64_t factor_rows;       /* 48-byte rows written by the linearisation kernel per iteration */
+  uint64_t pair_blocks;       /* off-diagonal pose-pair blocks of S with at least one term */
+  uint64_t pair_entries;      /* rank-1 terms summed into those blocks */
+  uint64_t tiles_lower;       /* 64x64 tiles of the lower triangle incl. diagonal */
+  uint64_t tiles_S, tiles_L;  /* of those: structurally nonzero in S / in its factor (after fill) */
+} ba_hip_structure_stats;
+int ba_hip_get_structure_stats(ba_hip_engine* e, ba_hip_structure_stats* out);
 int ba_hip_set_profiling(ba_hip_engine* e, int enable);
 int ba_hip_get_kernel_stats(ba_hip_engine* e, ba_hip_kernel_stats* out);
 

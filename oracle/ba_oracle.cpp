@@ -135,8 +135,15 @@ void se3_to7(const SE3& t, double* p) {
 // SimplicialLDLT<Upper> (BundleAdjuster.cpp:752-799): both read the upper triangle
 // only; any exact factorisation agrees to rounding for the SPD systems of this path.
 // Blocked right-looking so the CPU baseline is not needlessly slow.
+// g_ldlt_threads > 1: the "best-effort CPU" mode of BASELINE.md §3 (ii) — the rows of a panel and
+// of a trailing update are independent, so they are dealt to OpenMP threads; every element is
+// computed by the same instruction sequence as with one thread (bitwise identical results).
+// 1 (default) is the reference-faithful mode: Eigen's LDLT is single-threaded.
+static int g_ldlt_threads = 1;
 bool ldlt_solve_upper(uint32_t n, const double* s, const double* rhs, double* x) {
   if (n == 0) return true;
+  const int nth = g_ldlt_threads;
+  (void)nth;
   std::vector<double> A((size_t)n * n);  // lower, row-major: A[i][j] = s[j][i], j<=i
   for (uint32_t i = 0; i < n; ++i)
     for (uint32_t j = 0; j <= i; ++j) A[(size_t)i * n + j] = s[(size_t)j * n + i];
@@ -156,6 +163,7 @@ bool ldlt_solve_upper(uint32_t n, const double* s, const double* rhs, double* x)
       d[k] = dk;
       if (dk == 0.0 || std::isnan(dk)) ok = false;
       const double inv = 1.0 / dk;
+#pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && n - k > 2048)
       for (uint32_t i = k + 1; i < n; ++i) {
         double v = A[(size_t)i * n + k];
         const double* li = &A[(size_t)i * n + k0];
@@ -172,6 +180,7 @@ bool ldlt_solve_upper(uint32_t n, const double* s, const double* rhs, double* x)
     for (uint32_t i = 0; i < m; ++i)
       for (uint32_t p = 0; p < kb; ++p)
         Wp[(size_t)i * kb + p] = A[(size_t)(r0 + i) * n + k0 + p] * d[k0 + p];
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nth) if (nth > 1)
     for (uint32_t i = 0; i < m; ++i) {
       const double* li = &A[(size_t)(r0 + i) * n + k0];
       double* ai = &A[(size_t)(r0 + i) * n + r0];
@@ -1677,6 +1686,8 @@ void orc_math_se3_mul(const double a[7], const double b[7], double out[7]) {
   se3_to7(se3_from7(a) * se3_from7(b), out);
 }
 void orc_math_se3_inv(const double a[7], double out[7]) { se3_to7(se3_from7(a).inverse(), out); }
+void orc_set_num_threads(int n) { g_ldlt_threads = n < 1 ? 1 : n; }
+int orc_get_num_threads(void) { return g_ldlt_threads; }
 void orc_math_dense_solve_upper(uint32_t n, const double* s, const double* rhs, double* x) {
   ldlt_solve_upper(n, s, rhs, x);
 }

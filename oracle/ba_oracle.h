@@ -148,6 +148,10 @@ void orc_math_log_decoupled(const double a[7], const double b[7], double out[6])
 void orc_math_se3_mul(const double a[7], const double b[7], double out[7]);
 void orc_math_se3_inv(const double a[7], double out[7]);
 void orc_math_dense_solve_upper(uint32_t n, const double* s, const double* rhs, double* x);
+/* threads of the dense LDL^T (process-wide).  1 = reference-faithful (Eigen's LDLT / SimplicialLDLT
+   run on one thread, BundleAdjuster.cpp:752-799); > 1 = the "best-effort CPU" baseline mode. */
+void orc_set_num_threads(int n);
+int orc_get_num_threads(void);
 /* IntegrateResidual (Types.h:662-738): pose [t7,v3], returns [t7,v3] and optional
    10x6 bias Jacobian and 10x10 covariance. */
 void orc_math_integrate(const double pose_t[7], const double v[3], const double* meas,

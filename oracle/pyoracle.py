@@ -382,6 +382,11 @@ def se3_inv(a):
     return out
 
 
+def set_num_threads(n):
+    """Threads of the oracle's dense LDL^T: 1 = reference-faithful, > 1 = best-effort CPU mode."""
+    lib().orc_set_num_threads(int(n))
+
+
 def dense_solve_upper(s, rhs):
     s, rhs = _d(s), _d(rhs)
     x = np.empty(rhs.shape[0])

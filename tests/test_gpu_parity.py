@@ -396,6 +396,8 @@ def _run_engine_steps(eng, iters, out, key):
         for _ in range(iters):
             e0 = eng.linearize()
             rc = eng.solve_gn()
+            if len(res) == 0:
+                out[(key, "delta_p")] = eng.get_delta_gn()[0]
             nrm = eng.compose_step(0.0, 1.0)
             pre = eng.eval_residuals()
             eng.apply_step()
@@ -408,8 +410,38 @@ def _run_engine_steps(eng, iters, out, key):
         out[key] = exc
 
 
+def _oracle_gn_run(po, sc, lm_dim, pa, iters):
+    """The oracle on the same scene: per iteration (result, proj_error, delta_norm), the first
+    pose step and the final poses — the CPU side of the sharded / distributed tests."""
+    o = po.OracleBundleAdjuster(lm_dim, 6)
+    o.Init(gn_options(po))
+    fill(o, sc, active=pa)
+    rows, dp0 = [], None
+    for it in range(iters):
+        o.Solve(1)
+        so = o.summary()
+        rows.append((so.result, so.proj_error, so.delta_norm))
+        if it == 0:
+            dp0 = o.delta_p()
+    return rows, dp0, o.poses()[0], o.landmarks()
+
+
+def _check_against_oracle(ref, out, key, poses, tol_dp=1e-8):
+    rows, dp0, poses_o, _ = ref
+    assert rel_err(out[(key, "delta_p")], dp0) < tol_dp          # north_star: 1e-6 on delta_x
+    for it, (res_o, err_o, dn_o) in enumerate(rows):
+        rc, _, pre, post, np_, nl_ = out[key][it]
+        assert rc == 0
+        if adjuster.RESULT_NAMES[res_o] != "Success":
+            continue  # a converged scene rejects on the last bit of two equal sums (DESIGN.md §8)
+        assert post <= pre
+        assert abs(post - err_o) <= 1e-8 * err_o                   # accepted error of the iteration
+        assert abs((np_ + nl_) - dn_o) <= 1e-7 * max(dn_o, 1e-12)
+    assert rel_err(poses, poses_o) < 1e-8
+
+
 @pytest.mark.parametrize("lm_dim", [1, 3])
-def test_two_shards_equal_one(lm_dim):
+def test_two_shards_equal_one(oracle_lib, lm_dim):
     """The same scene solved by ONE engine and by TWO engines holding half of the landmarks
     each (threads + in-process all-reduce hook): S, rhs, Huber median, errors, steps and
     the final state must agree — the 8-GPU path of bench.py, emulated on one GPU."""
@@ -463,14 +495,21 @@ def test_two_shards_equal_one(lm_dim):
     p0, _, _ = engs[0].get_poses(sc.num_poses)
     p1, _, _ = engs[1].get_poses(sc.num_poses)
     assert rel_err(p0, ps) < 1e-9 and np.array_equal(p0, p1)
+    # ... and with the oracle (not only with the engine itself): first pose step, accepted errors,
+    # step norms, final poses and landmarks
+    ref = _oracle_gn_run(oracle_lib, sc, lm_dim, pa, 3)
+    _check_against_oracle(ref, out, "single", ps)
+    _check_against_oracle(ref, out, 0, p0)
     for e_ in engs + [single]:
         e_.end_solve()
+    assert rel_err(np.concatenate([engs[r].get_landmarks(shards[r][1] - shards[r][0]) for r in range(2)]),
+                   ref[3]) < 1e-8
     lms = np.concatenate([engs[r].get_landmarks(shards[r][1] - shards[r][0]) for r in range(2)])
     assert rel_err(lms, single.get_landmarks(L)) < 1e-9
 
 
 @pytest.mark.parametrize("nranks", [2, 3])
-def test_distributed_solve_matches_single(nranks):
+def test_distributed_solve_matches_single(oracle_lib, nranks):
     """Distributed reduced solve (ba_hip_set_collectives): 300 poses -> 28 tiles = 7 column
     panels dealt round-robin to 2 / 3 engines that hold a landmark shard each; reduce-scatter of
     S, per-panel factorisation + broadcast, owner-filtered trailing updates.  Errors, step
@@ -532,6 +571,11 @@ def test_distributed_solve_matches_single(nranks):
     p0, _, _ = engs[0].get_poses(sc.num_poses)
     p1, _, _ = engs[1].get_poses(sc.num_poses)
     assert np.array_equal(p0, p1)  # every rank computes the same step bit for bit
+    # the distributed factorisation against the ORACLE's dense LDL^T on the whole scene
+    ref = _oracle_gn_run(oracle_lib, sc, lm_dim, pa, 3)
+    _check_against_oracle(ref, out, "single", ps)
+    for r in range(nranks):
+        _check_against_oracle(ref, out, r, engs[r].get_poses(sc.num_poses)[0])
     for e_ in engs + [single]:
         e_.end_solve()
 
@@ -1114,3 +1158,181 @@ def test_landmarks_only_solve_with_all_poses_fixed(oracle_lib, lm_dim, use_dogle
     assert rel_err(h.landmarks(), o.landmarks()) < 1e-10
     th, _, _ = h.poses()
     assert rel_err(th, sc.poses) < 1e-15                          # the poses did not
+
+
+# ---- BASELINE.json configs at full size / all residual kinds ------------------------------------
+def _add_all_residual_kinds(b, sc, po_math, P, rng_seed=4, unary_every=10):
+    """projection (already filled) + IMU between neighbours + unary prior on every k-th pose +
+    binary odometry between neighbours: the shape of BASELINE.json configs[4]."""
+    rng = np.random.default_rng(rng_seed)
+    for i in range(P - 1):
+        b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+    for i in range(0, P, unary_every):
+        b.AddUnaryConstraint(i, sc.gt_poses[i], np.diag([1e-2] * 3 + [1e-3] * 3), True)
+    for i in range(P - 1):
+        t12 = po_math.se3_mul(po_math.se3_inv(sc.gt_poses[i]), sc.gt_poses[i + 1])
+        t12[:3] += 0.01 * rng.normal(size=3)
+        b.AddBinaryConstraint(i, i + 1, t12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_config4_miniature_matches_oracle(oracle_lib, lm_dim):
+    """BASELINE.json configs[4] in miniature: ONE problem with all four residual kinds —
+    reprojection + unary priors + binary odometry + IMU pre-integration — PoseSize 15, dogleg
+    trust region (BundleAdjuster.cpp:298-663, 850-1083).  S and rhs at the first linearisation,
+    then errors, trust region and state over three iterations, against the oracle."""
+    po = oracle_lib
+    P = 40
+    sc = scene.make_scene(P, 160, 6, lm_dim=lm_dim, seed=77)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, use_dogleg=1)),
+                      (adjuster.BundleAdjuster, hip_options(use_dogleg=1))):
+        b = cls(lm_dim, 15)
+        b.Init(opts)
+        b.SetGravity(sc.gravity)
+        fill(b, sc)
+        _add_all_residual_kinds(b, sc, po, P, unary_every=8)
+        objs.append(b)
+    o, h = objs
+    for it in range(3):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        if it == 0:
+            assert rel_err(h.S(), o.S()) < 1e-9
+            assert rel_err(h.rhs(), o.rhs()) < 1e-9
+        for name in ("proj_error", "inertial_error", "unary_error", "binary_error", "pre_solve_norm",
+                     "post_solve_norm"):
+            a, b_ = getattr(so, name), getattr(sh, name)
+            assert abs(a - b_) <= 1e-6 * max(abs(a), 1e-9), (it, name, a, b_)
+        assert abs(so.trust_region_size - sh.trust_region_size) <= 1e-6 * abs(so.trust_region_size)
+        assert abs(so.delta_norm - sh.delta_norm) <= 1e-5 * max(so.delta_norm, 1e-12)
+    _state_close(o, h, 1e-6)
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-6
+
+
+def _bench_scene_engine(P, L, K, keep_s=False):
+    sc = scene.make_scene(P, L, K, lm_dim=1, seed=2)
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    keep[::K + 1] = False
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    eng = hipapi.Engine(1, 6)
+    if keep_s:
+        o = hipapi.Options()
+        o.projection_outlier_threshold = 1.0
+        o.use_robust_norm_for_proj_residuals = 1
+        o.use_triangular_matrices = 1
+        o.keep_reduced_system = 1
+        eng.set_options(o)
+    eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+    eng.set_poses(sc.poses, is_active=pa)
+    eng.set_landmarks(sc.landmarks, sc.lm_ref_pose)
+    eng.set_projection_residuals(sc.obs_z[keep], sc.obs_pose[keep], sc.obs_lm[keep])
+    eng.finalize()
+    eng.begin_solve()
+    eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+    return sc, eng
+
+
+@pytest.mark.gpu
+def test_config3_full_size_properties():
+    """BASELINE.json configs[3] — the scene the metric is quoted on (10k poses / 1M landmarks /
+    10M residuals, n = 59 988; bench.py's default workload and schedule: KOUT 16, left-looking
+    sub-panels of 8, k_update128).  The oracle cannot factor n = 60k, so the gate is size-independent:
+    (1) S delta = rhs, formed on the device from the kept copy of S (28.8 GB — never downloaded);
+    (2) the step is bitwise repeatable; (3) two Gauss-Newton steps are accepted and reduce the error."""
+    sc, eng = _bench_scene_engine(10000, 1000000, 10, keep_s=True)
+    assert eng.num_pose_params() == 59988
+    e0 = eng.linearize()
+    assert eng.solve_gn() == 0
+    res, rhs = eng.check_solve()
+    assert rhs > 0 and res / rhs < 1e-9, (res, rhs)
+    d1, l1 = eng.get_delta_gn()
+    assert np.all(np.isfinite(d1)) and np.linalg.norm(d1) > 0
+    eng.linearize()                      # same state: nothing was applied
+    assert eng.solve_gn() == 0
+    d2, l2 = eng.get_delta_gn()
+    assert np.array_equal(d1, d2) and np.array_equal(l1, l2)   # no atomics anywhere: bit for bit
+    errs = [e0.proj_error]
+    for _ in range(2):
+        eng.compose_step(0.0, 1.0)
+        pre = eng.eval_residuals()
+        eng.apply_step()
+        post = eng.eval_residuals()
+        assert post.total() < pre.total()
+        errs.append(post.total())
+        eng.linearize()
+        assert eng.solve_gn() == 0
+    assert errs[2] < errs[1] < errs[0]
+    # the first step moved the poses towards the ground truth
+    t, _, _ = eng.get_poses(sc.num_poses)
+    assert np.linalg.norm(t[:, :3] - sc.gt_poses[:, :3]) < np.linalg.norm(sc.poses[:, :3] - sc.gt_poses[:, :3])
+    eng.end_solve()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_config2_full_size_visual_inertial():
+    """BASELINE.json configs[2] at full size: 5k poses / 500k landmarks / 5M residuals + IMU
+    pre-integration, PoseSize 15 (n = 75 000), through the C++ class.  Property gate: result codes,
+    dogleg steps accepted, errors decrease, repeated Solve(1) on the warm object (no rebuild)."""
+    P, L = 5000, 500000
+    sc = scene.make_scene(P, L, 10, lm_dim=1, seed=3)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    h = adjuster.BundleAdjuster(1, 15)
+    o = adjuster.default_options()
+    o.use_dogleg = 1
+    o.error_change_threshold = 0
+    o.param_change_threshold = 0
+    h.Init(o)
+    h.SetGravity(sc.gravity)
+    fill(h, sc)
+    for i in range(P - 1):
+        h.AddImuResidual(i, i + 1, sc.imu_meas[i])
+    tot = []
+    for it in range(3):
+        h.Solve(1)
+        s = h.summary()
+        assert adjuster.RESULT_NAMES[s.result] == "Success", adjuster.RESULT_NAMES[s.result]
+        assert np.isfinite(s.proj_error) and np.isfinite(s.inertial_error) and np.isfinite(s.delta_norm)
+        assert s.post_solve_norm <= s.pre_solve_norm
+        tot.append(s.post_solve_norm)
+    assert tot[2] < tot[1] < tot[0]
+    t, v, b = h.poses()
+    assert np.all(np.isfinite(t)) and np.all(np.isfinite(v)) and np.all(np.isfinite(b))
+    assert np.linalg.norm(t[:, :3] - sc.gt_poses[:, :3]) < np.linalg.norm(sc.poses[:, :3] - sc.gt_poses[:, :3])
+
+
+@pytest.mark.gpu
+def test_config4_full_size_all_residual_kinds(oracle_lib):
+    """BASELINE.json configs[4] at full size on ONE GPU: 10k poses / 1M landmarks / 10M residuals +
+    IMU + unary priors on every 100th pose + binary odometry, PoseSize 15, dogleg; n = 150 000 —
+    S is 180 GB of the 288 GB of HBM.  Property gate as for configs[2]."""
+    P, L = 10000, 1000000
+    sc = scene.make_scene(P, L, 10, lm_dim=1, seed=3)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    h = adjuster.BundleAdjuster(1, 15)
+    o = adjuster.default_options()
+    o.use_dogleg = 1
+    o.error_change_threshold = 0
+    o.param_change_threshold = 0
+    h.Init(o)
+    h.SetGravity(sc.gravity)
+    fill(h, sc)
+    _add_all_residual_kinds(h, sc, oracle_lib, P, unary_every=100)
+    tot = []
+    for it in range(2):
+        h.Solve(1)
+        s = h.summary()
+        assert adjuster.RESULT_NAMES[s.result] == "Success", adjuster.RESULT_NAMES[s.result]
+        for name in ("proj_error", "inertial_error", "unary_error", "binary_error", "delta_norm"):
+            assert np.isfinite(getattr(s, name)), name
+        assert s.post_solve_norm <= s.pre_solve_norm
+        tot.append(s.post_solve_norm)
+    assert tot[1] < tot[0]
+    t, v, b = h.poses()
+    assert np.all(np.isfinite(t)) and np.all(np.isfinite(v)) and np.all(np.isfinite(b))
