@@ -47,8 +47,12 @@ template <typename T>
 static int upload(Engine* e, DBuf<T>& buf, const std::vector<T>& v, size_t min_count = 0) {
   const size_t n = std::max(v.size(), min_count);
   BAE_HIP(buf.alloc(std::max<size_t>(n, 1)));
-  if (!v.empty())
+  if (!v.empty()) {
+    // the source is pageable host memory that the caller may free right after this returns (most
+    // call sites pass short-lived vectors): the copy must have read it by then, so drain the stream
     BAE_HIP(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+  }
   return 0;
 }
 

@@ -57,6 +57,28 @@ CONFIGS = {
 }
 
 
+def log(msg):
+    """progress on stderr (the JSON line on stdout stays alone)"""
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def usable_cpus(cap=16):
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the box's share
+    (16 for one GPU) — oversubscribed OpenMP teams spin against the CFS quota and crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def make_workload(cfg, P, L, K, lm_dim):
     sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=2)
     if cfg["imu"]:
@@ -250,6 +272,7 @@ def main():
 
     P, L, K, lm_dim = args.poses, args.landmarks, args.obs_per_landmark, args.lm_dim
     sc = make_workload(cfg, P, L, K, lm_dim)
+    log("scene ready: %d poses, %d landmarks" % (P, L))
 
     def barrier():
         if world > 1:
@@ -272,8 +295,10 @@ def main():
             # factorisation + broadcast (BA_BENCH_REPLICATED_SOLVE=1 keeps the replicated solve)
             if not os.environ.get("BA_BENCH_REPLICATED_SOLVE"):
                 eng.set_collectives(sharding.torch_collectives_hook(dist, "cuda"))
+        log("engine ready (setup %.2f s)" % t_setup)
         for _ in range(args.warmup):
             gn_step(eng)
+        log("warmup done")
         eng.set_profiling(True)
         barrier()
         t0 = time.perf_counter()
@@ -282,6 +307,7 @@ def main():
             accepted += int(ok)
         barrier()
         elapsed = time.perf_counter() - t0
+        log("timed region done: %.1f ms / step" % (1e3 * elapsed / args.steps))
         ks = eng.kernel_stats()
         timers = eng.get_timers()
         stats = eng.structure_stats() if world == 1 else {}
@@ -306,12 +332,15 @@ def main():
             for _ in range(reps):
                 h.Solve(1)
             api_ms = 1e3 * (time.perf_counter() - t1) / reps
+            log("C++ API path: first Solve(1) %.2f s, warm Solve(1) %.1f ms" % (first_solve_s, api_ms))
             del h
     else:
         h = build_adjuster(cfg, sc, lm_dim)
+        log("graph built on the host")
         t_setup = time.perf_counter()
         h.Solve(1)       # upload + structure build + the first iteration
         t_setup = time.perf_counter() - t_setup
+        log("first Solve(1): %.2f s" % t_setup)
         first_solve_s = t_setup
         for _ in range(max(args.warmup - 1, 0)):
             h.Solve(1)
@@ -324,6 +353,7 @@ def main():
             accepted += int(adjuster.RESULT_NAMES[s.result] == "Success")
             err = s.post_solve_norm if cfg["dogleg"] else s.proj_error + s.inertial_error + s.unary_error + s.binary_error
         elapsed = time.perf_counter() - t0
+        log("timed region done: %.1f ms / step" % (1e3 * elapsed / args.steps))
         ks = ev.kernel_stats()
         timers = ev.get_timers()
         stats = ev.structure_stats()
@@ -433,8 +463,10 @@ def main():
                 hk["pmc_GBs"] = hk["pmc_traffic_bytes"] / (hk["avg_launch_us"] * 1e-6) / 1e9
                 hk["pmc_frac_of_8TBs"] = hk["pmc_GBs"] / HBM_PEAK_GBS
         if not args.no_cpu_baseline and world == 1:
+            log("CPU baseline (oracle), 1 thread ...")
             out["cpu_baseline"] = cpu_baseline_record(cfg, args, n, O, 1)
-            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            log("CPU baseline, %d threads ..." % usable_cpus())
+            ncpu = usable_cpus()
             if ncpu > 1:
                 out["cpu_baseline_all_cores"] = cpu_baseline_record(cfg, args, n, O, ncpu)
             try:

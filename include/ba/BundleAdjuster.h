@@ -567,6 +567,22 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
     EnsureHostState();
     if (!UploadProblem()) return false;
   }
+  // reference parallel_algos.h:189-205 (ImuResidualT::covariance_computed lives with the residual:
+  // it survives Solve() calls until the problem is rebuilt by Init())
+  if (!Check(ba_hip_set_inertial_covariance_once(engine_, options_.calculate_inertial_covariance_once ? 1 : 0,
+                                                 imu_cov_reset_ ? 1 : 0),
+             "ba_hip_set_inertial_covariance_once")) return false;
+  imu_cov_reset_ = false;
+  {
+    // the noise diagonals come from imu_ (Init() fills them from the option sigmas; a caller may
+    // have replaced them with SetImuCalibration) — reference parallel_algos.h:204,288.  Like the
+    // gravity vector they take effect at ba_hip_begin_solve (no rebuild).
+    double r6[6], rb6[6];
+    for (int i = 0; i < 6; ++i) { r6[i] = (double)imu_.r[i]; rb6[i] = (double)imu_.r_b[i]; }
+    if (!Check(ba_hip_set_imu_noise(engine_, r6, rb6), "ba_hip_set_imu_noise")) return false;
+  }
+  const double g[3] = {imu_.g_vec[0], imu_.g_vec[1], imu_.g_vec[2]};
+  if (!Check(ba_hip_set_gravity(engine_, g), "ba_hip_set_gravity")) return false;
   return true;
 }
 

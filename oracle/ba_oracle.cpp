@@ -135,8 +135,8 @@ void se3_to7(const SE3& t, double* p) {
 // SimplicialLDLT<Upper> (BundleAdjuster.cpp:752-799): both read the upper triangle
 // only; any exact factorisation agrees to rounding for the SPD systems of this path.
 // Blocked right-looking so the CPU baseline is not needlessly slow.
-// g_ldlt_threads > 1: the "best-effort CPU" mode of BASELINE.md §3 (ii) — the rows of a panel and
-// of a trailing update are independent, so they are dealt to OpenMP threads; every element is
+// g_ldlt_threads > 1: the "best-effort CPU" mode of BASELINE.md §3 (ii) — the rows of a trailing
+// update (97 % of the flops) are independent, so they are dealt to OpenMP threads; every element is
 // computed by the same instruction sequence as with one thread (bitwise identical results).
 // 1 (default) is the reference-faithful mode: Eigen's LDLT is single-threaded.
 static int g_ldlt_threads = 1;
@@ -163,7 +163,6 @@ bool ldlt_solve_upper(uint32_t n, const double* s, const double* rhs, double* x)
       d[k] = dk;
       if (dk == 0.0 || std::isnan(dk)) ok = false;
       const double inv = 1.0 / dk;
-#pragma omp parallel for schedule(static) num_threads(nth) if (nth > 1 && n - k > 2048)
       for (uint32_t i = k + 1; i < n; ++i) {
         double v = A[(size_t)i * n + k];
         const double* li = &A[(size_t)i * n + k0];

@@ -16,7 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pyoracle as po  # noqa: E402
 
 po.build()
-ncpu = len(os.sched_getaffinity(0))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+ncpu = bench.usable_cpus()
 model = ""
 with open("/proc/cpuinfo") as f:
     for ln in f:
