@@ -234,4 +234,61 @@ BA_HD void proj_jacobians(const Cam& cam, const double* z, const double* x,
   }
 }
 
+// Same residual and Jacobians from fewer inputs — what k_linearize uses (one thread per
+// observation: every transform held in registers costs occupancy).  Identities used:
+//   point in the measuring vehicle frame   R_pw (Xw - rho t_wp) = R_vs (P - rho t_sv),  P = sensor-frame point
+//     =>  rotation columns of dz_dx_meas:   [.]x (R_vs d) = R_vs ((P - rho t_sv) x d)
+//   point in the reference vehicle frame   R_vs_r ray + rho t_vs_r = R_pw_r (Xw - rho t_wp_r)
+//     =>  rotation columns of dz_dx_ref:    R_pw_r (a x (Xw - rho t_wp_r)),  a = R_sw_m^T d
+// so T_wp of the measuring pose and T_vs of the reference camera are not needed.
+//   LM == 1: x = (ray, rho) in the reference sensor frame, t_ws_r / t_wp_r of the reference pose;
+//   LM == 3: x = homogeneous world point, t_ws_r / t_wp_r unused.
+template <int LM>
+BA_HD void proj_linearize(const Cam& cam, const double* z, const double* x, const Rt& t_sw_m, const M3& R_vs_m,
+                          V3 t_sv_m, const Rt& t_ws_r, const Rt& t_wp_r, bool same_pose, ProjJac<LM>* out) {
+  const V3 xv = v3(x[0], x[1], x[2]);
+  const double rho = x[3];
+  V3 Xw = xv;  // world point, scaled by rho for LM == 1
+  if (LM == 1) Xw = mul(t_ws_r.R, xv) + t_ws_r.t * rho;
+  const V3 P = mul(t_sw_m.R, Xw) + t_sw_m.t * rho;
+  double u, v;
+  project(cam, P, &u, &v);
+  out->r[0] = z[0] - u;
+  out->r[1] = z[1] - v;
+  V3 d0, d1;
+  dproject(cam, P, &d0, &d1);
+  const V3 a0 = mulT(t_sw_m.R, d0), a1 = mulT(t_sw_m.R, d1);  // rows of dpi R_sw_m
+  if (LM == 1) {
+    const V3 tt = mul(t_sw_m.R, t_ws_r.t) + t_sw_m.t;  // translation of T_sw_m T_ws_r
+    out->jl[0] = -dot(d0, tt);
+    out->jl[1] = -dot(d1, tt);
+  } else if (LM == 3) {
+    out->jl[0] = -a0.x; out->jl[1] = -a0.y; out->jl[2] = -a0.z;
+    out->jl[3] = -a1.x; out->jl[4] = -a1.y; out->jl[5] = -a1.z;
+  }
+  // same_pose (parallel_algos.h:97-99,111-113): both pose blocks are zero — applied as a factor
+  // (0 or 1) at the end rather than an early return, so that every output stays in registers
+  const double keep = same_pose ? 0.0 : 1.0;
+  const double rk = rho * keep;
+  {
+    out->jm[0] = rk * a0.x; out->jm[1] = rk * a0.y; out->jm[2] = rk * a0.z;
+    out->jm[6] = rk * a1.x; out->jm[7] = rk * a1.y; out->jm[8] = rk * a1.z;
+    const V3 q = (P - t_sv_m * rho) * keep;
+    const V3 c0 = mul(R_vs_m, cross(q, d0)), c1 = mul(R_vs_m, cross(q, d1));
+    out->jm[3] = c0.x; out->jm[4] = c0.y; out->jm[5] = c0.z;
+    out->jm[9] = c1.x; out->jm[10] = c1.y; out->jm[11] = c1.z;
+  }
+  if (LM == 1) {
+    out->jr[0] = -rk * a0.x; out->jr[1] = -rk * a0.y; out->jr[2] = -rk * a0.z;
+    out->jr[6] = -rk * a1.x; out->jr[7] = -rk * a1.y; out->jr[8] = -rk * a1.z;
+    const V3 y = (Xw - t_wp_r.t * rho) * keep;
+    const V3 f0 = mulT(t_wp_r.R, cross(a0, y)), f1 = mulT(t_wp_r.R, cross(a1, y));
+    out->jr[3] = f0.x; out->jr[4] = f0.y; out->jr[5] = f0.z;
+    out->jr[9] = f1.x; out->jr[10] = f1.y; out->jr[11] = f1.z;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) out->jr[i] = 0.0;
+  }
+}
+
 }  // namespace bad

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/ba_hip.h"
+#include "structure.h"
 
 namespace bae {
 
@@ -37,45 +38,9 @@ static const int kPoseState = 16;
 // one factor row: 6 doubles (see DESIGN.md "factor rows")
 static const int kRow = 6;
 
-struct Problem {  // host copies, reference ids
-  uint32_t num_cams = 0, num_poses = 0, num_lms = 0, num_proj = 0;
-  uint32_t num_unary = 0, num_binary = 0, num_imu = 0;
-  std::vector<double> cam_params, cam_tvs;                 // [C][4], [C][7]
-  std::vector<double> pose_cam_params;                     // [P][4] or empty (use_per_pose_cam_params)
-  std::vector<double> imu_noise;                           // r(6) | r_b(6) or empty (from the option sigmas)
-  std::vector<double> pose_state;                          // [P][16]
-  std::vector<uint8_t> pose_active;
-  std::vector<double> lm_xw;                               // [L][4]
-  std::vector<uint32_t> lm_ref_pose, lm_ref_cam;
-  std::vector<uint8_t> lm_active;
-  std::vector<double> proj_z, proj_w;                      // [O][2], [O]
-  std::vector<uint32_t> proj_pose, proj_lm, proj_cam;
-  // pose-pose residuals
-  std::vector<uint32_t> un_pose; std::vector<double> un_t, un_cov_inv; std::vector<uint8_t> un_rot;
-  std::vector<uint32_t> bin_p1, bin_p2; std::vector<double> bin_t, bin_cov_inv, bin_cov_inv_sqrt, bin_w;
-  std::vector<uint8_t> bin_rot;
-  std::vector<uint32_t> imu_p1, imu_p2, imu_ptr; std::vector<double> imu_meas, imu_w;
-  double gravity[3] = {0, 0, -9.8007};
-};
-
-// Host-built structure (ba_hip_finalize)
-struct Structure {
-  uint32_t P = 0, Pact = 0, L = 0, Lact = 0, O = 0, C = 0;
-  uint32_t n = 0;         // pose_dim * Pact
-  uint32_t ld = 0;        // leading dimension of the dense reduced system (>= n+1, padded)
-  uint32_t n_inc = 0;     // pose-landmark incidences (active pose, active landmark)
-  uint32_t n_jslots = 0;  // (observation, side) slots carrying pose Jacobian rows
-  uint32_t jbase = 0;     // first J factor row (the W / -W V^-1 rows of the incidences come first)
-  uint32_t n_rows = 0;    // factor rows
-  uint32_t n_pairs = 0;   // pose pairs (i <= j) with a block in S
-  uint64_t n_pair_entries = 0;
-  uint64_t n_rhs_entries = 0;
+// Host-built structure (ba_hip_finalize): the lists of structure.h + the pose-pose scatter count
+struct Structure : Lists {
   uint32_t n_pp_entries = 0;  // (pose, residual side) entries of the pose-pose scatter
-  std::vector<int32_t> pose_opt, lm_opt;
-  std::vector<uint32_t> obs_perm;  // sorted position -> residual id
-  // 64x64-tile pattern of S of THIS shard (nt x nt bytes, symmetric, nt = ld / 64): which tiles
-  // the gather lists and the pose-pose residuals can touch
-  std::vector<uint8_t> tile_nz;
 };
 
 struct Engine {
@@ -111,17 +76,13 @@ struct Engine {
   DBuf<double> obs_z;               // [O][2]
   DBuf<uint32_t> obs_pose, obs_cam, obs_lm, obs_rid;
   DBuf<double> obs_w0;
-  DBuf<int32_t> obs_jrow_m, obs_jrow_r;  // first factor row of the (obs,side) slot or -1
-  DBuf<int32_t> obs_wrow_m;              // first W factor row of the (meas pose, landmark) incidence or -1
-  DBuf<uint8_t> obs_first;               // 1 = first observation of its meas incidence
-  DBuf<int32_t> lm_wrow_r;               // first W factor row of the reference incidence or -1
-  DBuf<uint32_t> linc_ptr;               // [L+1] landmark-major incidence list
-  DBuf<uint32_t> linc_row;               // first W factor row of each incidence
-  DBuf<uint32_t> linc_pose;              // pose opt id of each incidence
-  // gather lists
-  DBuf<uint32_t> pair_ptr;               // [n_pairs+1] (64-bit offsets split? entries < 2^32 assumed)
-  DBuf<uint2> pair_ij;
-  DBuf<uint2> pair_ent;                  // (rowA, rowB)
+  // static lists of structure.h
+  DBuf<uint2> wave_rng;                  // [n_chunks] observation ranges of the linearisation waves
+  DBuf<uint32_t> tile_ptr;               // [tiles_lower+1]
+  DBuf<uint2> tile_ref;                  // (first term, count << 14 | offsets) per block overlapping a tile
+  DBuf<uint2> pair_ent;                  // (rowA, rowB) rank-1 terms of the off-diagonal blocks
+  DBuf<uint32_t> pose_ptr, pose_mid;     // [Pact+1], [Pact]
+  DBuf<uint32_t> pose_ent;               // 3 x n_pose_entries: (rowA, rowB, scalar index)
   DBuf<uint8_t> nzL;                     // tile pattern of the factor L (nt x nt bytes, lower), see k_chol.hip
   bool nzL_valid = false;
   std::vector<uint8_t> nzL_host;         // host copy (flop accounting of the profiled launches)
@@ -136,9 +97,6 @@ struct Engine {
   uint64_t dist_rows_version = ~0ull;
   DBuf<double> dist_msg;                 // panel broadcast message (distributed solve)
   DBuf<double> packed;                   // packed lower triangle + rhs row (all-reduce staging)
-  DBuf<uint32_t> pose_rows;              // [2*(Pact+1)]: pose-major J-slot ptr | incidence ptr
-  DBuf<uint32_t> prhs_ptr;               // [Pact+1]
-  DBuf<uint2> prhs_ent;                  // (row, scalar index)
 
   // pose-pose residuals (unary | binary | imu slots)
   DBuf<uint8_t> pose_active;
@@ -167,8 +125,8 @@ struct Engine {
   // ---- device: per-iteration
   DBuf<double> obs_e, obs_w;             // error for the median, robust weight
   DBuf<double> obs_jl;                   // [O][2*lm] sqrt(w) * dz_dlm (dogleg J_l * rhs_l)
-  DBuf<double> frow;                     // [n_rows][6]
-  DBuf<double> scal;                     // scalars: [2*O] sqrt(w) r, then [L*lm] b_l
+  DBuf<double> frow;                     // [n_rows][6] observation-major factor rows (structure.h)
+  DBuf<double> scal;                     // scalars: [2*O] sqrt(w) r, then [L*lm] b_l, then one 0
   DBuf<double> lm_vinv, lm_bl;           // [L][lm*lm], [L][lm]
   DBuf<double> A;                        // [(n+1)][ld] lower storage + rhs row
   DBuf<double> A_keep;                   // copy of A before factorisation (debug option)
@@ -183,7 +141,7 @@ struct Engine {
   // optional per-kernel timing (ba_hip_set_profiling)
   bool profiling = false;
   ba_hip_kernel_stats kstats = {};
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_syrk, ev_gather, ev_landmarks, ev_imu;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_syrk, ev_gather, ev_landmarks, ev_imu, ev_pose;
   void prof_begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t s = nullptr) {
     if (!profiling) return;
     hipEvent_t a, b;

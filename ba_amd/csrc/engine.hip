@@ -37,6 +37,7 @@ void Engine::prof_collect() {
   drain(ev_gather, kstats.gather_ms, kstats.gather_launches);
   drain(ev_landmarks, kstats.landmarks_ms, kstats.landmarks_launches);
   drain(ev_imu, kstats.imu_ms, kstats.imu_launches);
+  drain(ev_pose, kstats.pose_blocks_ms, kstats.pose_blocks_launches);
 }
 int Engine::fail_msg(const char* what) {
   err = what;
@@ -75,15 +76,6 @@ struct EventTimer {
   }
 };
 
-struct PairRec { uint64_t key; uint32_t a, b; };
-
-// threads for the host-side structure build (BA_HIP_HOST_THREADS overrides; at most 16)
-static unsigned host_threads() {
-  if (const char* v = getenv("BA_HIP_HOST_THREADS")) return (unsigned)std::max(1, atoi(v));
-  const unsigned hc = std::thread::hardware_concurrency();
-  return std::min(16u, std::max(1u, hc));
-}
-
 // gravity | measurement noise diag (gyro^2 x3, accel^2 x3) | bias random walk.  Not part of the
 // structure: refreshed by every ba_hip_begin_solve, so SetGravity / SetImuCalibration / new option
 // sigmas between two Solve() calls need no ba_hip_finalize.
@@ -102,7 +94,8 @@ static int upload_imu_consts(Engine* e) {
   return upload(e, e->imu_consts, c);
 }
 
-// Build everything that depends only on the problem graph (not on the state).
+// Build everything that depends only on the problem graph (not on the state): the lists of
+// structure.h on the host (threads), the pose-pose scatter lists, the tile pattern; then upload.
 static int build_structure(Engine* e) {
   Problem& pb = e->prob;
   Structure& st = e->st;
@@ -115,312 +108,15 @@ static int build_structure(Engine* e) {
     fprintf(stderr, "[setup] %-28s %.3f s\n", name, std::chrono::duration<double>(now - t_stage).count());
     t_stage = now;
   };
-  const int LM = e->lm_dim, D = e->pose_dim;
-  st.P = pb.num_poses; st.L = pb.num_lms; st.O = pb.num_proj; st.C = pb.num_cams;
-  if (st.O > 0 && st.C == 0) return e->fail_msg("projection residuals without a camera");
-  // opt ids: running count of active items in id order (BundleAdjuster.h:309-316,353-360)
-  st.pose_opt.assign(st.P, -1);
-  st.Pact = 0;
-  for (uint32_t p = 0; p < st.P; ++p)
-    if (pb.pose_active[p]) st.pose_opt[p] = (int32_t)st.Pact++;
-  st.lm_opt.assign(st.L, -1);
-  st.Lact = 0;
-  for (uint32_t l = 0; l < st.L; ++l)
-    if (pb.lm_active[l] && LM > 0) st.lm_opt[l] = (int32_t)st.Lact++;
-  st.n = st.Pact * D;
-  st.ld = ((st.n + 63) / 64) * 64;
-  if (st.ld == 0) st.ld = 64;
-
-  for (uint32_t a = 0; a < st.O; ++a) {
-    if (pb.proj_pose[a] >= st.P || pb.proj_lm[a] >= st.L || pb.proj_cam[a] >= st.C)
-      return e->fail_msg("projection residual references an unknown pose/landmark/camera");
-  }
-  for (uint32_t l = 0; l < st.L; ++l)
-    if (pb.lm_ref_pose[l] >= st.P || (st.C > 0 && pb.lm_ref_cam[l] >= st.C))
-      return e->fail_msg("landmark references an unknown pose/camera");
-
-  // ---- observations sorted by landmark (stable in residual id) --------------------
-  std::vector<uint32_t> lm_ptr(st.L + 1, 0);
-  for (uint32_t a = 0; a < st.O; ++a) lm_ptr[pb.proj_lm[a] + 1]++;
-  for (uint32_t l = 0; l < st.L; ++l) lm_ptr[l + 1] += lm_ptr[l];
-  st.obs_perm.assign(st.O, 0);
+  const int LM = e->lm_dim;
   {
-    std::vector<uint32_t> cur(lm_ptr.begin(), lm_ptr.end() - 1);
-    for (uint32_t a = 0; a < st.O; ++a) st.obs_perm[cur[pb.proj_lm[a]]++] = a;
-  }
-  std::vector<double> obs_z(2 * (size_t)st.O), obs_w0(st.O);
-  std::vector<uint32_t> obs_pose(st.O), obs_cam(st.O), obs_lm(st.O), obs_rid(st.O);
-  for (uint32_t s = 0; s < st.O; ++s) {
-    const uint32_t a = st.obs_perm[s];
-    obs_z[2 * (size_t)s] = pb.proj_z[2 * (size_t)a];
-    obs_z[2 * (size_t)s + 1] = pb.proj_z[2 * (size_t)a + 1];
-    obs_w0[s] = pb.proj_w[a];
-    obs_pose[s] = pb.proj_pose[a]; obs_cam[s] = pb.proj_cam[a];
-    obs_lm[s] = pb.proj_lm[a]; obs_rid[s] = a;
-  }
-
-  stage("obs sort by landmark");
-  // ---- Jacobian slots (obs, side) and incidences ---------------------------------
-  // A residual carries pose Jacobian blocks iff it is "listed" (it passed the
-  // diff_poses test of AddProjectionResidual, BundleAdjuster.h:489-497) and the pose
-  // is active (blocks are only inserted for active poses, BundleAdjuster.cpp:1613-1643).
-  auto listed = [&](uint32_t s) {
-    return LM != 1 || obs_pose[s] != pb.lm_ref_pose[obs_lm[s]];
-  };
-  // per-landmark incidences (landmark-major), distinct active poses
-  std::vector<uint32_t> linc_ptr(st.L + 1, 0);
-  std::vector<uint32_t> linc_pose_lm;               // pose opt id, landmark-major
-  std::vector<int32_t> obs_linc_m(st.O, -1);        // landmark-major incidence index of the meas side
-  std::vector<int32_t> lm_linc_r(st.L, -1);
-  std::vector<uint8_t> obs_first(st.O, 0);
-  {
-    std::vector<std::pair<uint32_t, uint32_t>> tmp;  // (pose opt, first obs)
-    for (uint32_t l = 0; l < st.L; ++l) {
-      linc_ptr[l] = (uint32_t)linc_pose_lm.size();
-      if (st.lm_opt[l] < 0) continue;
-      tmp.clear();
-      bool any_listed = false;
-      for (uint32_t s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
-        if (!listed(s)) continue;
-        any_listed = true;
-        const int32_t po = st.pose_opt[obs_pose[s]];
-        if (po < 0) continue;
-        bool found = false;
-        for (auto& t : tmp) if (t.first == (uint32_t)po) { found = true; break; }
-        if (!found) tmp.push_back({(uint32_t)po, s});
-      }
-      const int32_t ro = (LM == 1) ? st.pose_opt[pb.lm_ref_pose[l]] : -1;
-      const bool ref_inc = LM == 1 && ro >= 0 && any_listed;
-      std::vector<uint32_t> poses;
-      for (auto& t : tmp) poses.push_back(t.first);
-      if (ref_inc) poses.push_back((uint32_t)ro);
-      std::sort(poses.begin(), poses.end());
-      const uint32_t base = (uint32_t)linc_pose_lm.size();
-      for (uint32_t p : poses) linc_pose_lm.push_back(p);
-      auto find = [&](uint32_t po) {
-        return base + (uint32_t)(std::lower_bound(poses.begin(), poses.end(), po) - poses.begin());
-      };
-      for (auto& t : tmp) obs_first[t.second] = 1;
-      for (uint32_t s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
-        if (!listed(s)) continue;
-        const int32_t po = st.pose_opt[obs_pose[s]];
-        if (po >= 0) obs_linc_m[s] = (int32_t)find((uint32_t)po);
-      }
-      if (ref_inc) lm_linc_r[l] = (int32_t)find((uint32_t)ro);
+    std::string err;
+    if (!build_lists(pb, LM, e->pose_dim, st, err, stage)) {
+      e->err = err;
+      return -1;
     }
-    linc_ptr[st.L] = (uint32_t)linc_pose_lm.size();
+    st.n_pp_entries = 0;
   }
-  st.n_inc = (uint32_t)linc_pose_lm.size();
-  // pose-major renumbering of incidences (stable in landmark order)
-  std::vector<uint32_t> pinc_ptr(st.Pact + 1, 0), inc_pm(st.n_inc);
-  for (uint32_t q = 0; q < st.n_inc; ++q) pinc_ptr[linc_pose_lm[q] + 1]++;
-  for (uint32_t p = 0; p < st.Pact; ++p) pinc_ptr[p + 1] += pinc_ptr[p];
-  {
-    std::vector<uint32_t> cur(pinc_ptr.begin(), pinc_ptr.end() - 1);
-    for (uint32_t q = 0; q < st.n_inc; ++q) inc_pm[q] = cur[linc_pose_lm[q]]++;
-  }
-  // J slots, pose-major
-  std::vector<uint32_t> pslot_ptr(st.Pact + 1, 0);
-  auto meas_opt = [&](uint32_t s) { return listed(s) ? st.pose_opt[obs_pose[s]] : -1; };
-  auto ref_opt = [&](uint32_t s) {
-    return (LM == 1 && listed(s)) ? st.pose_opt[pb.lm_ref_pose[obs_lm[s]]] : -1;
-  };
-  for (uint32_t s = 0; s < st.O; ++s) {
-    const int32_t m = meas_opt(s), r = ref_opt(s);
-    if (m >= 0) pslot_ptr[m + 1]++;
-    if (r >= 0) pslot_ptr[r + 1]++;
-  }
-  for (uint32_t p = 0; p < st.Pact; ++p) pslot_ptr[p + 1] += pslot_ptr[p];
-  st.n_jslots = pslot_ptr[st.Pact];
-  const uint32_t wrows = st.n_inc * 2 * (uint32_t)std::max(LM, 1);
-  const uint32_t jbase = (LM > 0) ? st.n_inc * 2 * LM : 0;
-  (void)wrows;
-  std::vector<int32_t> obs_jrow_m(st.O, -1), obs_jrow_r(st.O, -1), obs_wrow_m(st.O, -1);
-  std::vector<int32_t> lm_wrow_r(st.L, -1);
-  {
-    std::vector<uint32_t> cur(pslot_ptr.begin(), pslot_ptr.end() - 1);
-    for (uint32_t s = 0; s < st.O; ++s) {
-      const int32_t m = meas_opt(s), r = ref_opt(s);
-      if (m >= 0) obs_jrow_m[s] = (int32_t)(jbase + 2 * cur[m]++);
-      if (r >= 0) obs_jrow_r[s] = (int32_t)(jbase + 2 * cur[r]++);
-      if (obs_linc_m[s] >= 0) obs_wrow_m[s] = (int32_t)(inc_pm[obs_linc_m[s]] * 2 * LM);
-    }
-    for (uint32_t l = 0; l < st.L; ++l)
-      if (lm_linc_r[l] >= 0) lm_wrow_r[l] = (int32_t)(inc_pm[lm_linc_r[l]] * 2 * LM);
-  }
-  st.n_rows = jbase + 2 * st.n_jslots + 1;  // last row: all zeros
-  st.jbase = jbase;
-  const uint32_t zero_row = st.n_rows - 1;
-  std::vector<uint32_t> linc_row(st.n_inc);
-  for (uint32_t q = 0; q < st.n_inc; ++q) linc_row[q] = inc_pm[q] * 2 * LM;
-
-  stage("jacobian slots / incidences");
-  // ---- gather lists for S ------------------------------------------------------------
-  // 75 M records at configs[3]: generated, radix-sorted (stable, so the order of the terms of a
-  // block — and with it every bit of S — does not depend on the thread count) and cut into pairs
-  // by a pool of host threads.
-  const unsigned T = host_threads();
-  auto parallel_for = [&](size_t count, const std::function<void(unsigned, size_t, size_t)>& fn) {
-    if (T <= 1 || count < (1u << 16)) { fn(0, 0, count); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t, count * t / T, count * (t + 1) / T);
-    for (auto& x : th) x.join();
-  };
-  auto key = [](uint32_t i, uint32_t j) { return ((uint64_t)i << 32) | j; };
-  // The diagonal blocks (i,i) are NOT in the lists: their terms — J^T J over the pose's own
-  // J rows, (-W V^-1) W^T over its own incidences — are contiguous row ranges in the
-  // pose-major numbering and are streamed by k_gather_S_diag.
-  (void)zero_row;
-  // record offsets: landmark l emits m(m-1)/2 * LM records, observation s 0 / 2 / 4
-  std::vector<size_t> lm_off((size_t)st.L + 1, 0), obs_off((size_t)st.O + 1, 0);
-  for (uint32_t l = 0; l < st.L; ++l) {
-    const size_t m = linc_ptr[l + 1] - linc_ptr[l];
-    lm_off[l + 1] = lm_off[l] + m * (m - 1) / 2 * LM;
-  }
-  parallel_for(st.O, [&](unsigned, size_t s0, size_t s1) {
-    for (size_t s = s0; s < s1; ++s) {
-      const int32_t m = meas_opt((uint32_t)s), r = ref_opt((uint32_t)s);
-      obs_off[s + 1] = (m >= 0 && r >= 0) ? (m == r ? 4 : 2) : 0;
-    }
-  });
-  for (uint32_t s = 0; s < st.O; ++s) obs_off[s + 1] += obs_off[s];
-  const size_t n_lm_recs = lm_off[st.L], n_recs = n_lm_recs + obs_off[st.O];
-  if (n_recs >= 0xFFFFFFFFull) return e->fail_msg("gather list exceeds 2^32 entries");
-  // uninitialised: the pages are first touched by the threads that fill them
-  std::unique_ptr<PairRec[]> recs(new PairRec[std::max<size_t>(n_recs, 1)]);
-  // landmarks: chunks of equal record count
-  const unsigned lm_parts = (T > 1 && n_lm_recs >= (1u << 16)) ? T : 1;
-  auto lm_part = [&](unsigned cpart) {
-    {
-      const size_t lo = n_lm_recs * cpart / lm_parts, hi = n_lm_recs * (cpart + 1) / lm_parts;
-      uint32_t l = (uint32_t)(std::upper_bound(lm_off.begin(), lm_off.end(), lo) - lm_off.begin());
-      l = l ? l - 1 : 0;
-      while (l < st.L && lm_off[l] < lo) ++l;  // first landmark starting at or after lo
-      for (; l < st.L && lm_off[l] < hi; ++l) {
-        size_t w = lm_off[l];
-        for (uint32_t qa = linc_ptr[l]; qa < linc_ptr[l + 1]; ++qa)
-          for (uint32_t qb = qa + 1; qb < linc_ptr[l + 1]; ++qb) {  // poses ascending within a landmark
-            const uint32_t ia = linc_pose_lm[qa], ib = linc_pose_lm[qb];
-            for (int k = 0; k < LM; ++k)
-              recs[w++] = {key(ia, ib), linc_row[qa] + LM + k, linc_row[qb] + k};  // (-W V^-1)_a W_b^T
-          }
-      }
-    }
-  };
-  if (lm_parts == 1) lm_part(0);
-  else {
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < lm_parts; ++t) th.emplace_back(lm_part, t);
-    for (auto& x : th) x.join();
-  }
-  parallel_for(st.O, [&](unsigned, size_t s0, size_t s1) {
-    for (size_t s = s0; s < s1; ++s) {
-      if (obs_off[s + 1] == obs_off[s]) continue;
-      const int32_t m = meas_opt((uint32_t)s), r = ref_opt((uint32_t)s);
-      const int32_t jm = obs_jrow_m[s], jr = obs_jrow_r[s];
-      size_t w = n_lm_recs + obs_off[s];
-      for (int k = 0; k < 2; ++k) {
-        if (m < r) recs[w++] = {key(m, r), (uint32_t)jm + k, (uint32_t)jr + k};
-        else if (r < m) recs[w++] = {key(r, m), (uint32_t)jr + k, (uint32_t)jm + k};
-        else {  // both sides on the same pose: J = J_m + J_r, the two cross terms
-          recs[w++] = {key(m, m), (uint32_t)jm + k, (uint32_t)jr + k};
-          recs[w++] = {key(m, m), (uint32_t)jr + k, (uint32_t)jm + k};
-        }
-      }
-    }
-  });
-  {
-    int bits = 1;
-    while ((1u << bits) < std::max(st.Pact, 2u)) ++bits;
-    // sort by j (low 32 bits) then i (high 32 bits): 16-bit digit passes, stable; per-thread
-    // histograms, bucket offsets digit-major then thread-major
-    std::unique_ptr<PairRec[]> t2(new PairRec[std::max<size_t>(n_recs, 1)]);
-    std::vector<std::vector<size_t>> cnt(T > 1 ? T : 1, std::vector<size_t>(65536));
-    auto radix_pass = [&](int shift) {
-      parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
-        std::vector<size_t>& c = cnt[t];
-        std::fill(c.begin(), c.end(), 0);
-        for (size_t i = i0; i < i1; ++i) c[(recs[i].key >> shift) & 0xFFFF]++;
-      });
-      const bool par = !(T <= 1 || n_recs < (1u << 16));
-      const unsigned used = par ? T : 1;
-      size_t run = 0;
-      for (int d = 0; d < 65536; ++d)
-        for (unsigned t = 0; t < used; ++t) { const size_t c = cnt[t][d]; cnt[t][d] = run; run += c; }
-      parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
-        std::vector<size_t>& c = cnt[t];
-        for (size_t i = i0; i < i1; ++i) t2[c[(recs[i].key >> shift) & 0xFFFF]++] = recs[i];
-      });
-      recs.swap(t2);
-    };
-    for (int shift = 0; shift < bits; shift += 16) radix_pass(shift);
-    for (int shift = 32; shift < 32 + bits; shift += 16) radix_pass(shift);
-  }
-  // cut into pairs: a pair starts where the key changes
-  std::vector<uint32_t> pair_ptr;
-  std::vector<uint2> pair_ij;
-  std::unique_ptr<uint2[]> pair_ent(new uint2[std::max<size_t>(n_recs, 1)]);
-  {
-    const unsigned parts = (T <= 1 || n_recs < (1u << 16)) ? 1 : T;
-    std::vector<size_t> nstart(parts + 1, 0);
-    parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
-      size_t c = 0;
-      for (size_t i = i0; i < i1; ++i) {
-        c += (i == 0 || recs[i].key != recs[i - 1].key);
-        pair_ent[i] = make_uint2(recs[i].a, recs[i].b);
-      }
-      nstart[t + 1] = c;
-    });
-    for (unsigned t = 0; t < parts; ++t) nstart[t + 1] += nstart[t];
-    pair_ptr.resize(nstart[parts] + 1);
-    pair_ij.resize(nstart[parts]);
-    parallel_for(n_recs, [&](unsigned t, size_t i0, size_t i1) {
-      size_t w = nstart[t];
-      for (size_t i = i0; i < i1; ++i)
-        if (i == 0 || recs[i].key != recs[i - 1].key) {
-          pair_ptr[w] = (uint32_t)i;
-          pair_ij[w++] = make_uint2((uint32_t)(recs[i].key >> 32), (uint32_t)(recs[i].key & 0xFFFFFFFFu));
-        }
-    });
-    pair_ptr[nstart[parts]] = (uint32_t)n_recs;
-  }
-  st.n_pairs = (uint32_t)pair_ij.size();
-  st.n_pair_entries = n_recs;
-  recs.reset();
-
-  stage("S gather lists");
-  // ---- gather lists for rhs -------------------------------------------------------------
-  // per active pose: [observation rows | incidence rows]; scalars: sqrt(w) r at 2*obs,
-  // b_l at 2*O + l*LM
-  std::vector<uint32_t> prhs(2 * (size_t)st.Pact + 1, 0);
-  std::vector<uint32_t> cntA(st.Pact, 0), cntB(st.Pact, 0);
-  for (uint32_t s = 0; s < st.O; ++s) {
-    const int32_t m = meas_opt(s), r = ref_opt(s);
-    if (m >= 0) cntA[m] += 2;
-    if (r >= 0) cntA[r] += 2;
-  }
-  for (uint32_t q = 0; q < st.n_inc; ++q) cntB[linc_pose_lm[q]] += LM;
-  for (uint32_t p = 0; p < st.Pact; ++p) {
-    prhs[p + 1] = prhs[p] + cntA[p] + cntB[p];
-    prhs[st.Pact + 1 + p] = prhs[p] + cntA[p];
-  }
-  st.n_rhs_entries = st.Pact ? prhs[st.Pact] : 0;
-  std::vector<uint2> prhs_ent(st.n_rhs_entries);
-  {
-    std::vector<uint32_t> curA(st.Pact), curB(st.Pact);
-    for (uint32_t p = 0; p < st.Pact; ++p) { curA[p] = prhs[p]; curB[p] = prhs[st.Pact + 1 + p]; }
-    for (uint32_t s = 0; s < st.O; ++s) {
-      const int32_t m = meas_opt(s), r = ref_opt(s);
-      if (m >= 0) for (uint32_t k = 0; k < 2; ++k) prhs_ent[curA[m]++] = make_uint2(obs_jrow_m[s] + k, 2 * s + k);
-      if (r >= 0) for (uint32_t k = 0; k < 2; ++k) prhs_ent[curA[r]++] = make_uint2(obs_jrow_r[s] + k, 2 * s + k);
-    }
-    for (uint32_t l = 0; l < st.L; ++l)
-      for (uint32_t q = linc_ptr[l]; q < linc_ptr[l + 1]; ++q)
-        for (int k = 0; k < LM; ++k)
-          prhs_ent[curB[linc_pose_lm[q]]++] = make_uint2(linc_row[q] + LM + k, 2 * st.O + l * LM + k);
-  }
-
-  stage("rhs gather lists");
   // ---- pose-pose residuals: slots [unary | binary | imu], scatter lists per active pose ------
   const uint32_t nu = pb.num_unary, nbn = pb.num_binary, ni = pb.num_imu, nres = nu + nbn + ni;
   std::vector<uint32_t> res_p1(nres), res_p2(nres, 0xffffffffu);
@@ -452,24 +148,21 @@ static int build_structure(Engine* e) {
   }
 
   stage("pose-pose lists");
-  // ---- 64x64-tile pattern of S (for the tile-sparse factorisation) ---------------------------
+  // ---- 64x64-tile pattern of S (for the tile-sparse factorisation): build_lists marked the tiles
+  // of the projection part and the diagonal; add the pose-pose residual blocks ------------------------
   {
     const uint32_t nt = st.ld / 64, D = (uint32_t)e->pose_dim;
-    st.tile_nz.assign((size_t)nt * nt, 0);
     auto mark = [&](uint32_t pi, uint32_t pj) {  // all tiles the D x D block (pi, pj) overlaps
       const uint32_t r0 = pi * D / 64, r1 = (pi * D + D - 1) / 64;
       const uint32_t c0 = pj * D / 64, c1 = (pj * D + D - 1) / 64;
       for (uint32_t r = r0; r <= r1; ++r)
         for (uint32_t c = c0; c <= c1; ++c) { st.tile_nz[(size_t)r * nt + c] = 1; st.tile_nz[(size_t)c * nt + r] = 1; }
     };
-    for (uint32_t p = 0; p < st.Pact; ++p) mark(p, p);
-    for (const uint2& ij : pair_ij) mark(ij.x, ij.y);
     for (uint32_t s = 0; s < nres; ++s) {
       const int32_t o1 = st.pose_opt[res_p1[s]];
       const int32_t o2 = res_p2[s] != 0xffffffffu ? st.pose_opt[res_p2[s]] : -1;
       if (o1 >= 0 && o2 >= 0) mark((uint32_t)o1, (uint32_t)o2);
     }
-    for (uint32_t t = 0; t < nt; ++t) st.tile_nz[(size_t)t * nt + t] = 1;  // padding identity
     e->nzL_valid = false;
   }
 
@@ -479,21 +172,28 @@ static int build_structure(Engine* e) {
 #define UP(buf, vec) if ((rc = upload(e, e->buf, vec))) return rc
   UP(pose_opt, st.pose_opt); UP(lm_opt, st.lm_opt);
   UP(lm_ref_pose, pb.lm_ref_pose); UP(lm_ref_cam, pb.lm_ref_cam);
-  UP(lm_ptr, lm_ptr); UP(obs_z, obs_z); UP(obs_pose, obs_pose); UP(obs_cam, obs_cam);
-  UP(obs_lm, obs_lm); UP(obs_rid, obs_rid); UP(obs_w0, obs_w0);
-  UP(obs_jrow_m, obs_jrow_m); UP(obs_jrow_r, obs_jrow_r); UP(obs_wrow_m, obs_wrow_m);
-  UP(obs_first, obs_first); UP(lm_wrow_r, lm_wrow_r);
-  UP(linc_ptr, linc_ptr); UP(linc_row, linc_row); UP(linc_pose, linc_pose_lm);
-  UP(pair_ptr, pair_ptr); UP(pair_ij, pair_ij);
+  UP(lm_ptr, st.lm_ptr); UP(obs_z, st.obs_z); UP(obs_pose, st.obs_pose); UP(obs_cam, st.obs_cam);
+  UP(obs_lm, st.obs_lm); UP(obs_rid, st.obs_rid); UP(obs_w0, st.obs_w0);
+  UP(tile_ptr, st.tile_ptr); UP(pose_ptr, st.pose_ptr); UP(pose_mid, st.pose_mid);
+  static_assert(sizeof(U2) == sizeof(uint2) && sizeof(U3) == 3 * sizeof(uint32_t), "list records are plain words");
   BAE_HIP(e->pair_ent.alloc(std::max<size_t>(st.n_pair_entries, 1)));
   if (st.n_pair_entries)
-    BAE_HIP(hipMemcpyAsync(e->pair_ent.p, pair_ent.get(), st.n_pair_entries * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
-  UP(prhs_ptr, prhs); UP(prhs_ent, prhs_ent);
-  {
-    std::vector<uint32_t> pose_rows(pslot_ptr);
-    pose_rows.insert(pose_rows.end(), pinc_ptr.begin(), pinc_ptr.end());
-    UP(pose_rows, pose_rows);
-  }
+    BAE_HIP(hipMemcpyAsync(e->pair_ent.p, st.pair_ent.get(), st.n_pair_entries * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
+  BAE_HIP(e->wave_rng.alloc(std::max<size_t>(st.n_chunks, 1)));
+  if (st.n_chunks)
+    BAE_HIP(hipMemcpyAsync(e->wave_rng.p, st.wave_rng.data(), (size_t)st.n_chunks * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
+  BAE_HIP(e->tile_ref.alloc(std::max<size_t>(st.n_tile_refs, 1)));
+  if (st.n_tile_refs)
+    BAE_HIP(hipMemcpyAsync(e->tile_ref.p, st.tile_ref.data(), st.n_tile_refs * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
+  BAE_HIP(e->pose_ent.alloc(std::max<size_t>(3 * st.n_pose_entries, 1)));
+  if (st.n_pose_entries)
+    BAE_HIP(hipMemcpyAsync(e->pose_ent.p, st.pose_ent.data(), st.n_pose_entries * sizeof(U3), hipMemcpyHostToDevice, e->stream));
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  // the big host lists are only needed on the device from here on
+  st.pair_ent.reset();
+  std::vector<U2>().swap(st.tile_ref);
+  std::vector<U3>().swap(st.pose_ent);
+  std::vector<double>().swap(st.obs_z);
   UP(pose_active, pb.pose_active);
   UP(un_pose, pb.un_pose); UP(un_t, pb.un_t); UP(un_cov_inv, pb.un_cov_inv); UP(un_rot, pb.un_rot);
   UP(bin_p1, pb.bin_p1); UP(bin_p2, pb.bin_p2); UP(bin_t, pb.bin_t); UP(bin_cov_inv, pb.bin_cov_inv);
@@ -558,11 +258,11 @@ static int build_structure(Engine* e) {
   const int LM1 = std::max(LM, 1);
   BAE_HIP(e->obs_e.alloc(O1)); BAE_HIP(e->obs_w.alloc(O1));
   BAE_HIP(e->obs_jl.alloc(O1 * 2 * LM1));
-  if (st.O) BAE_HIP(hipMemcpyAsync(e->obs_w.p, obs_w0.data(), (size_t)st.O * sizeof(double),
+  if (st.O) BAE_HIP(hipMemcpyAsync(e->obs_w.p, st.obs_w0.data(), (size_t)st.O * sizeof(double),
                                    hipMemcpyHostToDevice, e->stream));
   BAE_HIP(e->frow.alloc((size_t)st.n_rows * kRow));
   BAE_HIP(hipMemsetAsync(e->frow.p, 0, e->frow.bytes(), e->stream));
-  BAE_HIP(e->scal.alloc(2 * O1 + L1 * LM1));
+  BAE_HIP(e->scal.alloc(std::max<size_t>(st.n_scalars, 2 * O1 + L1 * LM1 + 1)));  // last: the zero scalar
   BAE_HIP(hipMemsetAsync(e->scal.p, 0, e->scal.bytes(), e->stream));
   BAE_HIP(e->lm_vinv.alloc(L1 * LM1 * LM1)); BAE_HIP(e->lm_bl.alloc(L1 * LM1));
   BAE_HIP(hipMemsetAsync(e->lm_vinv.p, 0, e->lm_vinv.bytes(), e->stream));
@@ -577,8 +277,10 @@ static int build_structure(Engine* e) {
   BAE_HIP(e->gn_l.alloc(nl)); BAE_HIP(e->step_l.alloc(nl));
   BAE_HIP(hipMemsetAsync(e->gn_l.p, 0, e->gn_l.bytes(), e->stream));
   BAE_HIP(hipMemsetAsync(e->step_l.p, 0, e->step_l.bytes(), e->stream));
+  // reduction scratch: block partials of the element-wise kernels (up to 4 components) and one
+  // partial per linearisation wave
   const size_t nparts = std::max<size_t>({(O1 + 255) / 256, (L1 + 255) / 256, (size_t)(st.ld + 255) / 256, 1});
-  BAE_HIP(e->partials.alloc(4 * nparts));
+  BAE_HIP(e->partials.alloc(std::max<size_t>(4 * nparts, st.n_chunks)));
   BAE_HIP(e->scalars_out.alloc(64));
   BAE_HIP(e->hist.alloc(2048 + 8));
   BAE_HIP(e->flags.alloc(16));
@@ -659,9 +361,9 @@ void ba_hip_destroy(ba_hip_engine* h) {
 #define REL(b) e->b.release()
   REL(cam); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
-  REL(obs_jrow_m); REL(obs_jrow_r); REL(obs_wrow_m); REL(obs_first); REL(lm_wrow_r);
-  REL(linc_ptr); REL(linc_row); REL(linc_pose); REL(pair_ptr); REL(pair_ij); REL(pair_ent); REL(imu_frozen); REL(imu_cov_done); REL(pose_cam);
-  REL(prhs_ptr); REL(prhs_ent); REL(pose_rows); REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows);
+  REL(wave_rng); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
+  REL(imu_frozen); REL(imu_cov_done); REL(pose_cam);
+  REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
@@ -924,6 +626,10 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   e->timers.robust_weights = t_r.stop_ms();
   EventTimer t_l(e->stream);
   if ((rc = launch_landmarks(e, c_huber, e->opt.use_robust_norm_for_proj_residuals))) return rc;
+  // proj_error_ of BuildProblem (BundleAdjuster.cpp:1386): sum of w |r|^2 with the new weights, one
+  // partial per linearisation wave
+  double proj_err = 0.0;
+  if ((rc = sum_partials(e, st.O ? st.n_chunks : 0, 1, &proj_err))) return rc;
   e->timers.j_evaluation += t_l.stop_ms();
   EventTimer t_s(e->stream);
   e->factored = false;
@@ -962,12 +668,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
     }
   }
   e->timers.jtj_schur = t_s.stop_ms();
-  // proj_error_ of BuildProblem (BundleAdjuster.cpp:1386) = EvaluateResiduals at the same
-  // state with the new weights
-  if ((rc = launch_residuals(e, 1))) return rc;
-  double s = 0.0;
-  if ((rc = sum_partials(e, (st.O + 255) / 256, 1, &s))) return rc;
-  errs.proj_error = s;
+  errs.proj_error = proj_err;
   if (out) *out = errs;
   return 0;
 }
@@ -1282,6 +983,7 @@ int ba_hip_get_structure_stats(ba_hip_engine* h, ba_hip_structure_stats* out) {
   out->poses_active = st.Pact; out->landmarks_active = st.Lact; out->observations = st.O;
   out->incidences = st.n_inc; out->factor_rows = st.n_rows;
   out->pair_blocks = st.n_pairs; out->pair_entries = st.n_pair_entries;
+  out->tile_refs = st.n_tile_refs; out->pose_entries = st.n_pose_entries; out->linearize_waves = st.n_chunks;
   const uint64_t nt = st.ld / 64;
   out->tiles_lower = nt * (nt + 1) / 2;
   if (!e->nzL_valid && !(e->allreduce && e->nranks > 1)) {

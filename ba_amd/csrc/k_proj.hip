@@ -3,10 +3,10 @@
 // state update, sensor<->world landmark transforms.
 //
 // Reference code replaced (see include/ba_hip.h for the per-call mapping):
-//   parallel_algos.h:35-152        projection residual + Jacobians   -> k_landmarks
-//   BundleAdjuster.cpp:1355-1388   Huber weights                     -> k_landmarks
-//   BundleAdjuster.cpp:409-443     V, rhs_l, V^-1                    -> k_landmarks
-//   BundleAdjuster.cpp:452-460     W, W V^-1                         -> k_landmarks
+//   parallel_algos.h:35-152        projection residual + Jacobians   -> k_linearize
+//   BundleAdjuster.cpp:1355-1388   Huber weights                     -> k_linearize
+//   BundleAdjuster.cpp:409-443     V, rhs_l, V^-1                    -> k_linearize
+//   BundleAdjuster.cpp:452-460     W, W V^-1                         -> k_linearize
 //   BundleAdjuster.cpp:144-187     EvaluateResiduals (projection)    -> k_residuals
 //   BundleAdjuster.cpp:709-744     GetLandmarkDelta                  -> k_backsub
 //   BundleAdjuster.cpp:21-140      ApplyUpdate                       -> k_apply_*
@@ -235,147 +235,98 @@ int launch_residuals(Engine* e, int mode) {
 }
 
 // ---------------------------------------------------------------------------------
-// Per-landmark linearisation.  One thread walks the observations of one landmark:
-// residual, Jacobians (closed forms of dmath.h), Huber weight, then accumulates
-//   V = sum w Jl^T Jl, b_l = sum w Jl^T r, W_inc = sum w Jp^T Jl      (per incidence)
-// and emits the factor rows the gather kernels consume:
-//   J rows     sqrt(w) * Jp (masked columns zeroed, BundleAdjuster.cpp:1622-1629,1636-1642)
-//   W rows     columns of W_inc                      (jt_pr * j_l,   :452)
-//   NWV rows   columns of -W_inc V^-1                (W V^-1,        :460)
-// plus the scalars sqrt(w) r (r_pr_, :1384-1385) and b_l (rhs_l_, :429-430).
-__device__ __forceinline__ void store_row(double* __restrict__ frow, int row, const double* v,
-                                          double s) {
-  double* o = frow + (size_t)row * kRow;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) o[i] = v[i] * s;
-}
-
+// Linearisation, ONE THREAD PER OBSERVATION (parallel_algos.h:35-152, BundleAdjuster.cpp:1374-1387,
+// 409-460).  Observations are sorted by landmark; a wavefront owns a range of whole landmarks with
+// at most 64 observations (Lists::wave_rng), so that
+//   * the observation records (z, pose id, camera id, weight) are coalesced reads, the landmark row
+//     and the reference-pose transforms are wave-level broadcasts, pose transforms come from the
+//     L2-resident tables of k_pose_prep;
+//   * V = sum w Jl^T Jl, b_l = sum w Jl^T r and the reference-pose block W_r = sum w Jr^T Jl of a
+//     landmark are WAVEFRONT-LEVEL SEGMENTED REDUCTIONS over its lanes (shuffle scan, fixed tree:
+//     bitwise reproducible), the total is broadcast back, every lane inverts V (1x1, or the 3x3
+//     cofactor form) and forms its own W_m and -W_m V^-1 in registers;
+//   * the factor rows of the wave (observation-major, structure.h) are staged in LDS and leave as
+//     one contiguous span of 16-byte stores — no read-modify-write, no second pass, nothing scattered.
+// A landmark with more than 64 observations gets a wave of its own, which walks it twice (sums,
+// then rows).  The weighted error sum of BuildProblem (proj_error_, :1386) falls out as a per-wave
+// partial.
 template <int LM>
-__global__ void __launch_bounds__(64) k_landmarks(int L, int C, int O, double c_huber, int use_robust,
-                            const uint32_t* __restrict__ lm_ptr,
-                            const double* __restrict__ obs_z,
-                            const uint32_t* __restrict__ obs_pose,
-                            const uint32_t* __restrict__ obs_cam,
-                            const double* __restrict__ obs_w0,
-                            const int32_t* __restrict__ obs_jrow_m,
-                            const int32_t* __restrict__ obs_jrow_r,
-                            const int32_t* __restrict__ obs_wrow_m,
-                            const uint8_t* __restrict__ obs_first,
-                            const int32_t* __restrict__ lm_wrow_r,
-                            const uint32_t* __restrict__ linc_ptr,
-                            const uint32_t* __restrict__ linc_row,
-                            const int32_t* __restrict__ lm_opt,
-                            const uint16_t* __restrict__ pose_mask,
-                            const double* __restrict__ lm_x,
-                            const uint32_t* __restrict__ lm_ref_pose,
-                            const uint32_t* __restrict__ lm_ref_cam,
-                            const double* __restrict__ cam, const double* __restrict__ pose_cam,
-                            const double* __restrict__ tsw,
-                            const double* __restrict__ tws, const double* __restrict__ twp,
-                            double* __restrict__ obs_w, double* __restrict__ frow,
-                            double* __restrict__ scal, double* __restrict__ lm_vinv,
-                            double* __restrict__ lm_bl, double* __restrict__ obs_jl) {
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l >= L) return;
-  const uint32_t a0 = lm_ptr[l], a1 = lm_ptr[l + 1];
-  const bool lm_act = lm_opt[l] >= 0;
-  const uint32_t rp = lm_ref_pose[l], rc = lm_ref_cam[l];
+struct ObsLin {
+  double r[2], jm[12], jr[12], jl[2 * LM];
+  double w;     // robust weight
+};
+
+// Everything one observation contributes, at the current state: residual, Jacobians with the
+// columns of regularised parameters zeroed (BundleAdjuster.cpp:1622-1629), Huber weight.
+template <int LM>
+__device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, double c_huber, int use_robust,
+                                              const double* __restrict__ obs_z, const uint32_t* __restrict__ obs_pose,
+                                              const uint32_t* __restrict__ obs_cam, const double* __restrict__ obs_w0,
+                                              const uint16_t* __restrict__ pose_mask, const double* __restrict__ lm_x,
+                                              const uint32_t* __restrict__ lm_ref_pose,
+                                              const uint32_t* __restrict__ lm_ref_cam, const double* __restrict__ cam,
+                                              const double* __restrict__ pose_cam, const double* __restrict__ tsw,
+                                              const double* __restrict__ tws, const double* __restrict__ twp,
+                                              ObsLin<LM>* o) {
+  const uint32_t pm = obs_pose[a], cm = obs_cam[a];
+  const double* cp = cam + (size_t)cm * 35;
+  // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
+  const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
+  const Cam cc = {ip[0], ip[1], ip[2], ip[3]};
   double x[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) x[i] = lm_x[(size_t)l * 4 + i];
-  Rt t_ws_r, t_wp_r, t_vs_r;
+  const Rt t_sw_m = load_rt(tsw + ((size_t)pm * C + cm) * kRt);
+  // camera constants: R_vs at cp[4..12], t_sv at cp[25..27] (see build_structure)
+  M3 R_vs_m;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R_vs_m.m[i] = cp[4 + i];
+  const V3 t_sv_m = v3(cp[25], cp[26], cp[27]);
+  const double z[2] = {obs_z[2 * (size_t)a], obs_z[2 * (size_t)a + 1]};
+  ProjJac<LM> J;
   uint16_t mask_r = 0;
-  if (LM == 1) {
-    t_ws_r = load_rt(tws + ((size_t)rp * C + rc) * kRt);
-    t_wp_r = load_rt(twp + (size_t)rp * kRt);
-    t_vs_r = load_rt(cam + (size_t)rc * 35 + 4);
-    mask_r = pose_mask[rp];
-  }
-  const int wrow_r = (LM == 1) ? lm_wrow_r[l] : -1;
-  double V[LM * LM], bl[LM], Wr[6 * LM];
-#pragma unroll
-  for (int i = 0; i < LM * LM; ++i) V[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < LM; ++i) bl[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6 * LM; ++i) Wr[i] = 0.0;
-
-  for (uint32_t a = a0; a < a1; ++a) {
-    const uint32_t pm = obs_pose[a], cm = obs_cam[a];
-    const double* cp = cam + (size_t)cm * 35;
-    // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
-    const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
-    Cam cc = {ip[0], ip[1], ip[2], ip[3]};
-    const Rt t_sw_m = load_rt(tsw + ((size_t)pm * C + cm) * kRt);
-    const Rt t_wp_m = load_rt(twp + (size_t)pm * kRt);
-    const Rt t_sv_m = load_rt(cp + 16);
-    if (LM == 3) { t_ws_r = t_sw_m; t_wp_r = t_wp_m; t_vs_r = t_sv_m; }
-    const double z[2] = {obs_z[2 * (size_t)a], obs_z[2 * (size_t)a + 1]};
-    ProjJac<LM> J;
-    const bool same_pose = (LM == 1) && (pm == rp);
-    proj_jacobians<LM>(cc, z, x, t_sw_m, t_ws_r, t_wp_m, t_sv_m, t_wp_r, t_vs_r, same_pose, &J);
-    // Huber weight (BundleAdjuster.cpp:1374-1387)
-    double w = obs_w0[a];
-    const double md = (J.r[0] * J.r[0] + J.r[1] * J.r[1]) * w;
-    const double en = sqrt(md);
-    if (use_robust && en > c_huber) w *= c_huber / en;
-    obs_w[a] = w;
-    const double sw = sqrt(w);
-    scal[2 * (size_t)a] = J.r[0] * sw;
-    scal[2 * (size_t)a + 1] = J.r[1] * sw;
-#pragma unroll
-    for (int i = 0; i < 2 * LM; ++i) obs_jl[(size_t)a * 2 * LM + i] = lm_act ? J.jl[i] * sw : 0.0;
-    // column masks of regularised parameters
-    const uint16_t mask_m = pose_mask[pm];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      if (mask_m & (1u << c)) { J.jm[c] = 0.0; J.jm[6 + c] = 0.0; }
-      if (LM == 1 && (mask_r & (1u << c))) { J.jr[c] = 0.0; J.jr[6 + c] = 0.0; }
-    }
-    const int jrm = obs_jrow_m[a], jrr = obs_jrow_r[a];
-    if (jrm >= 0) { store_row(frow, jrm, J.jm, sw); store_row(frow, jrm + 1, J.jm + 6, sw); }
-    if (LM == 1 && jrr >= 0) { store_row(frow, jrr, J.jr, sw); store_row(frow, jrr + 1, J.jr + 6, sw); }
-    if (lm_act) {
-#pragma unroll
-      for (int p = 0; p < LM; ++p) {
-#pragma unroll
-        for (int q = 0; q < LM; ++q)
-          V[p * LM + q] += (J.jl[p] * J.jl[q] + J.jl[LM + p] * J.jl[LM + q]) * w;
-        bl[p] += (J.jl[p] * J.r[0] + J.jl[LM + p] * J.r[1]) * w;
-      }
-      const int wrm = obs_wrow_m[a];
-      if (wrm >= 0) {
-        const bool first = obs_first[a] != 0;
-#pragma unroll
-        for (int k = 0; k < LM; ++k) {
-          double* o = frow + (size_t)(wrm + k) * kRow;
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            const double v = (J.jm[r] * J.jl[k] + J.jm[6 + r] * J.jl[LM + k]) * w;
-            o[r] = first ? v : o[r] + v;
-          }
-        }
-      }
-      if (LM == 1 && wrow_r >= 0) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) Wr[r] += (J.jr[r] * J.jl[0] + J.jr[6 + r] * J.jl[1]) * w;
-      }
-    }
-  }
-  if (!lm_act) return;
-  // V guard (BundleAdjuster.cpp:431-440) and inverse
-  double Vi[LM * LM];
   if constexpr (LM == 1) {
-    if (fabs(V[0]) < 1e-6) V[0] += 1e-6;
-    Vi[0] = 1.0 / V[0];
+    const uint32_t rp = lm_ref_pose[l], rc = lm_ref_cam[l];
+    const Rt t_ws_r = load_rt(tws + ((size_t)rp * C + rc) * kRt);
+    const Rt t_wp_r = load_rt(twp + (size_t)rp * kRt);
+    mask_r = pose_mask[rp];
+    proj_linearize<1>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_ws_r, t_wp_r, pm == rp, &J);
   } else {
-    double nrm = 0.0;
+    proj_linearize<LM>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_sw_m, t_sw_m, false, &J);
+  }
+  // Huber weight (BundleAdjuster.cpp:1374-1387)
+  double w = obs_w0[a];
+  const double en = sqrt((J.r[0] * J.r[0] + J.r[1] * J.r[1]) * w);
+  if (use_robust && en > c_huber) w *= c_huber / en;
+  o->w = w;
+  o->r[0] = J.r[0]; o->r[1] = J.r[1];
+  const uint16_t mask_m = pose_mask[pm];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) nrm += V[i] * V[i];
-    if (sqrt(nrm) < 1e-6) { V[0] += 1e-6; V[4] += 1e-6; V[8] += 1e-6; }
+  for (int c = 0; c < 6; ++c) {
+    const bool zm = (mask_m >> c) & 1u, zr = (mask_r >> c) & 1u;
+    o->jm[c] = zm ? 0.0 : J.jm[c];
+    o->jm[6 + c] = zm ? 0.0 : J.jm[6 + c];
+    o->jr[c] = (LM != 1 || zr) ? 0.0 : J.jr[c];
+    o->jr[6 + c] = (LM != 1 || zr) ? 0.0 : J.jr[6 + c];
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * LM; ++i) o->jl[i] = J.jl[i];
+}
+
+// V guard (BundleAdjuster.cpp:431-440) and inverse; Vs = the LM (LM + 1) / 2 unique entries
+// (00 | 00 01 02 11 12 22), Vi row-major LM x LM
+template <int LM>
+__device__ __forceinline__ void invert_v(const double* Vs, double* Vi) {
+  if constexpr (LM == 1) {
+    double v = Vs[0];
+    if (fabs(v) < 1e-6) v += 1e-6;
+    Vi[0] = 1.0 / v;
+  } else {
+    double a = Vs[0], b = Vs[1], c = Vs[2], ee = Vs[3], f = Vs[4], i = Vs[5];
+    const double nrm = a * a + ee * ee + i * i + 2.0 * (b * b + c * c + f * f);
+    if (sqrt(nrm) < 1e-6) { a += 1e-6; ee += 1e-6; i += 1e-6; }
+    const double d = b, g = c, h = f;  // symmetric
     // closed-form 3x3 inverse (cofactors)
-    const double a = V[0], b = V[1], c = V[2], d = V[3], ee = V[4], f = V[5], g = V[6],
-                 h = V[7], i = V[8];
     const double A00 = ee * i - f * h, A01 = c * h - b * i, A02 = b * f - c * ee;
     const double A10 = f * g - d * i, A11 = a * i - c * g, A12 = c * d - a * f;
     const double A20 = d * h - ee * g, A21 = b * g - a * h, A22 = a * ee - b * d;
@@ -384,54 +335,230 @@ __global__ void __launch_bounds__(64) k_landmarks(int L, int C, int O, double c_
     Vi[3] = A10 * id; Vi[4] = A11 * id; Vi[5] = A12 * id;
     Vi[6] = A20 * id; Vi[7] = A21 * id; Vi[8] = A22 * id;
   }
+}
+
+// lane-local contributions to the landmark sums: [V unique | b_l | W_r (LM == 1)]
+template <int LM> struct LmSums { static constexpr int NV = LM * (LM + 1) / 2, N = NV + LM + (LM == 1 ? 6 : 0); };
+template <int LM>
+__device__ __forceinline__ void obs_sums(const ObsLin<LM>& q, double* v) {
+  int k = 0;
+#pragma unroll
+  for (int p = 0; p < LM; ++p)
+#pragma unroll
+    for (int c = p; c < LM; ++c) v[k++] = (q.jl[p] * q.jl[c] + q.jl[LM + p] * q.jl[LM + c]) * q.w;
+#pragma unroll
+  for (int p = 0; p < LM; ++p) v[k++] = (q.jl[p] * q.r[0] + q.jl[LM + p] * q.r[1]) * q.w;
+  if constexpr (LM == 1) {
+#pragma unroll
+    for (int x = 0; x < 6; ++x) v[k++] = (q.jr[x] * q.jl[0] + q.jr[6 + x] * q.jl[1]) * q.w;
+  }
+}
+
+// the R rows of one observation (structure.h): J_m (2), [J_r (2)], W_m (LM), -W_m V^-1 (LM)
+template <int LM>
+__device__ __forceinline__ void obs_rows(const ObsLin<LM>& q, const double* Vi, double* rows) {
+  const double sw = sqrt(q.w);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) rows[i] = q.jm[i] * sw;
+  constexpr int WO = (LM == 1 ? 4 : 2) * 6;
+  if constexpr (LM == 1) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) rows[12 + i] = q.jr[i] * sw;
+  }
+  double W[6 * LM];
+#pragma unroll
+  for (int k = 0; k < LM; ++k)
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+      W[k * 6 + x] = (q.jm[x] * q.jl[k] + q.jm[6 + x] * q.jl[LM + k]) * q.w;
+      rows[WO + k * 6 + x] = W[k * 6 + x];
+    }
+#pragma unroll
+  for (int c = 0; c < LM; ++c)
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < LM; ++k) s += W[k * 6 + x] * Vi[k * LM + c];
+      rows[WO + (LM + c) * 6 + x] = -s;
+    }
+}
+
+// landmark outputs: V^-1, b_l (also a scalar of the rhs lists), and for LM == 1 the reference
+// pose's rows W_r, -W_r V^-1
+template <int LM>
+__device__ __forceinline__ void store_landmark(uint32_t l, uint32_t O, uint32_t lrow_base, const double* tot,
+                                               const double* Vi, double* __restrict__ lm_vinv,
+                                               double* __restrict__ lm_bl, double* __restrict__ scal,
+                                               double* __restrict__ frow) {
+  constexpr int NV = LmSums<LM>::NV;
 #pragma unroll
   for (int i = 0; i < LM * LM; ++i) lm_vinv[(size_t)l * LM * LM + i] = Vi[i];
 #pragma unroll
   for (int i = 0; i < LM; ++i) {
-    lm_bl[(size_t)l * LM + i] = bl[i];
-    scal[2 * (size_t)O + (size_t)l * LM + i] = bl[i];
+    lm_bl[(size_t)l * LM + i] = tot[NV + i];
+    scal[2 * (size_t)O + (size_t)l * LM + i] = tot[NV + i];
   }
-  if (LM == 1 && wrow_r >= 0) {
-    double* o = frow + (size_t)wrow_r * kRow;
+  if constexpr (LM == 1) {
+    double* o = frow + ((size_t)lrow_base + 2 * (size_t)l) * kRow;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) o[r] = Wr[r];
-  }
-  // NWV rows = -W V^-1 for every incidence of the landmark
-  for (uint32_t q = linc_ptr[l]; q < linc_ptr[l + 1]; ++q) {
-    const uint32_t row = linc_row[q];
-    double Wq[6 * LM];
-#pragma unroll
-    for (int k = 0; k < LM; ++k)
-#pragma unroll
-      for (int r = 0; r < 6; ++r) Wq[k * 6 + r] = frow[(size_t)(row + k) * kRow + r];
-#pragma unroll
-    for (int c = 0; c < LM; ++c) {
-      double* o = frow + (size_t)(row + LM + c) * kRow;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < LM; ++k) s += Wq[k * 6 + r] * Vi[k * LM + c];
-        o[r] = -s;
-      }
-    }
+    for (int x = 0; x < 6; ++x) { o[x] = tot[NV + 1 + x]; o[6 + x] = -tot[NV + 1 + x] * Vi[0]; }
   }
 }
 
+template <int LM, int WAVES, bool BIG>
+__global__ void __launch_bounds__(64 * WAVES)
+k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_huber, int use_robust,
+            const uint2* __restrict__ wave_rng, const uint32_t* __restrict__ lm_ptr,
+            const double* __restrict__ obs_z, const uint32_t* __restrict__ obs_pose,
+            const uint32_t* __restrict__ obs_cam, const uint32_t* __restrict__ obs_lm,
+            const double* __restrict__ obs_w0, const int32_t* __restrict__ lm_opt,
+            const uint16_t* __restrict__ pose_mask, const double* __restrict__ lm_x,
+            const uint32_t* __restrict__ lm_ref_pose, const uint32_t* __restrict__ lm_ref_cam,
+            const double* __restrict__ cam, const double* __restrict__ pose_cam,
+            const double* __restrict__ tsw, const double* __restrict__ tws, const double* __restrict__ twp,
+            double* __restrict__ obs_w, double* __restrict__ frow, double* __restrict__ scal,
+            double* __restrict__ lm_vinv, double* __restrict__ lm_bl, double* __restrict__ obs_jl,
+            double* __restrict__ partials) {
+  constexpr int R = LM == 1 ? 6 : 8, RD = R * 6;   // rows / doubles per observation
+  constexpr int STRIDE = RD + 2;                    // LDS stride per lane (even: 16-byte reads; odd multiple of 2 banks)
+  constexpr int NS = LmSums<LM>::N, NV = LmSums<LM>::NV;
+  __shared__ __attribute__((aligned(16))) double stage[BIG ? 1 : WAVES][BIG ? 2 : 64 * STRIDE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t chunk = blockIdx.x * WAVES + wave;
+  if (chunk >= n_chunks) return;  // waves are independent: no block-level barrier below
+  const uint2 rng = wave_rng[chunk];
+  const uint32_t a0 = rng.x, a1 = rng.y, nobs = a1 - a0;
+#define BAE_LIN_ARGS C, c_huber, use_robust, obs_z, obs_pose, obs_cam, obs_w0, pose_mask, lm_x, lm_ref_pose, \
+                     lm_ref_cam, cam, pose_cam, tsw, tws, twp
+  double err = 0.0;
+  if constexpr (!BIG) {
+    const bool valid = (uint32_t)lane < nobs;
+    const uint32_t a = valid ? a0 + lane : a1 - 1;
+    const uint32_t l = obs_lm[a];
+    const bool lm_act = lm_opt[l] >= 0;
+    const int s0 = (int)(lm_ptr[l] - a0), s1 = (int)(lm_ptr[l + 1] - 1 - a0);  // lanes of this landmark
+    ObsLin<LM> q;
+    linearize_obs<LM>(a, l, BAE_LIN_ARGS, &q);
+    double v[NS];
+    obs_sums<LM>(q, v);
+    if (!valid || !lm_act) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) v[i] = 0.0;
+    }
+    // segmented inclusive scan over the lanes of a landmark, then the total from its last lane
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const bool take = lane - off >= s0;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const double up = __shfl_up(v[i], off, 64);
+        if (take) v[i] += up;
+      }
+    }
+    double tot[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) tot[i] = __shfl(v[i], s1, 64);
+    double Vi[LM * LM];
+    invert_v<LM>(tot, Vi);
+    double* st = stage[wave] + lane * STRIDE;
+    {
+      double rows[RD];
+      obs_rows<LM>(q, Vi, rows);
+#pragma unroll
+      for (int i = 0; i < RD; i += 2) *reinterpret_cast<double2*>(st + i) = make_double2(rows[i], rows[i + 1]);
+    }
+    if (valid) {
+      const double sw = sqrt(q.w);
+      obs_w[a] = q.w;
+      *reinterpret_cast<double2*>(scal + 2 * (size_t)a) = make_double2(q.r[0] * sw, q.r[1] * sw);
+#pragma unroll
+      for (int i = 0; i < 2 * LM; ++i) obs_jl[(size_t)a * 2 * LM + i] = lm_act ? q.jl[i] * sw : 0.0;
+      err = (q.r[0] * q.r[0] + q.r[1] * q.r[1]) * q.w;
+      if (lane == s1 && lm_act) store_landmark<LM>(l, O, lrow_base, tot, Vi, lm_vinv, lm_bl, scal, frow);
+    }
+    // LDS image -> one contiguous span of the factor rows (16 bytes per lane per store)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t total = nobs * RD;
+    double* dst = frow + (size_t)a0 * RD;
+    const double* img = stage[wave];
+    for (uint32_t g = 2 * lane; g < total; g += 128) {
+      const uint32_t ln = g / RD, k = g - ln * RD;
+      *reinterpret_cast<double2*>(dst + g) = *reinterpret_cast<const double2*>(img + ln * STRIDE + k);
+    }
+  } else {
+    // one landmark with more than 64 observations: pass 1 sums, pass 2 rows (direct stores)
+    (void)stage;
+    const uint32_t l = obs_lm[a0];
+    const bool lm_act = lm_opt[l] >= 0;
+    double tot[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) tot[i] = 0.0;
+    for (uint32_t a = a0 + lane; a < a1; a += 64) {
+      ObsLin<LM> q;
+      linearize_obs<LM>(a, l, BAE_LIN_ARGS, &q);
+      double v[NS];
+      obs_sums<LM>(q, v);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) tot[i] += lm_act ? v[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) tot[i] += __shfl_xor(tot[i], off, 64);
+    }
+    double Vi[LM * LM];
+    invert_v<LM>(tot, Vi);
+    for (uint32_t a = a0 + lane; a < a1; a += 64) {
+      ObsLin<LM> q;
+      linearize_obs<LM>(a, l, BAE_LIN_ARGS, &q);
+      double rows[RD];
+      obs_rows<LM>(q, Vi, rows);
+      double* dst = frow + (size_t)a * RD;
+#pragma unroll
+      for (int i = 0; i < RD; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(rows[i], rows[i + 1]);
+      const double sw = sqrt(q.w);
+      obs_w[a] = q.w;
+      *reinterpret_cast<double2*>(scal + 2 * (size_t)a) = make_double2(q.r[0] * sw, q.r[1] * sw);
+#pragma unroll
+      for (int i = 0; i < 2 * LM; ++i) obs_jl[(size_t)a * 2 * LM + i] = lm_act ? q.jl[i] * sw : 0.0;
+      err += (q.r[0] * q.r[0] + q.r[1] * q.r[1]) * q.w;
+    }
+    if (lane == 0 && lm_act) store_landmark<LM>(l, O, lrow_base, tot, Vi, lm_vinv, lm_bl, scal, frow);
+  }
+#undef BAE_LIN_ARGS
+  // weighted error of the wave (fixed tree) -> one partial per wave
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) err += __shfl_xor(err, off, 64);
+  if (lane == 0) partials[chunk] = err;
+  (void)NV;
+}
+
 int launch_landmarks(Engine* e, double c_huber, int use_robust) {
-  const int L = e->st.L;
-  if (L == 0 || e->st.O == 0) return 0;
-  const dim3 grid((L + 63) / 64), block(64);
-#define BAE_ARGS                                                                              \
-  L, (int)e->st.C, (int)e->st.O, c_huber, use_robust, e->lm_ptr.p, e->obs_z.p, e->obs_pose.p, \
-      e->obs_cam.p, e->obs_w0.p, e->obs_jrow_m.p, e->obs_jrow_r.p, e->obs_wrow_m.p,           \
-      e->obs_first.p, e->lm_wrow_r.p, e->linc_ptr.p, e->linc_row.p, e->lm_opt.p,              \
-      e->pose_mask.p, e->lm_x[e->cur].p, e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p,         \
-      e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->twp.p, e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p,   \
-      e->obs_jl.p
+  const Structure& st = e->st;
+  if (st.n_chunks == 0 || st.O == 0) return 0;
+  constexpr int WAVES = 2;
+  // waves [0, n_small): ranges of whole landmarks with at most 64 observations; [n_small, n_chunks):
+  // one landmark with more than 64 each (two-pass variant of the kernel)
+  const uint32_t n_small = st.n_chunks - st.n_big_chunks;
+#define BAE_ARGS(first, count)                                                                          \
+  count, (int)st.C, st.O, st.lrow_base, c_huber, use_robust, e->wave_rng.p + (first), e->lm_ptr.p, e->obs_z.p, \
+      e->obs_pose.p, e->obs_cam.p, e->obs_lm.p, e->obs_w0.p, e->lm_opt.p, e->pose_mask.p, e->lm_x[e->cur].p, \
+      e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->twp.p,     \
+      e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p, e->obs_jl.p, e->partials.p + (first)
   e->prof_begin(e->ev_landmarks);
-  if (e->lm_dim == 1) hipLaunchKernelGGL(k_landmarks<1>, grid, block, 0, e->stream, BAE_ARGS);
-  else hipLaunchKernelGGL(k_landmarks<3>, grid, block, 0, e->stream, BAE_ARGS);
+  if (n_small) {
+    const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
+    if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+    else hipLaunchKernelGGL((k_linearize<3, WAVES, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+  }
+  if (st.n_big_chunks) {
+    const dim3 grid((st.n_big_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
+    if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, true>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+    else hipLaunchKernelGGL((k_linearize<3, WAVES, true>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+  }
   e->prof_end(e->ev_landmarks);
 #undef BAE_ARGS
   BAE_HIP(hipGetLastError());
@@ -439,15 +566,18 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
 }
 
 // ---------------------------------------------------------------------------------
-// delta_l = V^-1 (b_l - sum_inc W_inc^T delta_p[pose(inc)])   (BundleAdjuster.cpp:709-744)
+// delta_l = V^-1 (b_l - sum_inc W_inc^T delta_p[pose(inc)])   (BundleAdjuster.cpp:709-744).
+// One thread per landmark walks its observations: the incidence of an observation is its W rows
+// (structure.h) when the observation is listed and its measuring pose active; plus the reference
+// pose's rows (LM == 1).
 template <int LM>
-__global__ void k_backsub(int L, int D, const int32_t* __restrict__ lm_opt,
-                          const uint32_t* __restrict__ linc_ptr,
-                          const uint32_t* __restrict__ linc_row,
-                          const uint32_t* __restrict__ linc_pose,
+__global__ void k_backsub(int L, int D, uint32_t lrow_base, const int32_t* __restrict__ lm_opt,
+                          const int32_t* __restrict__ pose_opt, const uint32_t* __restrict__ lm_ptr,
+                          const uint32_t* __restrict__ obs_pose, const uint32_t* __restrict__ lm_ref_pose,
                           const double* __restrict__ frow, const double* __restrict__ lm_vinv,
                           const double* __restrict__ lm_bl, const double* __restrict__ delta_p,
                           double* __restrict__ delta_l) {
+  constexpr int R = LM == 1 ? 6 : 8, WO = LM == 1 ? 4 : 2;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L) return;
   const int lo = lm_opt[l];
@@ -455,17 +585,31 @@ __global__ void k_backsub(int L, int D, const int32_t* __restrict__ lm_opt,
   double rhs[LM];
 #pragma unroll
   for (int i = 0; i < LM; ++i) rhs[i] = lm_bl[(size_t)l * LM + i];
-  for (uint32_t q = linc_ptr[l]; q < linc_ptr[l + 1]; ++q) {
-    const double* dp = delta_p + (size_t)linc_pose[q] * D;
-    const uint32_t row = linc_row[q];
+  const uint32_t rp = lm_ref_pose[l];
+  bool any_listed = false;
+  for (uint32_t a = lm_ptr[l]; a < lm_ptr[l + 1]; ++a) {
+    const uint32_t pm = obs_pose[a];
+    if (LM == 1 && pm == rp) continue;  // not listed (BundleAdjuster.h:489-497)
+    any_listed = true;
+    const int po = pose_opt[pm];
+    if (po < 0) continue;
+    const double* dp = delta_p + (size_t)po * D;
 #pragma unroll
     for (int k = 0; k < LM; ++k) {
-      const double* wr = frow + (size_t)(row + k) * kRow;
+      const double* wr = frow + ((size_t)a * R + WO + k) * kRow;
       double s = 0.0;
 #pragma unroll
       for (int r = 0; r < 6; ++r) s += wr[r] * dp[r];
       rhs[k] -= s;
     }
+  }
+  if (LM == 1 && any_listed && pose_opt[rp] >= 0) {
+    const double* dp = delta_p + (size_t)pose_opt[rp] * D;
+    const double* wr = frow + ((size_t)lrow_base + 2 * (size_t)l) * kRow;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) s += wr[r] * dp[r];
+    rhs[0] -= s;
   }
 #pragma unroll
   for (int a = 0; a < LM; ++a) {
@@ -480,9 +624,9 @@ int launch_backsub(Engine* e) {
   const int L = e->st.L;
   if (L == 0 || e->lm_dim == 0 || e->st.Lact == 0) return 0;
   const dim3 grid((L + 255) / 256), block(256);
-#define BAE_ARGS                                                                          \
-  L, e->pose_dim, e->lm_opt.p, e->linc_ptr.p, e->linc_row.p, e->linc_pose.p, e->frow.p,   \
-      e->lm_vinv.p, e->lm_bl.p, e->gn_p.p, e->gn_l.p
+#define BAE_ARGS                                                                                      \
+  L, e->pose_dim, e->st.lrow_base, e->lm_opt.p, e->pose_opt.p, e->lm_ptr.p, e->obs_pose.p, e->lm_ref_pose.p, \
+      e->frow.p, e->lm_vinv.p, e->lm_bl.p, e->gn_p.p, e->gn_l.p
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_backsub<1>, grid, block, 0, e->stream, BAE_ARGS);
   else hipLaunchKernelGGL(k_backsub<3>, grid, block, 0, e->stream, BAE_ARGS);
 #undef BAE_ARGS

@@ -1,11 +1,11 @@
 // gfx950 kernels that assemble the reduced camera system and the scalar reductions:
-//   * k_gather_S / k_gather_rhs — deterministic gathers that replace the reference's
+//   * k_assemble_tiles / k_pose_blocks — deterministic gathers that replace the reference's
 //     block-sparse products jt_pr*j_pr, jt_pr*j_l*vi*jt_l*j_pr and the dense write of
 //     S = U - W V^-1 W^T (BundleAdjuster.cpp:337-354, 448-485; SparseBlockMatrixOps.h:
 //     182-254, 318-364).  Every 6x6 block of S is the sum of rank-1 products of "factor
-//     rows" emitted by k_landmarks; the list of products per pose pair is static across
-//     Gauss-Newton iterations and is built once per Solve() on the host.  No atomics: S
-//     and rhs are bitwise reproducible.
+//     rows" emitted by k_linearize; the list of products per block is static across
+//     Gauss-Newton iterations and Solve() calls and is built once per graph (structure.h).
+//     No atomics: S and rhs are bitwise reproducible.
 //   * exact k-th element selection for the Huber sigma (std::nth_element,
 //     BundleAdjuster.cpp:1356-1358)
 //   * step composition, norms and the dogleg scalars (BundleAdjuster.cpp:858-1017)
@@ -15,128 +15,140 @@
 namespace bae {
 
 // ---------------------------------------------------------------------------------
-// Off-diagonal blocks of S from the static gather lists.  Lane (r, c0): r = row of the 6x6 block,
-// c0 = 0 or 3; the factor rows are 48-byte gathers served by L2 / Infinity Cache (rows are laid
-// out pose-major, so one pair touches two contiguous row ranges).
-// Output: lower storage of the symmetric S, row-major with leading dimension ld: block (i,j),
-// i<j, is written transposed at rows j*D.., cols i*D..  Masked parameters: S(idx,idx) = 1e6
-// (BundleAdjuster.cpp:587-598) is written by k_gather_S_diag — their rows and columns are
-// already zero because k_landmarks zeroed the Jacobian columns.
-// Five pose pairs per wavefront, one per 12-lane slot: a lane owns 3 elements (r, c0..c0+2) of
-// its pair's 6x6 block and walks that pair's entry list alone — no partial blocks, no LDS, no
-// barrier.  Short lists (configs[3]: 2.3 entries per pair on average) no longer leave four of the
-// five slots idle, and for long lists the five pairs of a wave (neighbours in the sorted order:
-// similar co-visibility, similar length) keep all slots busy just as the five-way split of one
-// list did.  The terms of a block are added in entry order.
+// Assembly of the reduced system from the factor rows of k_linearize (structure.h).
+//
+// k_assemble_tiles — one workgroup per 64x64 tile of the lower storage.  The tile is formed in LDS:
+// zeroed, then every pose-pair block that overlaps it is summed by ONE thread from its list of
+// rank-1 terms (rowA (x) rowB, two 48-byte row gathers per term; a block has 2.3 terms on average
+// at configs[3]) and dropped into the tile, then the tile leaves as 64 full 512-byte rows.  Every
+// byte of the lower triangle is written exactly once per iteration, coalesced: the separate
+// zero-fill pass and the 8-byte column scatters of the first design are gone.  Blocks that straddle
+// a tile boundary are listed by both tiles and clipped.  No atomics: bitwise reproducible.
 __global__ void __launch_bounds__(256)
-k_gather_S(uint32_t npairs, const uint32_t* __restrict__ pair_ptr,
-            const uint2* __restrict__ pair_ij, const uint2* __restrict__ pair_ent,
-            const double* __restrict__ frow, int D, uint32_t ld, double* __restrict__ A) {
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane >= 60) return;
-  const int slot = lane / 12, t = lane - 12 * slot;
-  const uint32_t pair = (blockIdx.x * 4 + w) * 5 + slot;
-  if (pair >= npairs) return;
-  const int r = t >> 1, c0 = (t & 1) * 3;
-  const uint32_t e0 = pair_ptr[pair], e1 = pair_ptr[pair + 1];
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-  uint32_t e = e0;
-  for (; e + 1 < e1; e += 2) {
-    const uint2 p0 = pair_ent[e], p1 = pair_ent[e + 1];
-    const double a0 = frow[(size_t)p0.x * kRow + r], a1 = frow[(size_t)p1.x * kRow + r];
-    const double* rb0 = frow + (size_t)p0.y * kRow + c0;
-    const double* rb1 = frow + (size_t)p1.y * kRow + c0;
-    const double b00 = rb0[0], b01 = rb0[1], b02 = rb0[2], b10 = rb1[0], b11 = rb1[1], b12 = rb1[2];
-    acc0 += a0 * b00; acc1 += a0 * b01; acc2 += a0 * b02;
-    acc0 += a1 * b10; acc1 += a1 * b11; acc2 += a1 * b12;
-  }
-  if (e < e1) {
-    const uint2 p0 = pair_ent[e];
-    const double a0 = frow[(size_t)p0.x * kRow + r];
-    const double* rb0 = frow + (size_t)p0.y * kRow + c0;
-    acc0 += a0 * rb0[0]; acc1 += a0 * rb0[1]; acc2 += a0 * rb0[2];
-  }
-  const uint2 ij = pair_ij[pair];
-  const uint32_t i = ij.x, j = ij.y;
-  if (i == j) {
-    // cross terms of observations whose two sides sit on the same pose; the block itself was
-    // written by k_gather_S_diag (stream order), single writer
-    double* o = A + ((size_t)i * D + r) * ld + (size_t)i * D + c0;
-    o[0] += acc0; o[1] += acc1; o[2] += acc2;
-  } else {
-    double* o = A + ((size_t)j * D + c0) * ld + (size_t)i * D + r;
-    o[0] = acc0; o[ld] = acc1; o[2 * (size_t)ld] = acc2;
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// Diagonal blocks (i,i): one workgroup per active pose streams the pose's own factor
-// rows — contiguous in the pose-major numbering — instead of walking an entry list:
-//   sum over its J rows of row row^T                       (jt_pr j_pr, diagonal part)
-//   sum over its incidences of (-W V^-1)_k W_k^T           (the Schur term of the pose with itself)
-// A pose of the 1M-residual benchmark owns ~2000 + 2*1000 rows; as list entries of ONE
-// wavefront they were the critical path of the whole gather.  Fixed reduction order
-// (strided rows per thread, xor-butterfly per wave, waves in order): bitwise reproducible.
-// Also writes the fixed entries of the block: 1e6 on masked parameters (shard 0 only).
-template <int LM>
-__global__ void __launch_bounds__(256)
-k_gather_S_diag(const uint32_t* __restrict__ pose_rows, uint32_t npose, uint32_t jbase,
-                const double* __restrict__ frow, int D, uint32_t ld,
-                const uint16_t* __restrict__ mask_opt, int write_fixed, double* __restrict__ A) {
-  __shared__ double red[4][36];
-  const uint32_t i = blockIdx.x;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  double acc[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  {
-    const uint32_t r0 = jbase + 2 * pose_rows[i], r1 = jbase + 2 * pose_rows[i + 1];
-    for (uint32_t row = r0 + tid; row < r1; row += 256) {
-      const double* v = frow + (size_t)row * kRow;
-      const double v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], v4 = v[4], v5 = v[5];
-      const double vv[6] = {v0, v1, v2, v3, v4, v5};
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = 0; b < 6; ++b) acc[a * 6 + b] += vv[a] * vv[b];
-    }
-  }
-  if (LM > 0) {
-    const uint32_t* pinc = pose_rows + (npose + 1);
-    const uint32_t q0 = pinc[i], q1 = pinc[i + 1];
-    const int lm = LM > 0 ? LM : 1;
+k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_ptr, const uint2* __restrict__ tile_ref,
+                 const uint2* __restrict__ pair_ent, const double* __restrict__ frow, uint32_t ld,
+                 double* __restrict__ A) {
+  constexpr int TS = 66;  // LDS row stride (doubles): even, so that rows can be read 16 bytes at a time
+  __shared__ __attribute__((aligned(16))) double T[64 * TS];
+  const uint32_t t = blockIdx.x;
+  uint32_t tr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((uint64_t)(tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  while ((uint64_t)tr * (tr + 1) / 2 > t) --tr;
+  const uint32_t tc = t - (uint32_t)((uint64_t)tr * (tr + 1) / 2);
+  if (tr >= nt) return;
+  const int tid = threadIdx.x;
+  const uint32_t q0 = tile_ptr[t], q1 = tile_ptr[t + 1];
+  if (q1 > q0) {
+    for (int i = tid; i < 64 * TS / 2; i += 256) reinterpret_cast<double2*>(T)[i] = make_double2(0.0, 0.0);
+    __syncthreads();
     for (uint32_t q = q0 + tid; q < q1; q += 256) {
-      const double* base = frow + (size_t)q * 2 * lm * kRow;
+      const uint2 ref = tile_ref[q];
+      const uint32_t cnt = ref.y >> 14;
+      const int ro = (int)((ref.y >> 7) & 127u) - kRefBias, co = (int)(ref.y & 127u) - kRefBias;
+      double acc[36];
 #pragma unroll
-      for (int k = 0; k < lm; ++k) {
-        const double* a = base + (size_t)(lm + k) * kRow;  // (-W V^-1) row k
-        const double* b = base + (size_t)k * kRow;         // W row k
-        const double av[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
-        const double bv[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};
+      for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+      for (uint32_t e = ref.x; e < ref.x + cnt; ++e) {
+        const uint2 en = pair_ent[e];
+        const double2* pa = reinterpret_cast<const double2*>(frow + (size_t)en.x * kRow);
+        const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)en.y * kRow);
+        const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        const double a[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+        const double b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
 #pragma unroll
         for (int x = 0; x < 6; ++x)
 #pragma unroll
-          for (int y = 0; y < 6; ++y) acc[x * 6 + y] += av[x] * bv[y];
+          for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a[x] * b[y];
       }
+      // block (i, j), i < j, lives transposed in the lower storage: row = j D + y, column = i D + x
+#pragma unroll
+      for (int y = 0; y < 6; ++y) {
+        const int rr = ro + y;
+        if (rr < 0 || rr >= 64) continue;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          const int cc = co + x;
+          if (cc >= 0 && cc < 64) T[rr * TS + cc] = acc[x * 6 + y];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // 64 rows of 64 doubles: a half-wave writes one 512-byte row per store
+  double* base = A + ((size_t)tr * 64) * ld + (size_t)tc * 64;
+  const int c2 = tid & 31;
+#pragma unroll
+  for (int r = tid >> 5; r < 64; r += 8) {
+    const double2 v = q1 > q0 ? *reinterpret_cast<const double2*>(T + r * TS + 2 * c2) : make_double2(0.0, 0.0);
+    *reinterpret_cast<double2*>(base + (size_t)r * ld + 2 * c2) = v;
+  }
+}
+
+// k_pose_blocks — one workgroup per active pose: its diagonal block and its right-hand sides from
+// the pose's term list (structure.h: pose_ent).  Terms before `mid` are the J rows of the pose,
+//   U_ii += row row^T,   rhs_p_i += row * sqrt(w) r                      (jt_pr j_pr, jt_pr r_pr: :337-353)
+// terms after it the Schur part,
+//   S_ii += (-W V^-1)_k W_k^T,   rhs_sc_i += (-W V^-1)_k b_l             (:468-484)
+// Fixed reduction order (strided terms per thread, xor-butterfly per wave, waves in order): bitwise
+// reproducible.  Also writes the fixed entries of the block: 1e6 on masked parameters (shard 0 only,
+// so that the cross-shard sum leaves them exact).  Runs after k_assemble_tiles (stream order), which
+// zeroed the block's place.
+__global__ void __launch_bounds__(256)
+k_pose_blocks(const uint32_t* __restrict__ pose_ptr, const uint32_t* __restrict__ pose_mid,
+              const uint32_t* __restrict__ pose_ent, const double* __restrict__ frow,
+              const double* __restrict__ scal, int D, uint32_t ld, const uint16_t* __restrict__ mask_opt,
+              int write_fixed, double* __restrict__ A, double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
+  __shared__ double red[4][48];
+  const uint32_t i = blockIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const uint32_t e0 = pose_ptr[i], em = pose_mid[i], e1 = pose_ptr[i + 1];
+  double acc[48];  // 36 block entries | 6 rhs_p | 6 Schur part of the rhs
+#pragma unroll
+  for (int k = 0; k < 48; ++k) acc[k] = 0.0;
+  for (uint32_t e = e0 + tid; e < e1; e += 256) {
+    const uint32_t ra = pose_ent[3 * (size_t)e], rb = pose_ent[3 * (size_t)e + 1], si = pose_ent[3 * (size_t)e + 2];
+    const double2* pa = reinterpret_cast<const double2*>(frow + (size_t)ra * kRow);
+    const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)rb * kRow);
+    const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+    const double a[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+    const double b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+    const double sc = scal[si];
+    const double s1 = e < em ? sc : 0.0, s2 = e < em ? 0.0 : sc;
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+#pragma unroll
+      for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a[x] * b[y];
+      acc[36 + x] += a[x] * s1;
+      acc[42 + x] += a[x] * s2;
     }
   }
 #pragma unroll
-  for (int k = 0; k < 36; ++k) {
+  for (int k = 0; k < 48; ++k) {
     double v = acc[k];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) red[w][k] = v;
   }
   __syncthreads();
-  if (tid < 36) {
-    const int rr = tid / 6, cc = tid - 6 * rr;
+  if (tid < 48) {
     double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (tid < 36) {
+      const int rr = tid / 6, cc = tid - 6 * rr;
+      const uint16_t m = mask_opt[i];
+      if (rr == cc && (m & (1u << rr))) v = write_fixed ? 1e6 : 0.0;
+      A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] = v;
+    } else if (tid < 42) {
+      rhs_p[(size_t)i * D + (tid - 36)] = v;
+      red[0][tid] = v;  // (own slot: read back below by the thread that owns the Schur part)
+    }
+  }
+  __syncthreads();
+  if (tid >= 42 && tid < 48) {
+    const double sb = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    rhs_sc[(size_t)i * D + (tid - 42)] = red[0][tid - 6] + sb;
+  } else if (tid >= 48 && tid - 48 < D - 6) {
     const uint16_t m = mask_opt[i];
-    if (rr == cc && (m & (1u << rr))) v = write_fixed ? 1e6 : 0.0;
-    A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] = v;
-  } else if ((int)tid - 36 < D - 6) {
-    const uint16_t m = mask_opt[i];
-    const int k = 6 + (tid - 36);
+    const int k = 6 + (tid - 48);
     if ((m & (1u << k)) && write_fixed) A[((size_t)i * D + k) * ld + (size_t)i * D + k] = 1e6;
   }
 }
@@ -145,54 +157,6 @@ k_gather_S_diag(const uint32_t* __restrict__ pose_rows, uint32_t npose, uint32_t
 __global__ void k_pad_diag(uint32_t n, uint32_t n_pad, uint32_t ld, double* __restrict__ A) {
   const uint32_t k = n + blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n_pad) A[(size_t)k * ld + k] = 1.0;
-}
-
-// One workgroup per active pose: rhs_p[i] = sum F[row] * scal[idx] over the pose's
-// observation rows (jt_pr * r_pr, BundleAdjuster.cpp:348-353), then minus W V^-1 rhs_l
-// over its incidences (:480-484).  The factor rows of a pose are contiguous (pose-major),
-// so consecutive threads read consecutive 48-byte rows; the scalars are 8-byte gathers.
-// Fixed reduction order (strided entries per thread, xor-butterfly, waves in order).
-__global__ void __launch_bounds__(256)
-k_gather_rhs(uint32_t npose, const uint32_t* __restrict__ prhs_ptr,
-             const uint32_t* __restrict__ prhs_mid, const uint2* __restrict__ prhs_ent,
-             const double* __restrict__ frow, const double* __restrict__ scal, int D,
-             double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
-  __shared__ double red[4][12];
-  const uint32_t i = blockIdx.x;
-  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-  const uint32_t e0 = prhs_ptr[i], em = prhs_mid[i], e1 = prhs_ptr[i + 1];
-  double acc[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) acc[k] = 0.0;
-  for (uint32_t e = e0 + tid; e < em; e += 256) {
-    const uint2 p = prhs_ent[e];
-    const double* v = frow + (size_t)p.x * kRow;
-    const double sc = scal[p.y];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) acc[c] += v[c] * sc;
-  }
-  for (uint32_t e = em + tid; e < e1; e += 256) {
-    const uint2 p = prhs_ent[e];
-    const double* v = frow + (size_t)p.x * kRow;
-    const double sc = scal[p.y];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) acc[6 + c] += v[c] * sc;
-  }
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    double v = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) red[w][k] = v;
-  }
-  __syncthreads();
-  if (tid < 6) {
-    const double sa = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    const double sb = (red[0][6 + tid] + red[1][6 + tid]) + (red[2][6 + tid] + red[3][6 + tid]);
-    rhs_p[(size_t)i * D + tid] = sa;
-    rhs_sc[(size_t)i * D + tid] = sa + sb;
-  }
-  (void)npose;
 }
 
 // Lower storage of S at 64-tile granularity (row r: columns 0 .. 64 (r/64 + 1) - 1, i.e. the
@@ -232,38 +196,22 @@ int launch_pack_lower(Engine* e, int unpack) {
   return 0;
 }
 
-// Zeroes the 64x64 tiles of the lower triangle (tile row >= tile column) of the row-major
-// storage: half the bytes of clearing the square.  Nothing reads or writes the strictly upper
-// tiles except the corner of a diagonal D x D block that straddles a tile boundary, and that
-// corner is rewritten in full by k_gather_S_diag every iteration.
-__global__ void __launch_bounds__(256)
-k_zero_lower_tiles(double* __restrict__ A, uint32_t ld, uint32_t nblk) {
-  const uint32_t t = blockIdx.x;
-  uint32_t i = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((uint64_t)(i + 1) * (i + 2) / 2 <= t) ++i;
-  while ((uint64_t)i * (i + 1) / 2 > t) --i;
-  const uint32_t c = t - (uint32_t)((uint64_t)i * (i + 1) / 2);
-  if (i >= nblk) return;
-  double2* base = reinterpret_cast<double2*>(A + ((size_t)i * 64) * ld + (size_t)c * 64);
-  const int tid = threadIdx.x, col2 = tid & 31, r0 = tid >> 5;  // 32 double2 per row, 8 rows per pass
-#pragma unroll
-  for (int r = r0; r < 64; r += 8) base[(size_t)r * (ld / 2) + col2] = make_double2(0.0, 0.0);
-}
-
 int launch_gather_S(Engine* e) {
   const Structure& st = e->st;
   const uint32_t n = st.n, ld = st.ld, n_pad = ld;
-  // zero the lower storage + rhs row (the whole square once per structure, so that the unused
-  // upper tiles never hold garbage), then identity on the padding
+  // the whole square + rhs row is zeroed once per structure (the tiles above the diagonal are
+  // never written afterwards); every iteration k_assemble_tiles rewrites the lower triangle
   if (e->A_cleared != e->A.p) {
     BAE_HIP(hipMemsetAsync(e->A.p, 0, (size_t)(n_pad + 1) * ld * sizeof(double), e->stream));
     e->A_cleared = e->A.p;
-  } else {
-    const uint32_t nblk = n_pad / 64;
-    hipLaunchKernelGGL(k_zero_lower_tiles, dim3(nblk * (nblk + 1) / 2), dim3(256), 0, e->stream, e->A.p, ld, nblk);
-    BAE_HIP(hipGetLastError());
-    BAE_HIP(hipMemsetAsync(e->A.p + (size_t)n_pad * ld, 0, (size_t)ld * sizeof(double), e->stream));
   }
+  const uint32_t nt = n_pad / 64;
+  e->prof_begin(e->ev_gather);
+  hipLaunchKernelGGL(k_assemble_tiles, dim3(nt * (nt + 1) / 2), dim3(256), 0, e->stream, nt, e->tile_ptr.p,
+                     e->tile_ref.p, e->pair_ent.p, e->frow.p, ld, e->A.p);
+  e->prof_end(e->ev_gather);
+  BAE_HIP(hipGetLastError());
+  BAE_HIP(hipMemsetAsync(e->A.p + (size_t)n_pad * ld, 0, (size_t)ld * sizeof(double), e->stream));
   // fixed entries (padding identity, 1e6 on masked parameters) are written by shard 0
   // only, so that the cross-shard sum of S leaves them exact
   const int write_fixed = (e->rank == 0) ? 1 : 0;
@@ -276,25 +224,11 @@ int launch_gather_S(Engine* e) {
   BAE_HIP(hipMemsetAsync(e->rhs_sc.p, 0, e->rhs_sc.bytes(), e->stream));
   if (st.Pact > 0) {
     const uint16_t* masks = e->pose_mask.p + st.P;  // masks by opt id live after the by-id masks
-#define BAE_DIAG(LMV)                                                                              \
-  hipLaunchKernelGGL(k_gather_S_diag<LMV>, dim3(st.Pact), dim3(256), 0, e->stream,                 \
-                     (const uint32_t*)e->pose_rows.p, st.Pact, st.jbase, (const double*)e->frow.p, \
-                     e->pose_dim, ld, masks, write_fixed, e->A.p)
-    if (e->lm_dim == 0) BAE_DIAG(0); else if (e->lm_dim == 1) BAE_DIAG(1); else BAE_DIAG(3);
-#undef BAE_DIAG
-    BAE_HIP(hipGetLastError());
-  }
-  if (st.n_pairs > 0) {
-    e->prof_begin(e->ev_gather);
-    hipLaunchKernelGGL(k_gather_S, dim3((st.n_pairs + 19) / 20), dim3(256), 0, e->stream, st.n_pairs,
-                       e->pair_ptr.p, e->pair_ij.p, e->pair_ent.p, e->frow.p, e->pose_dim, ld, e->A.p);
-    e->prof_end(e->ev_gather);
-    BAE_HIP(hipGetLastError());
-  }
-  if (st.Pact > 0 && st.O > 0) {
-    hipLaunchKernelGGL(k_gather_rhs, dim3(st.Pact), dim3(256), 0, e->stream, st.Pact,
-                       e->prhs_ptr.p, e->prhs_ptr.p + (st.Pact + 1), e->prhs_ent.p, e->frow.p,
-                       e->scal.p, e->pose_dim, e->rhs_p.p, e->rhs_sc.p);
+    e->prof_begin(e->ev_pose);
+    hipLaunchKernelGGL(k_pose_blocks, dim3(st.Pact), dim3(256), 0, e->stream, e->pose_ptr.p, e->pose_mid.p,
+                       e->pose_ent.p, e->frow.p, e->scal.p, e->pose_dim, ld, masks, write_fixed, e->A.p,
+                       e->rhs_p.p, e->rhs_sc.p);
+    e->prof_end(e->ev_pose);
     BAE_HIP(hipGetLastError());
   }
   return 0;
@@ -676,9 +610,10 @@ __global__ void k_dots_lm(uint32_t L, int LM, int gn_ok, const int32_t* __restri
   if (threadIdx.x == 0)
     for (int c = 0; c < 3; ++c) partials[(size_t)c * nparts + blockIdx.x] = red[c][0];
 }
-// per observation: v = sqrt(w) (Jm rhs_p[m] + Jr rhs_p[r] + Jl rhs_l[l]); sum |v|^2
-__global__ void k_jrhs(uint32_t O, int D, int LM, const int32_t* __restrict__ obs_jrow_m,
-                       const int32_t* __restrict__ obs_jrow_r, const uint32_t* __restrict__ obs_pose,
+// per observation: v = sqrt(w) (Jm rhs_p[m] + Jr rhs_p[r] + Jl rhs_l[l]); sum |v|^2.  The J rows of
+// observation a are rows a R, a R + 1 (measuring pose) and a R + 2, a R + 3 (reference pose, LM 1)
+// of the factor rows; a side counts when the observation is listed and the pose active.
+__global__ void k_jrhs(uint32_t O, int D, int LM, const uint32_t* __restrict__ obs_pose,
                        const uint32_t* __restrict__ obs_lm, const uint32_t* __restrict__ lm_ref_pose,
                        const int32_t* __restrict__ pose_opt, const int32_t* __restrict__ lm_opt,
                        const double* __restrict__ frow, const double* __restrict__ obs_jl,
@@ -686,19 +621,21 @@ __global__ void k_jrhs(uint32_t O, int D, int LM, const int32_t* __restrict__ ob
                        double* __restrict__ partials) {
   __shared__ double red[256];
   const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int R = LM == 1 ? 6 : 8;
   double sq = 0.0;
   if (a < O) {
     double v0 = 0, v1 = 0;
-    const int jm = obs_jrow_m[a], jr = obs_jrow_r[a];
-    const uint32_t l = obs_lm[a];
-    if (jm >= 0) {
-      const double* g = rhs_p + (size_t)pose_opt[obs_pose[a]] * D;
-      const double* r0 = frow + (size_t)jm * kRow;
+    const uint32_t l = obs_lm[a], pm = obs_pose[a], rp = lm_ref_pose[l];
+    const bool listed = LM != 1 || pm != rp;
+    const int om = listed ? pose_opt[pm] : -1, orr = (LM == 1 && listed) ? pose_opt[rp] : -1;
+    if (om >= 0) {
+      const double* g = rhs_p + (size_t)om * D;
+      const double* r0 = frow + (a * R) * kRow;
       for (int c = 0; c < 6; ++c) { v0 += r0[c] * g[c]; v1 += r0[kRow + c] * g[c]; }
     }
-    if (jr >= 0) {
-      const double* g = rhs_p + (size_t)pose_opt[lm_ref_pose[l]] * D;
-      const double* r0 = frow + (size_t)jr * kRow;
+    if (orr >= 0) {
+      const double* g = rhs_p + (size_t)orr * D;
+      const double* r0 = frow + (a * R + 2) * kRow;
       for (int c = 0; c < 6; ++c) { v0 += r0[c] * g[c]; v1 += r0[kRow + c] * g[c]; }
     }
     if (lm_opt[l] >= 0)
@@ -744,9 +681,8 @@ int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
     const uint32_t nb = st.O > 0 ? (st.O + 255) / 256 : 0;
     if (nb) {
       hipLaunchKernelGGL(k_jrhs, dim3(nb), dim3(256), 0, e->stream, st.O, e->pose_dim, e->lm_dim,
-                         e->obs_jrow_m.p, e->obs_jrow_r.p, e->obs_pose.p, e->obs_lm.p,
-                         e->lm_ref_pose.p, e->pose_opt.p, e->lm_opt.p, e->frow.p, e->obs_jl.p,
-                         e->rhs_p.p, e->lm_bl.p, e->partials.p);
+                         e->obs_pose.p, e->obs_lm.p, e->lm_ref_pose.p, e->pose_opt.p, e->lm_opt.p, e->frow.p,
+                         e->obs_jl.p, e->rhs_p.p, e->lm_bl.p, e->partials.p);
       BAE_HIP(hipGetLastError());
     }
     if ((rc = sum_partials(e, nb, 1, h, true))) return rc;

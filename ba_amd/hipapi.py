@@ -54,13 +54,14 @@ class KernelStats(C.Structure):
     _fields_ = [("syrk_launches", C.c_uint32), ("gather_launches", C.c_uint32),
                 ("landmarks_launches", C.c_uint32), ("imu_launches", C.c_uint32),
                 ("syrk_ms", C.c_double), ("gather_ms", C.c_double), ("landmarks_ms", C.c_double),
-                ("syrk_flops", C.c_double), ("imu_ms", C.c_double)]
+                ("syrk_flops", C.c_double), ("imu_ms", C.c_double), ("pose_blocks_ms", C.c_double),
+                ("pose_blocks_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class StructureStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("poses_active", "landmarks_active", "observations", "incidences",
                                           "factor_rows", "pair_blocks", "pair_entries", "tiles_lower",
-                                          "tiles_S", "tiles_L")]
+                                          "tiles_S", "tiles_L", "tile_refs", "pose_entries", "linearize_waves")]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)

@@ -219,10 +219,12 @@ int ba_hip_get_unary_scales(ba_hip_engine* e, double* scale);
  * the engine's stream around every launch of the three hot kernels (used by bench.py's
  * roofline; costs two events per launch, so it is off by default). */
 typedef struct {
-  uint32_t syrk_launches, gather_launches, landmarks_launches, imu_launches;
+  uint32_t syrk_launches, gather_launches /* k_assemble_tiles */, landmarks_launches /* k_linearize */, imu_launches;
   double syrk_ms, gather_ms, landmarks_ms;
   double syrk_flops;       /* algorithmic flops of those k_syrk launches */
   double imu_ms;           /* k_imu, the BuildProblem launch (parallel_algos.h:178-358) */
+  double pose_blocks_ms;   /* k_pose_blocks: diagonal blocks + right-hand sides */
+  uint32_t pose_blocks_launches, reserved;
 } ba_hip_kernel_stats;
 /* Sizes of the static structure ba_hip_finalize built (for byte accounting in benchmarks). */
 typedef struct {
@@ -233,6 +235,9 @@ typedef struct {
   uint64_t pair_entries;      /* rank-1 terms summed into those blocks */
   uint64_t tiles_lower;       /* 64x64 tiles of the lower triangle incl. diagonal */
   uint64_t tiles_S, tiles_L;  /* of those: structurally nonzero in S / in its factor (after fill) */
+  uint64_t tile_refs;         /* (tile, block) references of the tile assembly (straddling blocks count twice) */
+  uint64_t pose_entries;      /* terms of the diagonal blocks / right-hand sides (12 bytes each) */
+  uint64_t linearize_waves;   /* wavefronts of the linearisation kernel */
 } ba_hip_structure_stats;
 int ba_hip_get_structure_stats(ba_hip_engine* e, ba_hip_structure_stats* out);
 int ba_hip_set_profiling(ba_hip_engine* e, int enable);

@@ -35,9 +35,14 @@ def hc():
     return ctypes.CDLL(LIB)
 
 
+@pytest.mark.parametrize("variant", [1, 0], ids=["proj_linearize", "proj_jacobians"])
 @pytest.mark.parametrize("lm_dim", [1, 3])
-def test_projection_jacobians_of_the_kernels_match_the_oracle(oracle_lib, hc, lm_dim):
+def test_projection_jacobians_of_the_kernels_match_the_oracle(oracle_lib, hc, lm_dim, variant):
+    """variant 1: dmath.h proj_linearize — the form k_linearize evaluates (fewer transforms held in
+    registers); variant 0: proj_jacobians, the literal closed form.  Both against the oracle's
+    2x4 . 4x7 . 7x7 . 7x6 chains."""
     po = oracle_lib
+    hc.ba_hostcheck_set_variant(variant)
     sc = scene.make_scene(30, 60, 5, lm_dim=lm_dim, seed=17)
     t_vs = np.array([0.05, -0.02, 0.1, 0.0, 0.0, 0.0, 1.0])
     t_vs[3:] = scene.quat_exp(np.array([0.02, -0.03, 0.01]))
