@@ -80,6 +80,13 @@ struct Engine {
   DBuf<uint2> wave_rng;                  // [n_chunks] observation ranges of the linearisation waves
   DBuf<uint32_t> tile_ptr;               // [tiles_lower+1]
   DBuf<uint2> tile_ref;                  // (first term, count << 14 | offsets) per block overlapping a tile
+  DBuf<uint32_t> tile_order;             // launch order of the tile assembly (build_tile_order)
+  uint32_t n_tile_order = 0;
+  uint64_t tile_order_version = ~0ull;
+  int dbg_assemble_variant = 5;          // k_assemble_tiles<VAR> (ba_hip_debug_set key 1)
+  int dbg_linearize_variant = 0;         // 0 LDS-staged factor rows, 1 direct stores (key 4)
+  int dbg_tile_order = 0;                // 0 row-major tiles, 1 XCD-aware columns (key 2)
+  int dbg_all_tiles = 0;                 // 1: assemble / zero every lower tile, not only the factor's pattern (key 3)
   DBuf<uint2> pair_ent;                  // (rowA, rowB) rank-1 terms of the off-diagonal blocks
   DBuf<uint32_t> pose_ptr, pose_mid;     // [Pact+1], [Pact]
   DBuf<uint32_t> pose_ent;               // 3 x n_pose_entries: (rowA, rowB, scalar index)
@@ -191,6 +198,7 @@ uint32_t choose_kout(uint32_t nblk);
 bool dist_solve_enabled(const Engine* e);
 int dist_reduce_scatter_S(Engine* e);
 int launch_imu_residual_vectors(Engine* e, double* d_r15);
+int build_tile_order(Engine* e);
 int check_solve_residual(Engine* e, const double* dS, const double* dx, const double* db, double* out2);
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz);
 

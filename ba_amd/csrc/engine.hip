@@ -281,11 +281,52 @@ static int build_structure(Engine* e) {
   // partial per linearisation wave
   const size_t nparts = std::max<size_t>({(O1 + 255) / 256, (L1 + 255) / 256, (size_t)(st.ld + 255) / 256, 1});
   BAE_HIP(e->partials.alloc(std::max<size_t>(4 * nparts, st.n_chunks)));
-  BAE_HIP(e->scalars_out.alloc(64));
+  BAE_HIP(e->scalars_out.alloc(128));  // [0,64) results / staging, [64,128) first-level partial sums
   BAE_HIP(e->hist.alloc(2048 + 8));
   BAE_HIP(e->flags.alloc(16));
   BAE_HIP(hipStreamSynchronize(e->stream));
   stage("upload / device buffers");
+  return 0;
+}
+
+// Launch order of the tile assembly (k_assemble_tiles).  Only tiles of the factor's pattern are
+// written every iteration: the others are zero since the one-off clear of the square and nobody ever
+// writes them (the factorisation skips structurally zero tiles).  Order: blocks b, b + 8, .. share
+// an XCD; XCD x gets the tile columns I = x, x + 8, .. and walks each from the diagonal down, so the
+// tiles in flight on one XCD gather the same pose group's rows out of its L2.
+int build_tile_order(Engine* e) {
+  const Structure& st = e->st;
+  if (!e->nzL_valid) {
+    int rc = factor_tile_pattern(e);
+    if (rc) return rc;
+  }
+  if (e->tile_order_version == e->nzL_version && e->tile_order.p) return 0;
+  const uint32_t nt = st.ld / 64;
+  const bool pat = !e->dbg_all_tiles && e->nzL_host.size() == (size_t)nt * nt;
+  std::vector<uint32_t> order;
+  size_t longest = 0;
+  if (e->dbg_tile_order == 1) {
+    std::vector<std::vector<uint32_t>> queue(8);
+    for (uint32_t I = 0; I < nt; ++I)
+      for (uint32_t J = I; J < nt; ++J)
+        if (!pat || e->nzL_host[(size_t)J * nt + I]) queue[I % 8].push_back((uint32_t)((uint64_t)J * (J + 1) / 2 + I));
+    for (auto& q : queue) longest = std::max(longest, q.size());
+    order.assign(std::max<size_t>(8 * longest, 1), 0xffffffffu);
+    for (uint32_t x = 0; x < 8; ++x)
+      for (size_t k = 0; k < queue[x].size(); ++k) order[8 * k + x] = queue[x][k];
+  } else {
+    // row-major over the lower tiles: a tile row mixes gather-heavy tiles near the diagonal band with
+    // fill-only tiles, so latency-bound and bandwidth-bound workgroups overlap on every CU
+    for (uint32_t J = 0; J < nt; ++J)
+      for (uint32_t I = 0; I <= J; ++I)
+        if (!pat || e->nzL_host[(size_t)J * nt + I]) order.push_back((uint32_t)((uint64_t)J * (J + 1) / 2 + I));
+    longest = (order.size() + 7) / 8;
+    order.resize(std::max<size_t>(8 * longest, 1), 0xffffffffu);
+  }
+  e->n_tile_order = (uint32_t)(8 * longest);
+  int rc = upload(e, e->tile_order, order);
+  if (rc) return rc;
+  e->tile_order_version = e->nzL_version;
   return 0;
 }
 
@@ -361,7 +402,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
 #define REL(b) e->b.release()
   REL(cam); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
-  REL(wave_rng); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
+  REL(wave_rng); REL(tile_order); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
   REL(imu_frozen); REL(imu_cov_done); REL(pose_cam);
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
@@ -996,6 +1037,18 @@ int ba_hip_get_structure_stats(ba_hip_engine* h, ba_hip_structure_stats* out) {
         out->tiles_S += e->nzS_host[i * nt + k] ? 1 : 0;
         out->tiles_L += e->nzL_host[i * nt + k] ? 1 : 0;
       }
+  return 0;
+}
+
+int ba_hip_debug_set(ba_hip_engine* h, int key, int value) {
+  ENG(h);
+  switch (key) {
+    case 1: e->dbg_assemble_variant = value; break;
+    case 2: e->dbg_tile_order = value; e->tile_order_version = ~0ull; break;
+    case 4: e->dbg_linearize_variant = value; break;
+    case 3: e->dbg_all_tiles = value; e->tile_order_version = ~0ull; e->A_cleared = nullptr; break;
+    default: return e->fail_msg("ba_hip_debug_set: unknown key");
+  }
   return 0;
 }
 

@@ -406,7 +406,7 @@ __device__ __forceinline__ void store_landmark(uint32_t l, uint32_t O, uint32_t 
   }
 }
 
-template <int LM, int WAVES, bool BIG>
+template <int LM, int WAVES, bool BIG, bool STAGE>
 __global__ void __launch_bounds__(64 * WAVES)
 k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_huber, int use_robust,
             const uint2* __restrict__ wave_rng, const uint32_t* __restrict__ lm_ptr,
@@ -423,7 +423,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
   constexpr int R = LM == 1 ? 6 : 8, RD = R * 6;   // rows / doubles per observation
   constexpr int STRIDE = RD + 2;                    // LDS stride per lane (even: 16-byte reads; odd multiple of 2 banks)
   constexpr int NS = LmSums<LM>::N, NV = LmSums<LM>::NV;
-  __shared__ __attribute__((aligned(16))) double stage[BIG ? 1 : WAVES][BIG ? 2 : 64 * STRIDE];
+  __shared__ __attribute__((aligned(16))) double stage[(BIG || !STAGE) ? 1 : WAVES][(BIG || !STAGE) ? 2 : 64 * STRIDE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t chunk = blockIdx.x * WAVES + wave;
   if (chunk >= n_chunks) return;  // waves are independent: no block-level barrier below
@@ -461,12 +461,20 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     for (int i = 0; i < NS; ++i) tot[i] = __shfl(v[i], s1, 64);
     double Vi[LM * LM];
     invert_v<LM>(tot, Vi);
-    double* st = stage[wave] + lane * STRIDE;
-    {
+    if constexpr (STAGE) {
+      double* st = stage[wave] + lane * STRIDE;
       double rows[RD];
       obs_rows<LM>(q, Vi, rows);
 #pragma unroll
       for (int i = 0; i < RD; i += 2) *reinterpret_cast<double2*>(st + i) = make_double2(rows[i], rows[i + 1]);
+    } else if (valid) {
+      // direct variant: every lane stores its own RD doubles (lane stride RD * 8 bytes); the L2 merges
+      // the partial lines of the wave's contiguous span
+      double rows[RD];
+      obs_rows<LM>(q, Vi, rows);
+      double* dst = frow + (size_t)a * RD;
+#pragma unroll
+      for (int i = 0; i < RD; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(rows[i], rows[i + 1]);
     }
     if (valid) {
       const double sw = sqrt(q.w);
@@ -478,6 +486,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
       if (lane == s1 && lm_act) store_landmark<LM>(l, O, lrow_base, tot, Vi, lm_vinv, lm_bl, scal, frow);
     }
     // LDS image -> one contiguous span of the factor rows (16 bytes per lane per store)
+    if constexpr (STAGE) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -487,6 +496,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     for (uint32_t g = 2 * lane; g < total; g += 128) {
       const uint32_t ln = g / RD, k = g - ln * RD;
       *reinterpret_cast<double2*>(dst + g) = *reinterpret_cast<const double2*>(img + ln * STRIDE + k);
+    }
     }
   } else {
     // one landmark with more than 64 observations: pass 1 sums, pass 2 rows (direct stores)
@@ -550,14 +560,20 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
       e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p, e->obs_jl.p, e->partials.p + (first)
   e->prof_begin(e->ev_landmarks);
   if (n_small) {
-    const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
-    if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
-    else hipLaunchKernelGGL((k_linearize<3, WAVES, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+    if (e->dbg_linearize_variant == 0) {
+      const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
+      if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, false, true>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      else hipLaunchKernelGGL((k_linearize<3, WAVES, false, true>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+    } else {
+      const dim3 grid((n_small + 3) / 4), block(256);
+      if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, 4, false, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      else hipLaunchKernelGGL((k_linearize<3, 4, false, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+    }
   }
   if (st.n_big_chunks) {
     const dim3 grid((st.n_big_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
-    if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, true>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
-    else hipLaunchKernelGGL((k_linearize<3, WAVES, true>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+    if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, true, false>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+    else hipLaunchKernelGGL((k_linearize<3, WAVES, true, false>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
   }
   e->prof_end(e->ev_landmarks);
 #undef BAE_ARGS

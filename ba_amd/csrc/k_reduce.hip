@@ -24,13 +24,21 @@ namespace bae {
 // byte of the lower triangle is written exactly once per iteration, coalesced: the separate
 // zero-fill pass and the 8-byte column scatters of the first design are gone.  Blocks that straddle
 // a tile boundary are listed by both tiles and clipped.  No atomics: bitwise reproducible.
+// VAR 0: one thread per block (36 accumulators), terms one by one
+// VAR 1: six threads per block (thread x forms row x of a (x) b), terms one by one
+// VAR 2: six threads per block, terms four at a time — the four (rowA, rowB) index pairs are loaded
+//        first, then the eight row pieces, so that a block's dependent-load chain is
+//        2 x ceil(terms / 4) memory latencies instead of 2 x terms
+template <int VAR>
 __global__ void __launch_bounds__(256)
-k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_ptr, const uint2* __restrict__ tile_ref,
-                 const uint2* __restrict__ pair_ent, const double* __restrict__ frow, uint32_t ld,
-                 double* __restrict__ A) {
+k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_ptr,
+                 const uint2* __restrict__ tile_ref, const uint2* __restrict__ pair_ent,
+                 const double* __restrict__ frow, uint32_t ld, double* __restrict__ A) {
   constexpr int TS = 66;  // LDS row stride (doubles): even, so that rows can be read 16 bytes at a time
   __shared__ __attribute__((aligned(16))) double T[64 * TS];
-  const uint32_t t = blockIdx.x;
+  // launch order: see build_tile_order (engine.hip); padding entries are 0xffffffff
+  const uint32_t t = tile_order[blockIdx.x];
+  if (t == 0xffffffffu) return;
   uint32_t tr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while ((uint64_t)(tr + 1) * (tr + 2) / 2 <= t) ++tr;
   while ((uint64_t)tr * (tr + 1) / 2 > t) --tr;
@@ -41,34 +49,138 @@ k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_ptr, const uint2
   if (q1 > q0) {
     for (int i = tid; i < 64 * TS / 2; i += 256) reinterpret_cast<double2*>(T)[i] = make_double2(0.0, 0.0);
     __syncthreads();
-    for (uint32_t q = q0 + tid; q < q1; q += 256) {
-      const uint2 ref = tile_ref[q];
-      const uint32_t cnt = ref.y >> 14;
-      const int ro = (int)((ref.y >> 7) & 127u) - kRefBias, co = (int)(ref.y & 127u) - kRefBias;
-      double acc[36];
+    if constexpr (VAR == 3) {
+      // experiment: no gather at all (floor of the write phase)
+    } else if constexpr (VAR == 0 || VAR == 4 || VAR == 5) {
+      for (uint32_t q = q0 + tid; q < q1; q += 256) {
+        const uint2 ref = tile_ref[q];
+        const uint32_t cnt = ref.y >> 14;
+        const int ro = (int)((ref.y >> 7) & 127u) - kRefBias, co = (int)(ref.y & 127u) - kRefBias;
+        double acc[36];
 #pragma unroll
-      for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-      for (uint32_t e = ref.x; e < ref.x + cnt; ++e) {
-        const uint2 en = pair_ent[e];
-        const double2* pa = reinterpret_cast<const double2*>(frow + (size_t)en.x * kRow);
-        const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)en.y * kRow);
-        const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-        const double a[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
-        const double b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+        uint32_t e = ref.x;
+        if constexpr (VAR == 5) {
+          // two terms at a time: both index pairs first, then the four rows (independent loads)
+          for (; e + 2 <= ref.x + cnt; e += 2) {
+            const uint2 en0 = pair_ent[e], en1 = pair_ent[e + 1];
+            const double2* pa0 = reinterpret_cast<const double2*>(frow + (size_t)en0.x * kRow);
+            const double2* pb0 = reinterpret_cast<const double2*>(frow + (size_t)en0.y * kRow);
+            const double2* pa1 = reinterpret_cast<const double2*>(frow + (size_t)en1.x * kRow);
+            const double2* pb1 = reinterpret_cast<const double2*>(frow + (size_t)en1.y * kRow);
+            const double2 a00 = pa0[0], a01 = pa0[1], a02 = pa0[2], b00 = pb0[0], b01 = pb0[1], b02 = pb0[2];
+            const double2 a10 = pa1[0], a11 = pa1[1], a12 = pa1[2], b10 = pb1[0], b11 = pb1[1], b12 = pb1[2];
+            const double a0[6] = {a00.x, a00.y, a01.x, a01.y, a02.x, a02.y};
+            const double b0[6] = {b00.x, b00.y, b01.x, b01.y, b02.x, b02.y};
+            const double a1[6] = {a10.x, a10.y, a11.x, a11.y, a12.x, a12.y};
+            const double b1[6] = {b10.x, b10.y, b11.x, b11.y, b12.x, b12.y};
 #pragma unroll
-        for (int x = 0; x < 6; ++x)
+            for (int x = 0; x < 6; ++x)
 #pragma unroll
-          for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a[x] * b[y];
+              for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a0[x] * b0[y];
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+#pragma unroll
+              for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a1[x] * b1[y];
+          }
+        }
+        for (; e < ref.x + cnt; ++e) {
+          const uint2 en = pair_ent[e];
+          const double2* pa = reinterpret_cast<const double2*>(frow + (size_t)en.x * kRow);
+          const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)en.y * kRow);
+          const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+          const double a[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+          const double b[6] = {b0.x, b0.y, b1.x, b1.y, b2.x, b2.y};
+#pragma unroll
+          for (int x = 0; x < 6; ++x)
+#pragma unroll
+            for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a[x] * b[y];
+        }
+        // block (i, j), i < j, lives transposed in the lower storage: row = j D + y, column = i D + x
+#pragma unroll
+        for (int y = 0; y < 6; ++y) {
+          const int rr = ro + y;
+          if (rr < 0 || rr >= 64) continue;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) {
+            const int cc = co + x;
+            if (cc >= 0 && cc < 64) T[rr * TS + cc] = acc[x * 6 + y];
+          }
+        }
       }
-      // block (i, j), i < j, lives transposed in the lower storage: row = j D + y, column = i D + x
+    } else {
+      // work item = (block, x): the six threads of a block each form one row x of a (x) b — they read
+      // the same rowB (one request) and consecutive doubles of rowA
+      const uint32_t items = (q1 - q0) * 6;
+      for (uint32_t it = tid; it < items; it += 256) {
+        const uint32_t q = q0 + it / 6, x = it - (it / 6) * 6;
+        const uint2 ref = tile_ref[q];
+        const uint32_t cnt = ref.y >> 14;
+        const int ro = (int)((ref.y >> 7) & 127u) - kRefBias, co = (int)(ref.y & 127u) - kRefBias;
+        double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        uint32_t e = ref.x;
+        const uint32_t e1 = ref.x + cnt;
+        if constexpr (VAR == 2) {
+          for (; e + 4 <= e1; e += 4) {
+            uint2 en[4];
 #pragma unroll
-      for (int y = 0; y < 6; ++y) {
-        const int rr = ro + y;
-        if (rr < 0 || rr >= 64) continue;
+            for (int u = 0; u < 4; ++u) en[u] = pair_ent[e + u];
+            double ax[4];
+            double2 b[4][3];
 #pragma unroll
-        for (int x = 0; x < 6; ++x) {
-          const int cc = co + x;
-          if (cc >= 0 && cc < 64) T[rr * TS + cc] = acc[x * 6 + y];
+            for (int u = 0; u < 4; ++u) {
+              ax[u] = frow[(size_t)en[u].x * kRow + x];
+              const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)en[u].y * kRow);
+              b[u][0] = pb[0]; b[u][1] = pb[1]; b[u][2] = pb[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              acc[0] += ax[u] * b[u][0].x; acc[1] += ax[u] * b[u][0].y; acc[2] += ax[u] * b[u][1].x;
+              acc[3] += ax[u] * b[u][1].y; acc[4] += ax[u] * b[u][2].x; acc[5] += ax[u] * b[u][2].y;
+            }
+          }
+          if (e < e1) {  // 1..3 terms left: same shape, out-of-range slots read the last term with weight 0
+            uint2 en[3];
+            double wgt[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const uint32_t ee = e + u < e1 ? e + u : e1 - 1;
+              en[u] = pair_ent[ee];
+              wgt[u] = e + u < e1 ? 1.0 : 0.0;
+            }
+            double ax[3];
+            double2 b[3][3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              ax[u] = frow[(size_t)en[u].x * kRow + x] * wgt[u];
+              const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)en[u].y * kRow);
+              b[u][0] = pb[0]; b[u][1] = pb[1]; b[u][2] = pb[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              if (wgt[u] != 0.0) {
+                acc[0] += ax[u] * b[u][0].x; acc[1] += ax[u] * b[u][0].y; acc[2] += ax[u] * b[u][1].x;
+                acc[3] += ax[u] * b[u][1].y; acc[4] += ax[u] * b[u][2].x; acc[5] += ax[u] * b[u][2].y;
+              }
+            }
+          }
+        } else {
+          for (; e < e1; ++e) {
+            const uint2 en = pair_ent[e];
+            const double ax = frow[(size_t)en.x * kRow + x];
+            const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)en.y * kRow);
+            const double2 b0 = pb[0], b1 = pb[1], b2 = pb[2];
+            acc[0] += ax * b0.x; acc[1] += ax * b0.y; acc[2] += ax * b1.x;
+            acc[3] += ax * b1.y; acc[4] += ax * b2.x; acc[5] += ax * b2.y;
+          }
+        }
+        const int cc = co + (int)x;
+        if (cc >= 0 && cc < 64) {
+#pragma unroll
+          for (int y = 0; y < 6; ++y) {
+            const int rr = ro + y;
+            if (rr >= 0 && rr < 64) T[rr * TS + cc] = acc[y];
+          }
         }
       }
     }
@@ -80,6 +192,7 @@ k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_ptr, const uint2
 #pragma unroll
   for (int r = tid >> 5; r < 64; r += 8) {
     const double2 v = q1 > q0 ? *reinterpret_cast<const double2*>(T + r * TS + 2 * c2) : make_double2(0.0, 0.0);
+    if (VAR == 4 && r >= 8) break;  // experiment: gather only (the tile is NOT written in full: wrong results)
     *reinterpret_cast<double2*>(base + (size_t)r * ld + 2 * c2) = v;
   }
 }
@@ -206,9 +319,19 @@ int launch_gather_S(Engine* e) {
     e->A_cleared = e->A.p;
   }
   const uint32_t nt = n_pad / 64;
+  {
+    int rc = build_tile_order(e);
+    if (rc) return rc;
+  }
   e->prof_begin(e->ev_gather);
-  hipLaunchKernelGGL(k_assemble_tiles, dim3(nt * (nt + 1) / 2), dim3(256), 0, e->stream, nt, e->tile_ptr.p,
-                     e->tile_ref.p, e->pair_ent.p, e->frow.p, ld, e->A.p);
+#define BAE_ASM(V)                                                                                       \
+  hipLaunchKernelGGL(k_assemble_tiles<V>, dim3(e->n_tile_order), dim3(256), 0, e->stream, nt, e->tile_order.p, \
+                     e->tile_ptr.p, e->tile_ref.p, e->pair_ent.p, e->frow.p, ld, e->A.p)
+  switch (e->dbg_assemble_variant) {
+    case 0: BAE_ASM(0); break; case 1: BAE_ASM(1); break; case 2: BAE_ASM(2); break;
+    case 3: BAE_ASM(3); break; case 4: BAE_ASM(4); break; default: BAE_ASM(5); break;
+  }
+#undef BAE_ASM
   e->prof_end(e->ev_gather);
   BAE_HIP(hipGetLastError());
   BAE_HIP(hipMemsetAsync(e->A.p + (size_t)n_pad * ld, 0, (size_t)ld * sizeof(double), e->stream));
@@ -326,12 +449,38 @@ __global__ void k_sum_partials(uint32_t nparts, uint32_t ncomp, const double* __
   }
 }
 
+// first level for long partial lists (one partial per linearisation wave: 167k at configs[3]): 64
+// blocks each sum a contiguous slice in fixed order into partials2
+__global__ void k_sum_partials_l1(uint32_t nparts, uint32_t nblk, const double* __restrict__ parts,
+                                  double* __restrict__ out) {
+  __shared__ double red[256];
+  const uint32_t per = (nparts + nblk - 1) / nblk;
+  const uint32_t i0 = blockIdx.x * per, i1 = min(nparts, i0 + per);
+  double s = 0.0;
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += 256) s += parts[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
 int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard) {
   if (nparts == 0) {
     for (uint32_t c = 0; c < ncomp; ++c) host_out[c] = 0.0;
   } else {
+    const double* src = e->partials.p;
+    if (ncomp == 1 && nparts > 8192) {
+      hipLaunchKernelGGL(k_sum_partials_l1, dim3(64), dim3(256), 0, e->stream, nparts, 64u, (const double*)e->partials.p,
+                         e->scalars_out.p + 64);
+      BAE_HIP(hipGetLastError());
+      src = e->scalars_out.p + 64;
+      nparts = 64;
+    }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, e->stream, nparts, ncomp,
-                       e->partials.p, e->scalars_out.p);
+                       src, e->scalars_out.p);
     BAE_HIP(hipGetLastError());
     BAE_HIP(hipMemcpyAsync(host_out, e->scalars_out.p, ncomp * sizeof(double),
                            hipMemcpyDeviceToHost, e->stream));

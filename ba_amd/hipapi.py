@@ -80,7 +80,7 @@ SYMBOLS = [
     "ba_hip_num_lm_params", "ba_hip_get_S", "ba_hip_get_rhs", "ba_hip_get_delta_gn",
     "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_proj_residuals", "ba_hip_get_imu_residuals", "ba_hip_get_imu_errors", "ba_hip_get_timers", "ba_hip_get_unary_scales", "ba_hip_device_buffer",
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
-    "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats",
+    "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set",
 ]
 
 
@@ -315,6 +315,9 @@ class Engine:
         st = StructureStats()
         self._chk(self.L.ba_hip_get_structure_stats(self.h, C.byref(st)))
         return {n: int(getattr(st, n)) for n, _ in StructureStats._fields_}
+
+    def debug_set(self, key, value):
+        self._chk(self.L.ba_hip_debug_set(self.h, int(key), int(value)))
 
     def set_profiling(self, on):
         self._chk(self.L.ba_hip_set_profiling(self.h, int(on)))

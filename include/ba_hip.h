@@ -240,6 +240,10 @@ typedef struct {
   uint64_t linearize_waves;   /* wavefronts of the linearisation kernel */
 } ba_hip_structure_stats;
 int ba_hip_get_structure_stats(ba_hip_engine* e, ba_hip_structure_stats* out);
+/* Experiment knobs for scratch/ micro-benchmarks (kernel variants with identical results): key 1 =
+ * variant of the tile assembly kernel (0, 1, 2), key 2 = launch order of its tiles (0 row-major,
+ * 1 XCD-aware columns), key 3 = 1: write every lower tile instead of the factor's pattern only. */
+int ba_hip_debug_set(ba_hip_engine* e, int key, int value);
 int ba_hip_set_profiling(ba_hip_engine* e, int enable);
 int ba_hip_get_kernel_stats(ba_hip_engine* e, ba_hip_kernel_stats* out);
 

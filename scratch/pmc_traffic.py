@@ -1,5 +1,5 @@
 """Per-kernel HBM-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one
-bench.py iteration; writes profiles/r01_pmc_traffic_cfg<N>.json.
+bench.py iteration; writes gpurun_out/r02_pmc_traffic_cfg<N>.json (copy it to profiles/).
 
 Run on the GPU box (one pass per counter: the TCC block cannot hold both, MI355X_MICROARCH.md):
     python scratch/pmc_traffic.py <config>
@@ -31,9 +31,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(root, "gpurun_out", "pmc_%s_cfg%d" % (ctr, cfg))
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--",
-           "python3", os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "1", "--warmup", "0",
+           "python3", os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-api", "--steps", "1", "--warmup", "0",
            "--config", str(cfg)]
     env = dict(os.environ, TMPDIR="/tmp")
+    print("pass", ctr, flush=True)
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         print(r.stdout[-2000:], r.stderr[-2000:]); sys.exit(1)
@@ -55,10 +56,10 @@ for k, o in out.items():
     f = o.get("FETCH_SIZE_KB_per_launch", 0.0); w = o.get("WRITE_SIZE_KB_per_launch", 0.0)
     o["traffic_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
 res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes, scratch/pmc_traffic.py) -- "
-                  "python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 --config %d" % cfg,
+                  "python3 bench.py --no-cpu-baseline --no-api --steps 1 --warmup 0 --config %d" % cfg,
        "corrections": "KB -> bytes; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)",
        "kernels": dict(sorted(out.items()))}
-path = os.path.join(root, "gpurun_out", "r01_pmc_traffic_cfg%d.json" % cfg)
+path = os.path.join(root, "gpurun_out", "r02_pmc_traffic_cfg%d.json" % cfg)
 json.dump(res, open(path, "w"), indent=1)
 print("wrote", path)
 for k in sorted(out, key=lambda k: -out[k]["traffic_bytes_per_launch_corrected"] * out[k]["launches"])[:8]:
