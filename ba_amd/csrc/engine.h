@@ -64,6 +64,11 @@ struct Engine {
   ba_hip_collective_fn coll = nullptr;   // broadcast / reduce-scatter: distributed reduced solve
   void* coll_ctx = nullptr;
   int rank = 0, nranks = 1;
+  // native RCCL communicator (ba_hip_comm_init, comm.hip); comm_force: run the sharded code paths
+  // even with one rank (exercises the RCCL calls on a one-GPU box)
+  void* comm = nullptr;
+  bool comm_force = false;
+  bool sharded() const { return allreduce && (nranks > 1 || comm_force); }
 
   // ---- device: static problem data
   DBuf<double> cam;                 // [C][4 + 12 (T_vs) + 12 (T_sv)]
@@ -76,6 +81,7 @@ struct Engine {
   DBuf<double> obs_z;               // [O][2]
   DBuf<uint32_t> obs_pose, obs_cam, obs_lm, obs_rid;
   DBuf<double> obs_w0;
+  DBuf<uint8_t> obs_cond;                // 1 = conditioning residual (ba_hip_set_conditioning_residuals)
   // static lists of structure.h
   DBuf<uint2> wave_rng;                  // [n_chunks] observation ranges of the linearisation waves
   DBuf<uint32_t> tile_ptr;               // [tiles_lower+1]
@@ -199,6 +205,10 @@ bool dist_solve_enabled(const Engine* e);
 int dist_reduce_scatter_S(Engine* e);
 int launch_imu_residual_vectors(Engine* e, double* d_r15);
 int build_tile_order(Engine* e);
+// broadcast of `count` doubles from `root`, ordered into `s`: native RCCL enqueues without a host
+// round trip; with a caller-supplied hook the stream is drained first (hook contract)
+int dist_broadcast(Engine* e, double* buf, size_t count, int root, hipStream_t s);
+void comm_release(Engine* e);
 int check_solve_residual(Engine* e, const double* dS, const double* dx, const double* db, double* out2);
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz);
 

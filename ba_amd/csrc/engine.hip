@@ -194,6 +194,13 @@ static int build_structure(Engine* e) {
   std::vector<U2>().swap(st.tile_ref);
   std::vector<U3>().swap(st.pose_ent);
   std::vector<double>().swap(st.obs_z);
+  {
+    // conditioning residuals (BundleAdjuster.h:503-510): flags in sorted order
+    std::vector<uint8_t> is_cond(st.O, 0), cond_sorted(std::max<uint32_t>(st.O, 1), 0);
+    for (uint32_t id : pb.proj_cond) if (id < st.O) is_cond[id] = 1;
+    for (uint32_t s = 0; s < st.O; ++s) cond_sorted[s] = is_cond[st.obs_rid[s]];
+    UP(obs_cond, cond_sorted);
+  }
   UP(pose_active, pb.pose_active);
   UP(un_pose, pb.un_pose); UP(un_t, pb.un_t); UP(un_cov_inv, pb.un_cov_inv); UP(un_rot, pb.un_rot);
   UP(bin_p1, pb.bin_p1); UP(bin_p2, pb.bin_p2); UP(bin_t, pb.bin_t); UP(bin_cov_inv, pb.bin_cov_inv);
@@ -401,7 +408,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   (void)hipStreamSynchronize(e->stream);
 #define REL(b) e->b.release()
   REL(cam); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
-  REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0);
+  REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0); REL(obs_cond);
   REL(wave_rng); REL(tile_order); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
   REL(imu_frozen); REL(imu_cov_done); REL(pose_cam);
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
@@ -416,6 +423,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(pp_h); REL(pp_g); REL(pp_dz); REL(pp_info); REL(pp_err); REL(pp_ptr); REL(pp_res_p1);
   REL(pp_res_p2); REL(pp_ent);
 #undef REL
+  comm_release(e);
   for (hipEvent_t ev : e->ev_panel) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->ev_bulk) (void)hipEventDestroy(ev);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -498,6 +506,13 @@ int ba_hip_set_projection_residuals(ba_hip_engine* h, uint32_t n, const double* 
   else pb.proj_cam.assign(n, 0);
   if (weight) pb.proj_w.assign(weight, weight + n);
   else pb.proj_w.assign(n, 1.0);
+  e->finalized = false;
+  return 0;
+}
+
+int ba_hip_set_conditioning_residuals(ba_hip_engine* h, uint32_t n, const uint32_t* residual_id) {
+  ENG(h);
+  e->prob.proj_cond.assign(residual_id, residual_id + n);
   e->finalized = false;
   return 0;
 }
@@ -613,6 +628,18 @@ int ba_hip_finalize(ba_hip_engine* h) {
 #define NEED_FINAL() \
   if (!e->finalized) return e->fail_msg("ba_hip_finalize has not been called")
 
+int ba_hip_get_conditioning_error(ba_hip_engine* h, double* proj_sq_sum) {
+  ENG(h);
+  NEED_FINAL();
+  BAE_HIP(hipSetDevice(e->device));
+  *proj_sq_sum = 0.0;
+  if (e->prob.proj_cond.empty() || e->st.O == 0) return 0;
+  int rc = launch_pose_prep(e);
+  if (rc) return rc;
+  if ((rc = launch_residuals(e, 2))) return rc;
+  return sum_partials(e, (e->st.O + 255) / 256, 1, proj_sq_sum);
+}
+
 int ba_hip_begin_solve(ba_hip_engine* h) {
   ENG(h);
   NEED_FINAL();
@@ -651,7 +678,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   EventTimer t_r(e->stream);
   double c_huber = 0.0;
   uint64_t n_total = st.O;
-  if (e->allreduce && e->nranks > 1) {
+  if (e->sharded()) {
     double cnt = (double)st.O;
     BAE_HIP(hipMemcpy(e->scalars_out.p, &cnt, sizeof(double), hipMemcpyHostToDevice));
     if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
@@ -679,7 +706,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   // copy the reduced rhs into the rhs row of A
   BAE_HIP(hipMemcpyAsync(e->A.p + (size_t)st.ld * st.ld, e->rhs_sc.p, (size_t)st.n * sizeof(double),
                          hipMemcpyDeviceToDevice, e->stream));
-  if (e->allreduce && e->nranks > 1) {
+  if (e->sharded()) {
     // S (lower storage) with its rhs row, and the unreduced rhs_p, are sums over the
     // landmark shards: one all-reduce each over xGMI.
     if (dist_solve_enabled(e)) {
@@ -1001,7 +1028,7 @@ int ba_hip_check_solve(ba_hip_engine* h, double* residual_norm, double* rhs_norm
   BAE_HIP(hipSetDevice(e->device));
   if (!(e->factored && e->opt.keep_reduced_system && e->A_keep.p))
     return e->fail_msg("ba_hip_check_solve needs keep_reduced_system and a finished ba_hip_solve_gn");
-  if (e->allreduce && e->nranks > 1) return e->fail_msg("ba_hip_check_solve: single shard only");
+  if (e->sharded()) return e->fail_msg("ba_hip_check_solve: single shard only");
   double o[2];
   int rc = check_solve_residual(e, e->A_keep.p, e->gn_p.p, e->rhs_sc.p, o);
   if (rc) return rc;
@@ -1027,7 +1054,7 @@ int ba_hip_get_structure_stats(ba_hip_engine* h, ba_hip_structure_stats* out) {
   out->tile_refs = st.n_tile_refs; out->pose_entries = st.n_pose_entries; out->linearize_waves = st.n_chunks;
   const uint64_t nt = st.ld / 64;
   out->tiles_lower = nt * (nt + 1) / 2;
-  if (!e->nzL_valid && !(e->allreduce && e->nranks > 1)) {
+  if (!e->nzL_valid && !(e->sharded())) {
     int rc = factor_tile_pattern(e);
     if (rc) return rc;
   }
@@ -1073,6 +1100,21 @@ int ba_hip_device_buffer(ba_hip_engine* h, int which, void** dev_ptr, size_t* nu
   if (which == 0) { *dev_ptr = e->A.p; *num_doubles = (size_t)(e->st.ld + 1) * e->st.ld; return 0; }
   if (which == 1) { *dev_ptr = e->scalars_out.p; *num_doubles = e->scalars_out.n; return 0; }
   return e->fail_msg("unknown buffer id");
+}
+
+int ba_hip_allreduce_host(ba_hip_engine* h, void* host, size_t count, int dtype) {
+  ENG(h);
+  if (!e->sharded() || count == 0) return 0;  // single shard: the values are already the totals
+  BAE_HIP(hipSetDevice(e->device));
+  DBuf<double> d;  // both element types are 8 bytes
+  BAE_HIP(d.alloc(count));
+  hipError_t err = hipMemcpy(d.p, host, count * 8, hipMemcpyHostToDevice);
+  int rc = 0;
+  if (err != hipSuccess) rc = e->fail(err, "hipMemcpy");
+  if (!rc && e->allreduce(e->allreduce_ctx, d.p, count, dtype) != 0) rc = e->fail_msg("allreduce hook failed");
+  if (!rc && (err = hipMemcpy(host, d.p, count * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = e->fail(err, "hipMemcpy");
+  d.release();
+  return rc;
 }
 
 int ba_hip_solve_is_distributed(ba_hip_engine* h) {

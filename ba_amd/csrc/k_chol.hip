@@ -1062,7 +1062,7 @@ int factor_tile_pattern(Engine* e) {
   if (nz.size() != (size_t)nt * nt) nz.assign((size_t)nt * nt, 1);
   static const bool dense = getenv("BA_HIP_DENSE") != nullptr;
   if (dense) std::fill(nz.begin(), nz.end(), 1);
-  if (e->allreduce && e->nranks > 1 && !dense) {
+  if (e->sharded() && !dense) {
     std::vector<double> cnt(nz.begin(), nz.end());
     DBuf<double> d;
     BAE_HIP(d.alloc(cnt.size()));
@@ -1120,7 +1120,7 @@ uint32_t choose_kout(uint32_t nblk) {
 // one rank takes part, and the reduced system need not stay readable (keep_reduced_system).
 bool dist_solve_enabled(const Engine* e) {
   static const bool off = getenv("BA_HIP_NO_DIST_SOLVE") != nullptr;
-  return e->coll && e->allreduce && e->nranks > 1 && !e->opt.keep_reduced_system && !off;
+  return e->coll && e->sharded() && !e->opt.keep_reduced_system && !off;
 }
 
 // rows [r0, r0 + nrows) x columns [c0, c0 + w) of A  <->  dense row-major block in buf
@@ -1397,8 +1397,12 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
                              hipMemcpyDeviceToDevice, s0));
     }
     BAE_HIP(hipGetLastError());
-    BAE_HIP(hipStreamSynchronize(s0));  // message complete / previous unpack done
-    if (e->coll(e->coll_ctx, 1, msg, msg_len, (int)owner) != 0) return e->fail_msg("broadcast hook failed");
+    // the message is complete / the previous unpack done in stream order; a native communicator
+    // enqueues the broadcast behind them, a hook gets a drained stream
+    {
+      const int brc = dist_broadcast(e, msg, msg_len, (int)owner, s0);
+      if (brc) return brc;
+    }
     if (rank != owner) {
       hipLaunchKernelGGL(k_copy_panel_rows, dim3(nrows), dim3(256), 0, s0, dA, ld, tl, ntl, nblk * NB, J * NB, w,
                          msg, 1);

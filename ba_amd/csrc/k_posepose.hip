@@ -274,7 +274,7 @@ static int sum_small(Engine* e, int n, const double* d_v, double* host) {
     BAE_HIP(hipMemcpyAsync(host, e->scalars_out.p + 8, sizeof(double), hipMemcpyDeviceToHost, e->stream));
     BAE_HIP(hipStreamSynchronize(e->stream));
   }
-  if (e->allreduce && e->nranks > 1) {
+  if (e->sharded()) {
     BAE_HIP(hipMemcpy(e->scalars_out.p + 8, host, sizeof(double), hipMemcpyHostToDevice));
     if (e->allreduce(e->allreduce_ctx, e->scalars_out.p + 8, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpy(host, e->scalars_out.p + 8, sizeof(double), hipMemcpyDeviceToHost));
@@ -286,7 +286,7 @@ static int sum_small(Engine* e, int n, const double* d_v, double* host) {
 int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
   const Problem& pb = e->prob;
   const uint32_t nu = pb.num_unary, nb = pb.num_binary, ni = pb.num_imu;
-  if (nu + nb + ni == 0 && !(e->allreduce && e->nranks > 1)) return 0;
+  if (nu + nb + ni == 0 && !(e->sharded())) return 0;
   int rc;
   const double* state = e->pose_state[e->cur].p;
   if (nu) {
@@ -298,7 +298,7 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
   // Huber sigma over the unary mahalanobis distances (BundleAdjuster.cpp:1457-1461); the
   // unary residuals live on shard 0, the selection is still a global one
   uint64_t n_un_total = nu;
-  if (e->allreduce && e->nranks > 1) {
+  if (e->sharded()) {
     double cnt = (double)nu;
     BAE_HIP(hipMemcpy(e->scalars_out.p, &cnt, sizeof(double), hipMemcpyHostToDevice));
     if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
@@ -371,7 +371,7 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
 int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
   const Problem& pb = e->prob;
   const uint32_t nu = pb.num_unary, nb = pb.num_binary, ni = pb.num_imu;
-  if (nu + nb + ni == 0 && !(e->allreduce && e->nranks > 1)) return 0;
+  if (nu + nb + ni == 0 && !(e->sharded())) return 0;
   int rc;
   const double* state = e->pose_state[e->cur].p;
   if (nu) {
@@ -406,7 +406,7 @@ int launch_posepose_jrhs(Engine* e, double* out) {
   const Problem& pb = e->prob;
   const uint32_t nres = pb.num_unary + pb.num_binary + pb.num_imu;
   *out = 0.0;
-  if (nres == 0 && !(e->allreduce && e->nranks > 1)) return 0;
+  if (nres == 0 && !(e->sharded())) return 0;
   if (nres) {
     hipLaunchKernelGGL(k_pp_jrhs, dim3((nres + 63) / 64), dim3(64), 0, e->stream, (int)nres, e->pose_dim,
                        e->pp_res_p1.p, e->pp_res_p2.p, e->pose_opt.p, e->pose_mask.p, e->pp_dz.p,

@@ -119,7 +119,8 @@ int launch_end_solve(Engine* e) {
 // One thread per observation (observations sorted by landmark: coalesced reads of the
 // observation list, the landmark row is shared by neighbouring lanes, pose transforms
 // are gathered through L2).  mode 0: err[a] = |r|^2 * orig_weight (input of the Huber
-// median, parallel_algos.h:143-150).  mode 1: EvaluateResiduals — sum |r|^2 * weight
+// median, parallel_algos.h:143-150).  mode 2: sum of |r|^2 over the conditioning residuals
+// (SolutionSummary::cond_proj_error, BundleAdjuster.cpp:692-703).  mode 1: EvaluateResiduals — sum |r|^2 * weight
 // and per-landmark outlier counts (BundleAdjuster.cpp:155-187); block partial sums go
 // to `partials` and are added in a fixed order by sum_partials (deterministic).
 template <int LM>
@@ -134,7 +135,8 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
                             const double* __restrict__ cam, const double* __restrict__ pose_cam,
                             const double* __restrict__ tsw,
                             const double* __restrict__ tws, double* __restrict__ err,
-                            uint32_t* __restrict__ lm_outliers, double* __restrict__ partials) {
+                            uint32_t* __restrict__ lm_outliers, double* __restrict__ partials,
+                            const uint8_t* __restrict__ cond) {
   __shared__ double red[256];
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   double val = 0.0;
@@ -156,11 +158,13 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
     val = sq * wts[a];
     if (mode == 0) {
       err[a] = val;
+    } else if (mode == 2) {
+      val = cond[a] ? sq : 0.0;  // conditioning residuals: |residual|^2, unweighted (BundleAdjuster.cpp:700-703)
     } else if (sqrt(sq) > outlier_thr) {
       atomicAdd(&lm_outliers[l], 1u);
     }
   }
-  if (mode == 1) {
+  if (mode >= 1) {
     red[threadIdx.x] = val;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -226,7 +230,8 @@ int launch_residuals(Engine* e, int mode) {
 #define BAE_ARGS                                                                          \
   O, (int)e->st.C, mode, e->opt.projection_outlier_threshold, e->obs_z.p, e->obs_pose.p,  \
       e->obs_cam.p, e->obs_lm.p, w, e->lm_x[e->cur].p, e->lm_ref_pose.p, e->lm_ref_cam.p, \
-      e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->obs_e.p, e->lm_outliers.p, e->partials.p
+      e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->obs_e.p, e->lm_outliers.p, e->partials.p,     \
+      (const uint8_t*)e->obs_cond.p
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_residuals<1>, grid, block, 0, e->stream, BAE_ARGS);
   else hipLaunchKernelGGL(k_residuals<3>, grid, block, 0, e->stream, BAE_ARGS);
 #undef BAE_ARGS

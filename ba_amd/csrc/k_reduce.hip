@@ -486,7 +486,7 @@ int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, b
                            hipMemcpyDeviceToHost, e->stream));
     BAE_HIP(hipStreamSynchronize(e->stream));
   }
-  if (cross_shard && e->allreduce && e->nranks > 1) {
+  if (cross_shard && e->sharded()) {
     // cross-shard sum of the scalars
     BAE_HIP(hipMemcpyAsync(e->scalars_out.p, host_out, ncomp * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
@@ -599,7 +599,7 @@ static int select_kth_device(Engine* e, const double* d_values, uint32_t n_local
 }
 
 int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out) {
-  if (!(e->allreduce && e->nranks > 1) && n_local > 0) return select_kth_device(e, d_values, n_local, k, out);
+  if (!(e->sharded()) && n_local > 0) return select_kth_device(e, d_values, n_local, k, out);
   // digits from the top: bits [63:53] [52:42] [41:31] [30:20] [19:9] [8:0](9 bits, shift 0)
   static const int shifts[6] = {53, 42, 31, 20, 9, 0};
   unsigned long long prefix = 0, mask = 0;
@@ -615,7 +615,7 @@ int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, 
       BAE_HIP(hipGetLastError());
     }
     BAE_HIP(hipStreamSynchronize(e->stream));
-    if (e->allreduce && e->nranks > 1)
+    if (e->sharded())
       if (e->allreduce(e->allreduce_ctx, e->hist.p, 2048, 1) != 0)
         return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpy(hh.data(), e->hist.p, 2048 * sizeof(unsigned long long),
@@ -707,7 +707,7 @@ int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norm
     BAE_HIP(hipGetLastError());
     int rc = sum_partials(e, nb, 1, &norms2_host[1]);  // landmarks are sharded: summed
     if (rc) return rc;
-  } else if (e->allreduce && e->nranks > 1) {
+  } else if (e->sharded()) {
     int rc = sum_partials(e, 0, 1, &norms2_host[1]);
     if (rc) return rc;
   }

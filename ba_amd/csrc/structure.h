@@ -61,6 +61,7 @@ struct Problem {  // host copies, reference ids
   std::vector<uint8_t> lm_active;
   std::vector<double> proj_z, proj_w;                      // [O][2], [O]
   std::vector<uint32_t> proj_pose, proj_lm, proj_cam;
+  std::vector<uint32_t> proj_cond;                         // ids of the conditioning residuals (summary only)
   // pose-pose residuals
   std::vector<uint32_t> un_pose; std::vector<double> un_t, un_cov_inv; std::vector<uint8_t> un_rot;
   std::vector<uint32_t> bin_p1, bin_p2; std::vector<double> bin_t, bin_cov_inv, bin_cov_inv_sqrt, bin_w;

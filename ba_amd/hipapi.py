@@ -80,7 +80,8 @@ SYMBOLS = [
     "ba_hip_num_lm_params", "ba_hip_get_S", "ba_hip_get_rhs", "ba_hip_get_delta_gn",
     "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_proj_residuals", "ba_hip_get_imu_residuals", "ba_hip_get_imu_errors", "ba_hip_get_timers", "ba_hip_get_unary_scales", "ba_hip_device_buffer",
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
-    "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set",
+    "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set", "ba_hip_set_conditioning_residuals",
+    "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host",
 ]
 
 
@@ -346,6 +347,21 @@ class Engine:
             return
         self._cb2 = COLLECTIVE_FN(lambda ctx, op, ptr, count, root: int(fn(op, ptr, count, root)))
         self._chk(self.L.ba_hip_set_collectives(self.h, self._cb2, None))
+
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (rank 0 creates it, the other ranks receive it out of band)."""
+        buf = C.create_string_buffer(128)
+        if lib().ba_hip_comm_unique_id(buf) != 0:
+            raise HipError("ba_hip_comm_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        """Native RCCL communicator inside the engine (collective over all ranks)."""
+        self._chk(self.L.ba_hip_comm_init(self.h, C.c_char_p(unique_id), int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        self._chk(self.L.ba_hip_comm_destroy(self.h))
 
     def solve_is_distributed(self):
         return bool(self.L.ba_hip_solve_is_distributed(self.h))

@@ -434,6 +434,7 @@ class BundleAdjuster {
   // through this hook (include/ba_hip.h)
   void SetAllReduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) {
     allreduce_ = fn; allreduce_ctx_ = ctx; rank_ = rank; nranks_ = nranks;
+    mask_counts_dirty_ = true;
   }
 
  private:
@@ -505,6 +506,9 @@ class BundleAdjuster {
   bool host_state_stale_ = false;          // the device holds a newer state than poses_ / landmarks_
   uint32_t uploaded_poses_ = 0, uploaded_landmarks_ = 0;  // sizes of the engine's copy of the graph
   std::vector<double> un_scale_seen_;      // cumulative Huber scale already folded into un_cov_inv_
+  std::vector<uint64_t> mask_counts_;      // per pose: proj, binary, unary, inertial residual counts (global); + #unary
+  bool mask_counts_dirty_ = true;
+  std::vector<uint16_t> masks_uploaded_;   // what the engine currently holds
   mutable Delta last_step_;
   mutable bool last_step_stale_ = false;
   ba_hip_timers last_timers_ = {};
@@ -634,6 +638,9 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   if (!Check(ba_hip_set_projection_residuals(engine_, (uint32_t)pr_pose_.size(), pr_z_.data(), pr_pose_.data(),
                                              pr_lm_.data(), pr_cam_.data(), pr_w_.data()),
              "ba_hip_set_projection_residuals")) return false;
+  if (!Check(ba_hip_set_conditioning_residuals(engine_, (uint32_t)conditioning_proj_residuals_.size(),
+                                               conditioning_proj_residuals_.data()),
+             "ba_hip_set_conditioning_residuals")) return false;
   if (!Check(ba_hip_set_unary_residuals(engine_, (uint32_t)un_pose_.size(), un_pose_.data(), un_t_.data(),
                                         un_cov_inv_.data(), un_rot_.data()), "ba_hip_set_unary_residuals")) return false;
   if (!Check(ba_hip_set_binary_residuals(engine_, (uint32_t)bin_p1_.size(), bin_p1_.data(), bin_p2_.data(),
@@ -647,6 +654,8 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   engine_per_pose_cam_ = options_.use_per_pose_cam_params;
   uploaded_poses_ = P; uploaded_landmarks_ = L;
   un_scale_seen_.assign(un_pose_.size(), 1.0);  // the engine's cumulative Huber scales restart at 1
+  mask_counts_dirty_ = true;
+  masks_uploaded_.clear();
   return true;
 }
 
@@ -681,26 +690,45 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::WriteReducedCam
 
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
 void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::ComputeMasks(std::vector<uint16_t>& masks) {
+  // Residual counts per pose.  With landmark shards (SetAllReduce / native communicator) every rank
+  // holds only its share of the projection residuals and rank 0 the pose-pose ones, but the masks
+  // must be the same on all ranks — they follow from the GLOBAL counts: summed once per graph.
+  const size_t P = poses_.size();
+  if (mask_counts_.size() != 4 * P + 1 || mask_counts_dirty_) {
+    mask_counts_.assign(4 * P + 1, 0);
+    for (size_t p = 0; p < P; ++p) {
+      mask_counts_[4 * p + 0] = poses_[p].num_proj_residuals;
+      mask_counts_[4 * p + 1] = poses_[p].num_binary_residuals;
+      mask_counts_[4 * p + 2] = poses_[p].num_unary_residuals;
+      mask_counts_[4 * p + 3] = poses_[p].num_inertial_residuals;
+    }
+    mask_counts_[4 * P] = un_pose_.size();
+    if (nranks_ > 1 && engine_)
+      Check(ba_hip_allreduce_host(engine_, mask_counts_.data(), mask_counts_.size(), 1), "ba_hip_allreduce_host");
+    mask_counts_dirty_ = false;
+  }
+  const uint64_t* cnt = mask_counts_.data();
   // :1240-1259 — note the loop stops at the first inactive pose
   bool are_all_active = true;
-  for (Pose& pose : poses_) {
+  for (size_t p = 0; p < P; ++p) {
+    Pose& pose = poses_[p];
     if (!pose.is_active) { are_all_active = false; break; }
-    if (pose.num_proj_residuals == 0 && pose.num_binary_residuals == 0 &&
-        pose.num_unary_residuals == 0 && pose.num_inertial_residuals == 0) {
+    if (cnt[4 * p] == 0 && cnt[4 * p + 1] == 0 && cnt[4 * p + 2] == 0 && cnt[4 * p + 3] == 0) {
       pose.is_param_mask_used = true;
       pose.param_mask.assign(kPoseDim, false);
     }
   }
   if (kVelInState) {  // :1263-1279
-    for (Pose& pose : poses_) {
-      if (pose.num_inertial_residuals == 0 && pose.is_active) {
+    for (size_t p = 0; p < P; ++p) {
+      Pose& pose = poses_[p];
+      if (cnt[4 * p + 3] == 0 && pose.is_active) {
         pose.is_param_mask_used = true;
         pose.param_mask.assign(kPoseDim, true);
         for (uint32_t i = 6; i < kPoseDim; ++i) pose.param_mask[i] = false;
       }
     }
   }
-  if (are_all_active && un_pose_.empty() && options_.enable_auto_regularization && !poses_.empty()) {
+  if (are_all_active && cnt[4 * P] == 0 && options_.enable_auto_regularization && !poses_.empty()) {
     Pose& root = poses_[root_pose_id_];  // :1285-1330
     root.is_param_mask_used = true;
     root.param_mask.assign(kPoseDim, true);
@@ -885,7 +913,10 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
       poses_[root_pose_id_].t_wp = SE3::from7(&pt[7 * (size_t)root_pose_id_]);
     }
     ComputeMasks(masks);
-    if (!Check(ba_hip_set_pose_masks(engine_, (uint32_t)masks.size(), masks.data()), "ba_hip_set_pose_masks")) return;
+    if (masks != masks_uploaded_) {  // usually unchanged between iterations and Solve() calls
+      if (!Check(ba_hip_set_pose_masks(engine_, (uint32_t)masks.size(), masks.data()), "ba_hip_set_pose_masks")) return;
+      masks_uploaded_ = masks;
+    }
     ba_hip_errors built;
     if (!Check(ba_hip_linearize(engine_, &built), "ba_hip_linearize")) return;  // BuildProblem .. Schur
     proj_error_ = built.proj_error; binary_error_ = built.binary_error;
@@ -939,10 +970,10 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     if (Check(ba_hip_get_imu_errors(engine_, md.data()), "ba_hip_get_imu_errors"))
       for (uint32_t id : conditioning_inertial_residuals_) summary_.cond_inertial_error += md[id];
   }
-  for (uint32_t id : conditioning_proj_residuals_) {
-    // res.mahalanobis_distance / res.weight = |residual|^2 (:700-703)
-    const ProjectionResidual& r = GetProjectionResidual(id);
-    summary_.cond_proj_error += r.residual[0] * r.residual[0] + r.residual[1] * r.residual[1];
+  if (!conditioning_proj_residuals_.empty()) {
+    // res.mahalanobis_distance / res.weight = |residual|^2 (:700-703), summed on the device
+    double sq = 0;
+    if (Check(ba_hip_get_conditioning_error(engine_, &sq), "ba_hip_get_conditioning_error")) summary_.cond_proj_error = sq;
   }
 }
 

@@ -110,6 +110,12 @@ int ba_hip_set_landmarks(ba_hip_engine* e, uint32_t n, const double* x_w4,
 int ba_hip_set_projection_residuals(ba_hip_engine* e, uint32_t n, const double* z2,
                                     const uint32_t* meas_pose_id, const uint32_t* landmark_id,
                                     const uint32_t* cam_id, const double* weight);
+/* Projection residuals that are "conditioning" (reference pose inactive, measuring pose active,
+ * BundleAdjuster.h:503-510): ids into the list above.  Only SolutionSummary::cond_proj_error uses
+ * them; ba_hip_get_conditioning_error returns the sum of |residual|^2 over them at the current state
+ * (BundleAdjuster.cpp:692-703), formed on the device. */
+int ba_hip_set_conditioning_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* residual_id);
+int ba_hip_get_conditioning_error(ba_hip_engine* e, double* proj_sq_sum);
 /* unary_residuals_ (BundleAdjuster.h:377-407): prior pose and cov^-1 (6x6 row-major) */
 int ba_hip_set_unary_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose_id,
                                const double* t_wp7, const double* cov_inv36,
@@ -256,6 +262,11 @@ int ba_hip_device_buffer(ba_hip_engine* e, int which, void** dev_ptr, size_t* nu
  * dtype: 0 = f64, 1 = u64.  Must return 0 on success.  NULL = single shard. */
 typedef int (*ba_hip_allreduce_fn)(void* ctx, void* dev_ptr, size_t count, int dtype);
 int ba_hip_set_allreduce(ba_hip_engine* e, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);
+/* Cross-shard SUM of `count` host values (dtype 0 = f64, 1 = u64) through the installed all-reduce
+ * (hook or native communicator); a no-op on a single shard.  Used by the host class for the few
+ * graph statistics the gauge masks depend on (BundleAdjuster.cpp:1237-1330): per-pose residual
+ * counts must be GLOBAL counts when the residuals are sharded. */
+int ba_hip_allreduce_host(ba_hip_engine* e, void* host, size_t count, int dtype);
 /* Collectives hook (optional, on top of the all-reduce hook): with it the dense reduced solve
  * is DISTRIBUTED over the shards instead of replicated:
  * the partial S of every shard is reduce-scattered to the owners of its column panels (256 / 512 / 1024 columns by system size)
@@ -267,6 +278,20 @@ int ba_hip_set_allreduce(ba_hip_engine* e, ba_hip_allreduce_fn fn, void* ctx, in
  * Same calling conventions as the all-reduce hook.  NULL = replicated solve. */
 typedef int (*ba_hip_collective_fn)(void* ctx, int op, void* dev_ptr, size_t count, int root);
 int ba_hip_set_collectives(ba_hip_engine* e, ba_hip_collective_fn fn, void* ctx);
+/* Native communicator: the engine loads librccl itself (one process per GPU, RCCL over xGMI) and
+ * runs every cross-shard sum and the collectives of the distributed reduced solve on an
+ * engine-owned ncclComm — a C++ user of ba::BundleAdjuster needs no torch and no hooks.
+ *   ba_hip_comm_unique_id  rank 0 creates the 128-byte id and hands it to the other ranks out of band
+ *   ba_hip_comm_init       collective over all ranks (ncclCommInitRank on the engine's device);
+ *                          installs the native all-reduce + collectives (replacing any hook) and sets
+ *                          rank / nranks.  nranks == 1 is allowed and still drives the sharded code
+ *                          paths through RCCL (test on a one-GPU box)
+ *   ba_hip_comm_destroy    back to a single unsharded engine
+ * With it the per-panel broadcast of the distributed solve is enqueued in stream order (no host
+ * round trip per panel). */
+int ba_hip_comm_unique_id(void* id128);
+int ba_hip_comm_init(ba_hip_engine* e, const void* id128, int rank, int nranks);
+int ba_hip_comm_destroy(ba_hip_engine* e);
 /* 1 if the next ba_hip_solve_gn will run the distributed solve, 0 if replicated / single. */
 int ba_hip_solve_is_distributed(ba_hip_engine* e);
 

@@ -1337,3 +1337,152 @@ def test_config4_full_size_all_residual_kinds(oracle_lib):
     assert tot[1] < tot[0]
     t, v, b = h.poses()
     assert np.all(np.isfinite(t)) and np.all(np.isfinite(v)) and np.all(np.isfinite(b))
+
+
+# ---- multi-rank paths: native RCCL, class-level sharding ------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep_s", [0, 1], ids=["distributed_solve", "replicated_solve"])
+def test_native_rccl_communicator_single_rank(oracle_lib, keep_s):
+    """ba_hip_comm_init: the engine loads librccl itself and runs the cross-shard sums and the
+    collectives of the distributed reduced solve on its own ncclComm.  One rank (all this box has):
+    the sharded code paths are forced on, every all-reduce / reduce-scatter / broadcast goes through
+    RCCL, and the results must equal the plain single engine and the oracle."""
+    lm_dim = 1
+    sc = scene.make_scene(300, 3000, 6, lm_dim=lm_dim, seed=67)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    keep[::sc.obs_per_landmark + 1] = False
+
+    def make(native):
+        eng = hipapi.Engine(lm_dim, 6)
+        o = hipapi.Options()
+        o.projection_outlier_threshold = 1.0
+        o.use_robust_norm_for_proj_residuals = 1
+        o.use_triangular_matrices = 1
+        o.keep_reduced_system = keep_s   # the distributed solve is off while S must stay readable
+        eng.set_options(o)
+        if native:
+            eng.comm_init(hipapi.Engine.comm_unique_id(), 0, 1)
+        eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+        eng.set_poses(sc.poses, is_active=pa)
+        eng.set_landmarks(sc.landmarks, sc.lm_ref_pose)
+        eng.set_projection_residuals(sc.obs_z[keep], sc.obs_pose[keep], sc.obs_lm[keep])
+        eng.finalize()
+        eng.begin_solve()
+        eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+        return eng
+
+    plain, native = make(False), make(True)
+    assert native.solve_is_distributed() == (keep_s == 0) and not plain.solve_is_distributed()
+    out = {}
+    _run_engine_steps(plain, 3, out, "plain")
+    _run_engine_steps(native, 3, out, "native")
+    for k in ("plain", "native"):
+        assert not isinstance(out[k], Exception), out[k]
+    for a, b in zip(out["plain"], out["native"]):
+        assert a[0] == b[0] == 0
+        for x, y in zip(a[1:], b[1:]):
+            assert abs(x - y) <= 1e-9 * max(abs(x), 1e-12)
+    pp, _, _ = plain.get_poses(sc.num_poses)
+    pn, _, _ = native.get_poses(sc.num_poses)
+    assert rel_err(pn, pp) < 1e-9
+    ref = _oracle_gn_run(oracle_lib, sc, lm_dim, pa, 3)
+    _check_against_oracle(ref, out, "native", pn)
+    native.comm_destroy()
+    assert not native.solve_is_distributed()
+    for e_ in (plain, native):
+        e_.end_solve()
+        e_.close()
+
+
+@pytest.mark.gpu
+def test_class_level_sharding_uses_global_counts_for_the_gauge_masks(oracle_lib):
+    """Two landmark shards driven through the C++ class (SetAllReduce), unary priors on rank 0 only
+    and one pose that only shard 0 observes: the gauge masks (BundleAdjuster.cpp:1237-1330) must
+    come from GLOBAL residual counts — with rank-local counts shard 1 would regularise the root
+    pose and fully mask the pose it does not see (round-1 advisor finding).  Reference: one
+    adjuster holding everything, and the oracle."""
+    import threading
+    import types
+
+    from ba_amd import sharding
+    po = oracle_lib
+    lm_dim = 1
+    sc = scene.make_scene(40, 200, 6, lm_dim=lm_dim, seed=91)
+    nsel = sc.obs_per_landmark + 1
+    L = sc.num_landmarks
+    half = L // 2
+    lonely = int(sc.obs_pose[nsel * 3 + 2])           # a pose that landmark 3 (shard 0) observes
+    idx = np.arange(len(sc.obs_pose))
+    drop = (sc.obs_lm >= half) & (sc.obs_pose == lonely) & (idx % nsel != 0)
+    drop |= (sc.lm_ref_pose[sc.obs_lm] == lonely) & (sc.obs_lm >= half)   # nor as a reference pose there
+    keep = ~drop
+
+    def sub(lo, hi):
+        m = keep & (sc.obs_lm >= lo) & (sc.obs_lm < hi)
+        s = types.SimpleNamespace(**vars(sc))
+        s.landmarks, s.lm_ref_pose = sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi]
+        s.obs_z, s.obs_pose, s.obs_lm = sc.obs_z[m], sc.obs_pose[m], sc.obs_lm[m] - lo
+        s.num_landmarks = hi - lo
+        return s
+
+    def priors(b):
+        for i in range(0, sc.num_poses, 8):
+            b.AddUnaryConstraint(i, sc.gt_poses[i], np.diag([1e-2] * 3 + [1e-3] * 3), True)
+
+    def make(cls, opts, s, with_priors):
+        b = cls(lm_dim, 6)
+        b.Init(opts)
+        fill(b, s)
+        if with_priors:
+            priors(b)
+        return b
+
+    whole = sub(0, L)
+    assert not np.any((whole.obs_pose == lonely) & (whole.obs_lm >= half))
+    o = make(po.OracleBundleAdjuster, gn_options(po), whole, True)
+    single = make(adjuster.BundleAdjuster, hip_options(write_reduced_camera_matrix=0), whole, True)
+    ranks = [make(adjuster.BundleAdjuster, hip_options(write_reduced_camera_matrix=0), sub(0, half), True),
+             make(adjuster.BundleAdjuster, hip_options(write_reduced_camera_matrix=0), sub(half, L), False)]
+    ar = sharding.ThreadAllReduce(2)
+    for r in range(2):
+        ranks[r].set_allreduce(ar.hook(r), r, 2)
+    res = {}
+
+    def run(r):
+        try:
+            rows = []
+            for _ in range(3):
+                ranks[r].Solve(1)
+                s = ranks[r].summary()
+                rows.append((s.result, s.proj_error, s.unary_error, s.delta_norm))
+            res[r] = rows
+        except Exception as exc:
+            res[r] = exc
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    rows_single, rows_o = [], []
+    for _ in range(3):
+        single.Solve(1)
+        o.Solve(1)
+        s, so = single.summary(), o.summary()
+        rows_single.append((s.result, s.proj_error, s.unary_error, s.delta_norm))
+        rows_o.append((so.result, so.proj_error, so.unary_error, so.delta_norm))
+    for t in th:
+        t.join(timeout=180)
+    assert not ar.failed
+    for r in range(2):
+        assert not isinstance(res[r], Exception), res[r]
+    for it in range(3):
+        assert res[0][it] == res[1][it] or np.allclose(res[0][it], res[1][it], rtol=1e-12)  # same sums on both ranks
+        for a, b_ in zip(res[0][it], rows_single[it]):
+            assert abs(a - b_) <= 1e-8 * max(abs(b_), 1e-12)
+        for a, b_ in zip(res[0][it], rows_o[it]):
+            assert abs(a - b_) <= 1e-7 * max(abs(b_), 1e-12)
+    ps, po_ = single.poses()[0], o.poses()[0]
+    p0, p1 = ranks[0].poses()[0], ranks[1].poses()[0]
+    assert np.array_equal(p0, p1)
+    assert rel_err(p0, ps) < 1e-9 and rel_err(p0, po_) < 1e-8
