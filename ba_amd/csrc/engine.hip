@@ -985,6 +985,29 @@ int ba_hip_get_proj_residuals(ba_hip_engine* h, double* residual2) {
   return 0;
 }
 
+int ba_hip_get_proj_jacobians(ba_hip_engine* h, double* j_meas12, double* j_ref12, double* j_lm, double* r2) {
+  ENG(h);
+  NEED_FINAL();
+  const Structure& st = e->st;
+  if (st.O == 0) return 0;
+  BAE_HIP(hipSetDevice(e->device));
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  const int LM = e->lm_dim, R = rows_per_obs(LM);
+  std::vector<double> rows((size_t)st.O * R * kRow), jl((size_t)st.O * 2 * LM), sc((size_t)2 * st.O);
+  BAE_HIP(hipMemcpy(rows.data(), e->frow.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+  BAE_HIP(hipMemcpy(jl.data(), e->obs_jl.p, jl.size() * sizeof(double), hipMemcpyDeviceToHost));
+  BAE_HIP(hipMemcpy(sc.data(), e->scal.p, sc.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (uint32_t s = 0; s < st.O; ++s) {
+    const size_t a = st.obs_perm[s];
+    const double* rr = &rows[(size_t)s * R * kRow];
+    if (j_meas12) for (int i = 0; i < 12; ++i) j_meas12[12 * a + i] = rr[i];
+    if (j_ref12) for (int i = 0; i < 12; ++i) j_ref12[12 * a + i] = LM == 1 ? rr[12 + i] : 0.0;
+    if (j_lm) for (int i = 0; i < 2 * LM; ++i) j_lm[2 * LM * a + i] = jl[(size_t)s * 2 * LM + i];
+    if (r2) { r2[2 * a] = sc[2 * (size_t)s]; r2[2 * a + 1] = sc[2 * (size_t)s + 1]; }
+  }
+  return 0;
+}
+
 int ba_hip_get_imu_residuals(ba_hip_engine* h, double* residual15) {
   ENG(h);
   NEED_FINAL();

@@ -81,7 +81,7 @@ SYMBOLS = [
     "ba_hip_get_step", "ba_hip_get_proj_weights", "ba_hip_get_proj_residuals", "ba_hip_get_imu_residuals", "ba_hip_get_imu_errors", "ba_hip_get_timers", "ba_hip_get_unary_scales", "ba_hip_device_buffer",
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
     "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set", "ba_hip_set_conditioning_residuals",
-    "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host",
+    "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host", "ba_hip_get_proj_jacobians",
 ]
 
 
@@ -300,6 +300,13 @@ class Engine:
         w = np.empty(n)
         self._chk(self.L.ba_hip_get_proj_weights(self.h, _p(w, dp)))
         return w
+
+    def get_proj_jacobians(self, n):
+        """sqrt(w)-weighted (dz_dx_meas, dz_dx_ref, dz_dlm, r) per residual id of the last linearisation."""
+        lm = max(self.lm_dim, 1)
+        jm, jr, jl, r = np.zeros((n, 2, 6)), np.zeros((n, 2, 6)), np.zeros((n, 2, lm)), np.zeros((n, 2))
+        self._chk(self.L.ba_hip_get_proj_jacobians(self.h, _p(jm, dp), _p(jr, dp), _p(jl, dp), _p(r, dp)))
+        return jm, jr, jl[:, :, :self.lm_dim], r
 
     def get_timers(self):
         t = Timers()

@@ -259,12 +259,17 @@ def main():
     if world > 1 and api_driver:
         raise SystemExit("configs 2 / 4 are single-GPU benchmarks (pose-pose residuals live on one rank)")
     dist = torch = None
+    # BA_BENCH_COMM=native (default): the engine's own RCCL communicator (ba_hip_comm_init) carries
+    # every collective; torch.distributed (gloo) is only the launcher's control plane (unique-id
+    # exchange, barriers, the max over ranks).  BA_BENCH_COMM=torch: collectives through
+    # torch.distributed hooks (backend nccl = RCCL; BA_BENCH_BACKEND=gloo for a CPU-staged rehearsal
+    # on a box with fewer GPUs than ranks).
+    comm_mode = os.environ.get("BA_BENCH_COMM", "native")
+    backend = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        # BA_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than
-        # ranks (ranks share devices; gloo stages the device tensors through the host)
-        backend = os.environ.get("BA_BENCH_BACKEND", "nccl")  # nccl = RCCL over xGMI
+        backend = os.environ.get("BA_BENCH_BACKEND", "gloo" if comm_mode == "native" else "nccl")
         if backend != "nccl":
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
@@ -289,7 +294,13 @@ def main():
         t_setup = time.perf_counter()
         eng, _ = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
         t_setup = time.perf_counter() - t_setup  # host -> device uploads + structure build (once per graph)
-        if world > 1:
+        if world > 1 and comm_mode == "native":
+            # native RCCL inside the engine: all-reduce, reduce-scatter of S to the panel owners,
+            # per-panel broadcast in stream order (BA_HIP_NO_DIST_SOLVE=1 keeps the replicated solve)
+            ids = [hipapi.Engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            eng.comm_init(ids[0], rank, world)
+        elif world > 1:
             eng.set_allreduce(sharding.torch_allreduce_hook(dist, "cuda"), rank, world)
             # distributed reduced solve: reduce-scatter of S to the panel owners, per-panel
             # factorisation + broadcast (BA_BENCH_REPLICATED_SOLVE=1 keeps the replicated solve)
@@ -314,7 +325,7 @@ def main():
         eng.set_profiling(False)
         n = eng.num_pose_params()
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         eng.end_solve()
@@ -417,7 +428,9 @@ def main():
                        "driver": ("ba::BundleAdjuster::Solve(1) per step on a warm object (C++ API path, include/ba_capi.h)"
                                   if api_driver else "phase calls of the C-ABI (include/ba_hip.h)"),
                        "parallelism": ("landmark-sharded x%d, reduce-scatter of S to panel owners, distributed LDL^T "
-                                       "(panel broadcast)" % world) if world > 1 else "single GPU"},
+                                       "(panel broadcast); collectives: %s" % (world, "engine-owned RCCL communicator"
+                                                                               if comm_mode == "native" else "torch.distributed hooks (%s)" % backend))
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "%s (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)" % bulk_kernel,
                          "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": syrk_tf / FP64_MFMA_PEAK_TF, "traffic": pmc_bytes("bae::" + bulk_kernel),

@@ -659,33 +659,70 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
   return true;
 }
 
-// Parameter masks (gauge handling), reference BundleAdjuster.cpp:1237-1330.
-// The reference's interchange dump (BundleAdjuster.cpp:600-606, Utils.h:66): the reduced
-// camera matrix s_ and the reduced right-hand side as CSV in Eigen's FullPrecision format
-// (", " between coefficients, one row per line) into s.txt and rhs.txt of the working
-// directory, so that a build of the original can be diffed against this one.  (The Jacobian
-// dumps j_pr.txt / j_l.txt / r_pr.txt of :608-616 are not produced: the Jacobians are never
-// materialised as matrices on the device.)
+// The reference's interchange dump (BundleAdjuster.cpp:600-616, Utils.h:66): the reduced camera
+// matrix s_, the reduced right-hand side and the dense images of j_pr_, r_pr_, j_l_ as CSV in
+// Eigen's FullPrecision format (", " between coefficients, one row per line) into s.txt, rhs.txt,
+// j_pr.txt, r_pr.txt, j_l.txt of the working directory, so that a build of the original can be
+// diffed against this one (ba_amd/dumps.py loads and cross-checks them).  j_pr.txt is
+// (2 x residuals) x (6 x active poses), j_l.txt (2 x residuals) x (LmSize x active landmarks) — dense:
+// a debug tool for small problems, as in the reference.  The calibration dumps (j_kpr.txt,
+// jt_kpr_j_kpr.txt) do not exist here: CalibSize is 0.
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
 void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::WriteReducedCameraMatrix() {
   const uint32_t n = ba_hip_num_pose_params(engine_);
-  if (n == 0) return;
   std::cerr << "Writing reduced camera matrix for " << n << " pose parameters and " << kCalibDim
             << " calib  parameters " << std::endl;
-  std::vector<double> sm((size_t)n * n), rhs(n);
-  if (!Check(ba_hip_get_S(engine_, sm.data()), "ba_hip_get_S")) return;
-  if (!Check(ba_hip_get_rhs(engine_, rhs.data(), nullptr, nullptr), "ba_hip_get_rhs")) return;
-  if (FILE* f = std::fopen("s.txt", "w")) {
-    for (uint32_t r = 0; r < n; ++r) {
-      for (uint32_t c = 0; c < n; ++c) std::fprintf(f, c ? ", %.16g" : "%.16g", sm[(size_t)r * n + c]);
-      std::fputc('\n', f);
+  auto put_row = [](FILE* f, const double* v, size_t cnt) {
+    for (size_t c = 0; c < cnt; ++c) std::fprintf(f, c ? ", %.17g" : "%.17g", v[c]);
+    std::fputc('\n', f);
+  };
+  if (n > 0) {
+    std::vector<double> sm((size_t)n * n), rhs(n);
+    if (!Check(ba_hip_get_S(engine_, sm.data()), "ba_hip_get_S")) return;
+    if (!Check(ba_hip_get_rhs(engine_, rhs.data(), nullptr, nullptr), "ba_hip_get_rhs")) return;
+    if (FILE* f = std::fopen("s.txt", "w")) {
+      for (uint32_t r = 0; r < n; ++r) put_row(f, &sm[(size_t)r * n], n);
+      std::fclose(f);
     }
-    std::fclose(f);
+    if (FILE* f = std::fopen("rhs.txt", "w")) {
+      for (uint32_t r = 0; r < n; ++r) put_row(f, &rhs[r], 1);
+      std::fclose(f);
+    }
   }
-  if (FILE* f = std::fopen("rhs.txt", "w")) {
-    for (uint32_t r = 0; r < n; ++r) std::fprintf(f, "%.16g\n", rhs[r]);
-    std::fclose(f);
+  const size_t O = pr_pose_.size();
+  if (O == 0 || LmSize == 0) return;
+  constexpr int LL = LmSize > 0 ? LmSize : 1;
+  std::vector<double> jm(12 * O), jr(12 * O), jl(2 * LL * O), rr(2 * O);
+  if (!Check(ba_hip_get_proj_jacobians(engine_, jm.data(), jr.data(), jl.data(), rr.data()), "ba_hip_get_proj_jacobians")) return;
+  const size_t pcols = (size_t)kPrPoseDim * num_active_poses_, lcols = (size_t)LL * num_active_landmarks_;
+  FILE* fp = std::fopen("j_pr.txt", "w");
+  FILE* fl = std::fopen("j_l.txt", "w");
+  FILE* fr = std::fopen("r_pr.txt", "w");
+  std::vector<double> prow(std::max<size_t>(pcols, 1)), lrow(std::max<size_t>(lcols, 1));
+  for (size_t a = 0; a < O && fp && fl && fr; ++a) {
+    const Landmark& lm = landmarks_[pr_lm_[a]];
+    const Pose& pm = poses_[pr_pose_[a]];
+    const Pose& pr = poses_[lm.ref_pose_id];
+    // blocks are inserted for active poses of "listed" residuals only (BundleAdjuster.h:489-497,
+    // BundleAdjuster.cpp:1613-1643, 1694-1720) and for active landmarks (:1788-1797)
+    const bool listed = LmSize != 1 || pr_pose_[a] != lm.ref_pose_id;
+    for (int k = 0; k < 2; ++k) {
+      std::fill(prow.begin(), prow.end(), 0.0);
+      std::fill(lrow.begin(), lrow.end(), 0.0);
+      if (listed && pm.is_active)
+        for (int c = 0; c < 6; ++c) prow[(size_t)pm.opt_id * kPrPoseDim + c] += jm[12 * a + 6 * k + c];
+      if (LmSize == 1 && listed && pr.is_active)
+        for (int c = 0; c < 6; ++c) prow[(size_t)pr.opt_id * kPrPoseDim + c] += jr[12 * a + 6 * k + c];
+      if (lm.is_active)
+        for (int c = 0; c < LL; ++c) lrow[(size_t)lm.opt_id * LL + c] = jl[2 * LL * a + LL * k + c];
+      if (pcols) put_row(fp, prow.data(), pcols);
+      if (lcols) put_row(fl, lrow.data(), lcols);
+      put_row(fr, &rr[2 * a + k], 1);
+    }
   }
+  if (fp) std::fclose(fp);
+  if (fl) std::fclose(fl);
+  if (fr) std::fclose(fr);
 }
 
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>

@@ -74,6 +74,36 @@ struct SE3 {
     q[0] = qq.x(); q[1] = qq.y(); q[2] = qq.z(); q[3] = qq.w();
   }
   void to7(double* p) const { for (int i = 0; i < 3; ++i) p[i] = t[i]; for (int i = 0; i < 4; ++i) p[3 + i] = q[i]; }
+  // group operations as Sophus::SE3Group offers them to callers (applications/: `pose * update`,
+  // `pose *= update`, `inverse()`); the quaternion product is renormalised as Sophus does
+  SE3 operator*(const SE3& o) const {
+    SE3 r;
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    // t + R o.t  (Eigen's _transformVector form)
+    const double ux = y * o.t[2] - z * o.t[1], uy = z * o.t[0] - x * o.t[2], uz = x * o.t[1] - y * o.t[0];
+    const double vx = 2 * ux, vy = 2 * uy, vz = 2 * uz;
+    r.t[0] = t[0] + o.t[0] + w * vx + (y * vz - z * vy);
+    r.t[1] = t[1] + o.t[1] + w * vy + (z * vx - x * vz);
+    r.t[2] = t[2] + o.t[2] + w * vz + (x * vy - y * vx);
+    r.q[0] = w * o.q[0] + x * o.q[3] + y * o.q[2] - z * o.q[1];
+    r.q[1] = w * o.q[1] + y * o.q[3] + z * o.q[0] - x * o.q[2];
+    r.q[2] = w * o.q[2] + z * o.q[3] + x * o.q[1] - y * o.q[0];
+    r.q[3] = w * o.q[3] - x * o.q[0] - y * o.q[1] - z * o.q[2];
+    const double n = std::sqrt(r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3]);
+    for (int i = 0; i < 4; ++i) r.q[i] /= n;
+    return r;
+  }
+  SE3& operator*=(const SE3& o) { *this = *this * o; return *this; }
+  SE3 inverse() const {
+    SE3 r;
+    r.q[0] = -q[0]; r.q[1] = -q[1]; r.q[2] = -q[2]; r.q[3] = q[3];
+    SE3 rot = r;  // pure rotation R^T
+    SE3 tt;
+    tt.t[0] = -t[0]; tt.t[1] = -t[1]; tt.t[2] = -t[2];
+    r = rot * tt;
+    r.q[0] = -q[0]; r.q[1] = -q[1]; r.q[2] = -q[2]; r.q[3] = q[3];
+    return r;
+  }
   Vector3t translation() const { Vector3t v; for (int i = 0; i < 3; ++i) v[i] = t[i]; return v; }
   Matrix3t rotationMatrix() const {
     const double x = q[0], y = q[1], z = q[2], w = q[3];

@@ -202,6 +202,13 @@ int ba_hip_get_proj_weights(ba_hip_engine* e, double* weight); /* per residual i
 /* residual vectors z - pi (2 doubles per residual id) at the current state, i.e. what
  * ProjectionResidual::residual holds after a Solve() (BundleAdjuster.cpp:155-181) */
 int ba_hip_get_proj_residuals(ba_hip_engine* e, double* residual2);
+/* The weighted Jacobian blocks and residuals of the last ba_hip_linearize as the reference stores
+ * them in j_pr_, j_l_ and r_pr_ (BundleAdjuster.cpp:1636-1642, 1795-1796, 1384-1385): per residual id
+ * sqrt(w) dz_dx_meas (2x6), sqrt(w) dz_dx_ref (2x6, LmSize 1), sqrt(w) dz_dlm (2xLm) and
+ * sqrt(w) r (2), masked columns zeroed.  Read back from the factor rows — the device never holds a
+ * Jacobian MATRIX; the host class writes the reference's j_pr.txt / j_l.txt / r_pr.txt from this
+ * (write_reduced_camera_matrix, BundleAdjuster.cpp:608-616).  Any pointer may be NULL. */
+int ba_hip_get_proj_jacobians(ba_hip_engine* e, double* j_meas12, double* j_ref12, double* j_lm, double* r2);
 int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
 /* Test tap for systems too large to download (S is 28.8 GB at BASELINE.json configs[3]): forms
  * || S delta_gn - rhs_p_sc || and || rhs_p_sc || ON THE DEVICE from the copy of S kept before the

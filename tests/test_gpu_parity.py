@@ -376,17 +376,60 @@ def test_cpp_application_runs_on_the_engine():
     assert "proj error" in r.stdout
 
 
-def test_pose_graph_application_with_interpolation_buffer():
-    """applications/unary_binary_imu_test: the shape of the reference's application of the same
-    name (BundleAdjuster<double,0,9,0>; odometry -> binary, position fixes -> unary, IMU via
-    InterpolationBufferT::GetRange -> AddImuResidual; Solve; GetPose) on synthetic streams."""
+def test_pose_graph_application_with_interpolation_buffer(oracle_lib, tmp_path):
+    """applications/unary_binary_imu_test — the reference's GPS + IMU pose-graph program
+    (BundleAdjuster<double,0,9,0>, `ODO` / `UTM` / `IMU` log parser, gyro dead reckoning, unary
+    constraints at the fixes, IMU residuals over InterpolationBufferT::GetRange, Solve(25, 0.2)) on the
+    committed synthetic log.dat.  The program dumps the graph it built; the same graph goes through
+    the oracle with the same options and the two solutions must agree."""
     import subprocess
+    po = oracle_lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "ba_amd", "lib", "unary_binary_imu_test")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    log = os.path.join(root, "applications", "unary_binary_imu_test", "log.dat")
+    graph = str(tmp_path / "graph.txt")
+    r = subprocess.run([exe, log, "--dump-graph", graph], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "mean position error" in r.stdout
+    nodes = np.array([[float(x) for x in ln.split()[1:]] for ln in r.stdout.splitlines() if ln.startswith("NODE")])
+    summ = [ln for ln in r.stdout.splitlines() if ln.startswith("SUMMARY")][0].split()
+    assert len(nodes) == 41   # one node per UTM record of the committed log
+    # ---- the same graph through the oracle ----
+    o = po.OracleBundleAdjuster(0, 9)
+    opt = po.default_options()
+    opt.trust_region_size = 100000
+    o.Init(opt)
+    o.SetGravity([0.0, 0.0, 9.8])
+    cov = np.diag([1000.0, 1000.0, 30000.0, np.finfo(float).max, np.finfo(float).max, np.finfo(float).max])
+    with open(graph) as f:
+        lines = f.read().splitlines()
+    i = 0
+    nimu = 0
+    while i < len(lines):
+        w = lines[i].split()
+        if w[0] == "POSE":
+            assert o.AddPose([float(x) for x in w[3:10]], True, float(w[2])) == int(w[1])
+        elif w[0] == "UNARY":
+            o.AddUnaryConstraint(int(w[1]), [float(w[2]), float(w[3]), float(w[4]), 0, 0, 0, 1], cov, True)
+        elif w[0] == "IMU":
+            n = int(w[3])
+            meas = np.array([[float(x) for x in lines[i + 1 + k].split()] for k in range(n)])
+            o.AddImuResidual(int(w[1]), int(w[2]), meas)
+            i += n
+            nimu += 1
+        i += 1
+    assert nimu == len(nodes) - 1
+    o.Solve(25, 0.2)
+    so = o.summary()
+    assert int(summ[2]) == so.result
+    t_o, v_o, _ = o.poses()
+    assert rel_err(nodes[:, 2:9], t_o) < 1e-6          # poses (north_star tolerance on the state)
+    assert np.abs(nodes[:, 9:12] - v_o).max() < 1e-6 * max(1.0, np.abs(v_o).max())
+    # the inertial error at the solution is a 1e-7 remnant of cancelling terms: absolute agreement
+    assert abs(float(summ[6]) - so.inertial_error) <= 1e-8
+    assert abs(float(summ[4]) - so.unary_error) <= 1e-6 * so.unary_error
+    # the solve did something: the nodes moved away from pure gyro dead reckoning
+    assert np.abs(nodes[:, 2:4]).max() > 10.0
 
 
 # ---- landmark sharding (SURVEY.md §8e) on one device ------------------------------------------
@@ -845,6 +888,54 @@ def test_reduced_camera_matrix_dump(tmp_path, monkeypatch):
     assert rel_err(rhs, h.rhs()) < 1e-15
     first = (tmp_path / "s.txt").read_text().splitlines()[0]
     assert ", " in first and ";" not in first  # Utils.h:66 kLongCsvFmt
+
+
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_jacobian_dumps_and_loader(oracle_lib, tmp_path, monkeypatch, lm_dim):
+    """j_pr.txt / r_pr.txt / j_l.txt (BundleAdjuster.cpp:608-616) + ba_amd/dumps.py: the dumped
+    Jacobians equal the oracle's sqrt(w) J blocks, and s.txt / rhs.txt equal the Schur complement
+    rebuilt from the dumped files with dense numpy — what a third party holding a build of the
+    original would diff."""
+    from ba_amd import dumps
+    po = oracle_lib
+    sc = scene.make_scene(14, 50, 5, lm_dim=lm_dim, seed=19)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    la = np.ones(sc.num_landmarks, dtype=np.uint8)
+    la[[3, 17]] = 0
+    monkeypatch.chdir(tmp_path)
+    o, h = both(po, sc, lm_dim, active=pa, lm_active=la, apply_results=0, write_reduced_camera_matrix=2)
+    o.Solve(1)
+    h.Solve(1)
+    d = dumps.load_reduced_system(str(tmp_path))
+    assert set(d) == {"s", "rhs", "j_pr", "r_pr", "j_l"}
+    O = h.GetNumProjResiduals()
+    nP, nL = int(pa.sum()), int(la.sum())
+    assert d["j_pr"].shape == (2 * O, 6 * nP) and d["j_l"].shape == (2 * O, lm_dim * nL) and d["r_pr"].shape == (2 * O,)
+    err_s, err_r = dumps.check_consistency(d, lm_dim)
+    assert err_s < 1e-11 and err_r < 1e-11, (err_s, err_r)
+    # against the oracle: its per-residual Jacobians are unweighted (as stored in the residual), the
+    # dumped matrices carry sqrt(w) (j_pr_ entries, :1636-1642)
+    jm_o, jr_o, jl_o = o.proj_jacobians()
+    sw = np.sqrt(o.proj_weights())
+    acc = accepted_obs(sc)
+    popt = -np.ones(sc.num_poses, dtype=int)
+    popt[pa > 0] = np.arange(nP)
+    lopt = -np.ones(sc.num_landmarks, dtype=int)
+    lopt[la > 0] = np.arange(nL)
+    Jp, Jl = np.zeros_like(d["j_pr"]), np.zeros_like(d["j_l"])
+    for a, (pm, pr, l) in enumerate(acc):
+        listed = lm_dim != 1 or pm != pr
+        if listed and popt[pm] >= 0:
+            Jp[2 * a:2 * a + 2, 6 * popt[pm]:6 * popt[pm] + 6] += sw[a] * jm_o[a]
+        if lm_dim == 1 and listed and popt[pr] >= 0:
+            Jp[2 * a:2 * a + 2, 6 * popt[pr]:6 * popt[pr] + 6] += sw[a] * jr_o[a]
+        if lopt[l] >= 0:
+            Jl[2 * a:2 * a + 2, lm_dim * lopt[l]:lm_dim * lopt[l] + lm_dim] = sw[a] * jl_o[a]
+    assert rel_err(d["j_pr"], Jp) < 1e-11
+    assert rel_err(d["j_l"], Jl) < 1e-11
+    assert rel_err(d["r_pr"], (sw[:, None] * o.proj_residuals()).ravel()) < 1e-11
+    assert dumps.diff(str(tmp_path), str(tmp_path))["s"] == 0.0
 
 
 # ---- full-size properties (BASELINE.json configs[1]) ---------------------------------------
