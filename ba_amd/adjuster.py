@@ -38,7 +38,7 @@ class BaOptions(C.Structure):
                 ("use_robust_norm_for_proj_residuals", C.c_int32),
                 ("use_robust_norm_for_inertial_residuals", C.c_int32),
                 ("write_reduced_camera_matrix", C.c_int32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("factorization_pivot_tolerance", C.c_double)]
 
 
 class BaSummary(C.Structure):

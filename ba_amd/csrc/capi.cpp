@@ -63,6 +63,7 @@ struct Impl : Iface {
     opt.write_reduced_camera_matrix = o->write_reduced_camera_matrix >= 2;
     opt.keep_reduced_system = o->write_reduced_camera_matrix != 0;
     opt.device = o->device;
+    opt.factorization_pivot_tolerance = o->factorization_pivot_tolerance;
     ba.Init(opt);
   }
   void set_gravity(const double* g) override { ba.SetGravity(ba::Vector3t({g[0], g[1], g[2]})); }
@@ -202,6 +203,7 @@ void ba_default_options(ba_options* o) {
   o->use_robust_norm_for_inertial_residuals = d.use_robust_norm_for_inertial_residuals;
   o->write_reduced_camera_matrix = d.write_reduced_camera_matrix ? 2 : (d.keep_reduced_system ? 1 : 0);
   o->device = d.device;
+  o->factorization_pivot_tolerance = d.factorization_pivot_tolerance;
 }
 ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim) {
   Iface* p = make(lm_dim, pose_dim);

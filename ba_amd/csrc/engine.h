@@ -149,7 +149,8 @@ struct Engine {
   DBuf<double> partials;                 // reduction scratch
   DBuf<double> scalars_out;              // small result block (device) + host mirror
   DBuf<unsigned long long> hist;         // selection histograms
-  DBuf<int32_t> flags;                   // factorisation status etc.
+  DBuf<int32_t> flags;                   // factorisation status block (k_chol.hip: setup_status_block)
+  DBuf<double> pivot_floor;              // tol * |S_jj| per row (ba_hip_options::pivot_rel_tolerance)
 
   // optional per-kernel timing (ba_hip_set_profiling)
   bool profiling = false;

@@ -416,7 +416,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
   REL(gn_l); REL(step_p); REL(step_l); REL(invdiag); REL(partials); REL(scalars_out); REL(hist);
-  REL(flags);
+  REL(flags); REL(pivot_floor);
   REL(pose_active); REL(un_pose); REL(un_t); REL(un_cov_inv); REL(un_scale); REL(un_rot);
   REL(bin_p1); REL(bin_p2); REL(bin_t); REL(bin_cov_inv); REL(bin_cov_inv_sqrt); REL(bin_w); REL(bin_rot);
   REL(imu_p1); REL(imu_p2); REL(imu_ptr); REL(imu_meas); REL(imu_consts); REL(imu_cov_inv);

@@ -605,7 +605,7 @@ struct TileLds {
 // compiler would otherwise re-serialise the updates into dot products in front of every
 // pivot).  The rest of the tile is updated on the matrix cores straight out of LDS.
 // Diagonal inverses: lane = (block, column), column-oriented forward substitution.
-__device__ __forceinline__ void factor_tile_wave0(TileLds& sh, int lane) {
+__device__ __forceinline__ void factor_tile_wave0(TileLds& sh, int lane, const double* __restrict__ floor_tile) {
   const int li = lane & 15, lk = lane >> 4;
   unsigned long long negmask = 0;
 #pragma unroll
@@ -693,6 +693,9 @@ __device__ __forceinline__ void factor_tile_wave0(TileLds& sh, int lane) {
   {
     const double q = sh.T[lane][lane];
     if (!(q > 0.0 && q < 1e150)) sh.bad = 1;  // zero, NaN or Inf pivot
+    // optional rank-deficiency guard (ba_hip_options::pivot_rel_tolerance): |d_j| = q^2 against
+    // tol * |S_jj| of the matrix before elimination
+    if (floor_tile && q * q < floor_tile[lane]) sh.bad = 1;
     sh.dv[lane] = 1.0 / q;
   }
   {
@@ -853,7 +856,10 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
       }
   if (tid == 0) sh.bad = 0;
   __syncthreads();
-  if (wave == 0) factor_tile_wave0(sh, lane);
+  // the per-row pivot floors, if any, are published through the status block (ints 2..3 hold the
+  // device pointer): no extra kernel argument on the many launch sites
+  const double* floors = *reinterpret_cast<const double* const*>(status + 2);
+  if (wave == 0) factor_tile_wave0(sh, lane, floors ? floors + (size_t)c0 * NB : nullptr);
   __syncthreads();
   {
     double* ob = opbuf + (size_t)c0 * NOPV * 64;
@@ -1327,6 +1333,28 @@ int dist_reduce_scatter_S(Engine* e) {
   return 0;
 }
 
+// pivot floors tol * |A_jj| of the matrix about to be factorised (rank-deficiency guard)
+__global__ void k_pivot_floor(uint32_t n_pad, uint32_t ld, const double* __restrict__ A, double tol,
+                              double* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_pad) out[j] = tol * fabs(A[(size_t)j * ld + j]);
+}
+
+// status block: int 0 = factorisation status, ints 2..3 = device pointer of the pivot floors (or null)
+static int setup_status_block(Engine* e, const double* dA, uint32_t ld, hipStream_t s0) {
+  BAE_HIP(hipMemsetAsync(e->flags.p, 0, 4 * sizeof(int), s0));
+  const double tol = e->opt.pivot_rel_tolerance;
+  if (tol > 0.0) {
+    BAE_HIP(e->pivot_floor.alloc(ld));
+    hipLaunchKernelGGL(k_pivot_floor, dim3((ld + 255) / 256), dim3(256), 0, s0, ld, ld, dA, tol, e->pivot_floor.p);
+    BAE_HIP(hipGetLastError());
+    const double* ptr = e->pivot_floor.p;
+    BAE_HIP(hipMemcpyAsync(e->flags.p + 2, &ptr, sizeof(ptr), hipMemcpyHostToDevice, s0));
+    BAE_HIP(hipStreamSynchronize(s0));  // `ptr` is a stack variable
+  }
+  return 0;
+}
+
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz) {
   const uint32_t nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
   const uint32_t KOUT = choose_kout(nblk);
@@ -1371,7 +1399,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     e->ev_panel.push_back(a);
     e->ev_bulk.push_back(b);
   }
-  BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), s0));
+  { const int src = setup_status_block(e, dA, ld, s0); if (src) return src; }
   if (rank == 0)  // factor packet of tile 0
     hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
                        colneg, e->flags.p, nz, nblk + 1u);
@@ -1487,7 +1515,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     e->ev_panel.push_back(a);
     e->ev_bulk.push_back(b);
   }
-  BAE_HIP(hipMemsetAsync(e->flags.p, 0, sizeof(int), s0));
+  { const int src = setup_status_block(e, dA, ld, s0); if (src) return src; }
   // factor packet of tile 0 (nothing to update: one workgroup)
   hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
                        colneg, e->flags.p, nz, nblk + 1u);

@@ -24,7 +24,8 @@ class Options(C.Structure):
                 ("use_robust_norm_for_inertial_residuals", C.c_int32),
                 ("use_triangular_matrices", C.c_int32), ("keep_reduced_system", C.c_int32),
                 ("gyro_sigma", C.c_double), ("accel_sigma", C.c_double),
-                ("gyro_bias_sigma", C.c_double), ("accel_bias_sigma", C.c_double)]
+                ("gyro_bias_sigma", C.c_double), ("accel_bias_sigma", C.c_double),
+                ("pivot_rel_tolerance", C.c_double)]
 
 
 class Errors(C.Structure):

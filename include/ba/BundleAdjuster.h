@@ -74,6 +74,10 @@ struct Options {  // reference BundleAdjuster.h:72-107, same names and defaults
   bool use_sparse_solver = true;  // accepted; the engine always factorises densely
   bool write_reduced_camera_matrix = false;
   bool keep_reduced_system = false;  // extension: keep S readable (GetReducedSystem taps) without writing files
+  // extension (0 = off = reference behaviour): pivots below this fraction of their original
+  // diagonal entry make Solve() report FactorizationError instead of applying an arbitrary step
+  // on a rank-deficient reduced system (include/ba_hip.h: ba_hip_options::pivot_rel_tolerance)
+  Scalar factorization_pivot_tolerance = 0;
   bool calculate_calibration_marginals = false;
   bool use_per_pose_cam_params = false;
   bool regularize_biases_in_batch = true;
@@ -558,6 +562,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
   o.keep_reduced_system = options_.write_reduced_camera_matrix || options_.keep_reduced_system;  // debug tap (reference :600-627)
   o.gyro_sigma = options_.gyro_sigma; o.accel_sigma = options_.accel_sigma;
   o.gyro_bias_sigma = options_.gyro_bias_sigma; o.accel_bias_sigma = options_.accel_bias_sigma;
+  o.pivot_rel_tolerance = options_.factorization_pivot_tolerance;
   if (!Check(ba_hip_set_options(engine_, &o), "ba_hip_set_options")) return false;
   if (structure_dirty_ || allreduce_ != engine_allreduce_ || allreduce_ctx_ != engine_allreduce_ctx_) {
     ba_hip_set_allreduce(engine_, allreduce_, allreduce_ctx_, rank_, nranks_);

@@ -28,6 +28,7 @@ typedef struct { /* ba::Options<double>, reference BundleAdjuster.h:72-107 */
   int32_t write_reduced_camera_matrix; /* 1: keep S readable through the taps; 2: also write s.txt / rhs.txt
                                           (the reference's dump, BundleAdjuster.cpp:600-606) */
   int32_t device;
+  double factorization_pivot_tolerance; /* extension, 0 = off: ba::Options::factorization_pivot_tolerance */
 } ba_options;
 
 typedef struct { /* ba::SolutionSummary<double> + GetErrors, reference :48-70,593-602 */

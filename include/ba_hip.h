@@ -49,6 +49,13 @@ typedef struct {
                                                      in-place factorisation (the reference's
                                                      write_reduced_camera_matrix, BundleAdjuster.cpp:600-627) */
   double gyro_sigma, accel_sigma, gyro_bias_sigma, accel_bias_sigma; /* BundleAdjuster.h:204-218 */
+  /* Rank-deficiency guard of the reduced solve (extension; 0 = off = the reference's behaviour).
+   * The reference reports FactorizationError only for a pivot that is EXACTLY zero (Eigen's LDLT /
+   * SimplicialLDLT info(), BundleAdjuster.cpp:756-759) — on a numerically singular S whether an
+   * elimination cancels to exactly zero is rounding-order luck.  With tol > 0 a pivot d_j with
+   * |d_j| < tol * |S_jj| (S_jj = the diagonal entry before elimination) raises
+   * BA_HIP_FACTORIZATION_ERROR instead of letting an arbitrary step through. */
+  double pivot_rel_tolerance;
 } ba_hip_options;
 
 /* The four error sums of EvaluateResiduals / BuildProblem (BundleAdjuster.cpp:144-274,
