@@ -49,6 +49,9 @@ struct Engine {
   hipStream_t stream2 = nullptr;   // bulk trailing updates of the factorisation (look-ahead)
   const double* A_cleared = nullptr;  // the allocation of A whose whole square has been zeroed once
   std::vector<hipEvent_t> ev_panel, ev_bulk;
+  hipEvent_t ev_imu_start = nullptr, ev_imu_done = nullptr;  // k_imu on stream2 (launch_imu_early)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;           // k_pose_blocks on stream2 (launch_gather_S)
+  bool imu_early_pending = false;
   bool own_stream = false;
   std::string err;
   ba_hip_options opt;
@@ -138,6 +141,7 @@ struct Engine {
   // ---- device: per-iteration
   DBuf<double> obs_e, obs_w;             // error for the median, robust weight
   DBuf<double> obs_jl;                   // [O][2*lm] sqrt(w) * dz_dlm (dogleg J_l * rhs_l)
+  DBuf<double> diag_blocks;              // [Pact][36] diagonal blocks of S (k_pose_blocks -> k_write_diag)
   DBuf<double> frow;                     // [n_rows][6] observation-major factor rows (structure.h)
   DBuf<double> scal;                     // scalars: [2*O] sqrt(w) r, then [L*lm] b_l, then one 0
   DBuf<double> lm_vinv, lm_bl;           // [L][lm*lm], [L][lm]
@@ -195,6 +199,7 @@ int launch_apply_step(Engine* e);                      // state[cur] -> state[1-
 int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out);
 int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out);
 int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard = true);
+int launch_imu_early(Engine* e, double c_huber_proj);
 int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs);
 int launch_posepose_eval(Engine* e, ba_hip_errors* errs);
 int launch_posepose_jrhs(Engine* e, double* out);

@@ -414,7 +414,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
-  REL(frow); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
+  REL(frow); REL(diag_blocks); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
   REL(gn_l); REL(step_p); REL(step_l); REL(invdiag); REL(partials); REL(scalars_out); REL(hist);
   REL(flags); REL(pivot_floor);
   REL(pose_active); REL(un_pose); REL(un_t); REL(un_cov_inv); REL(un_scale); REL(un_rot);
@@ -424,6 +424,8 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(pp_res_p2); REL(pp_ent);
 #undef REL
   comm_release(e);
+  if (e->ev_imu_done) { (void)hipEventDestroy(e->ev_imu_done); (void)hipEventDestroy(e->ev_imu_start); }
+  if (e->ev_fork) { (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
   for (hipEvent_t ev : e->ev_panel) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->ev_bulk) (void)hipEventDestroy(ev);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -692,6 +694,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
     c_huber = 1.2107 * std::sqrt(med);
   }
   e->timers.robust_weights = t_r.stop_ms();
+  if ((rc = launch_imu_early(e, c_huber))) return rc;  // overlaps the projection linearisation
   EventTimer t_l(e->stream);
   if ((rc = launch_landmarks(e, c_huber, e->opt.use_robust_norm_for_proj_residuals))) return rc;
   // proj_error_ of BuildProblem (BundleAdjuster.cpp:1386): sum of w |r|^2 with the new weights, one

@@ -282,6 +282,60 @@ static int sum_small(Engine* e, int n, const double* d_v, double* host) {
   return 0;
 }
 
+// The inertial residuals of BuildProblem (k_imu: one lane per residual, RK4 + 15x15 algebra — a few
+// milliseconds of latency-bound work on ~80 wavefronts) depend on the state and on the projection
+// Huber constant only, not on the projection linearisation: they run on the engine's second stream
+// concurrently with k_linearize / k_assemble_tiles and are joined by launch_posepose_build.
+int launch_imu_early(Engine* e, double c_huber_proj) {
+  const Problem& pb = e->prob;
+  const uint32_t nu = pb.num_unary, nb = pb.num_binary, ni = pb.num_imu;
+  if (ni == 0) return 0;
+  const double* state = e->pose_state[e->cur].p;
+  hipStream_t s2 = e->stream2;
+  if (!e->ev_imu_done) {
+    BAE_HIP(hipEventCreateWithFlags(&e->ev_imu_done, hipEventDisableTiming));
+    BAE_HIP(hipEventCreateWithFlags(&e->ev_imu_start, hipEventDisableTiming));
+  }
+  // everything the main stream has queued so far (state, uploads) comes first
+  BAE_HIP(hipEventRecord(e->ev_imu_start, e->stream));
+  BAE_HIP(hipStreamWaitEvent(s2, e->ev_imu_start, 0));
+  if (ni && e->imu_cov_once) {
+    // frozen integration covariances survive re-uploads of the same (append-only) residual list
+    if (ni < e->imu_cov_count) e->imu_cov_count = 0;  // the list was rebuilt: forget everything
+    if (e->imu_cov_done.n < ni) {
+      DBuf<double> fz; DBuf<uint8_t> dn;
+      BAE_HIP(fz.alloc((size_t)ni * 160));
+      BAE_HIP(dn.alloc(ni));
+      BAE_HIP(hipMemsetAsync(dn.p, 0, ni, s2));
+      if (e->imu_cov_count) {
+        BAE_HIP(hipMemcpyAsync(fz.p, e->imu_frozen.p, (size_t)e->imu_cov_count * 160 * sizeof(double),
+                               hipMemcpyDeviceToDevice, s2));
+        BAE_HIP(hipMemcpyAsync(dn.p, e->imu_cov_done.p, e->imu_cov_count, hipMemcpyDeviceToDevice, s2));
+      }
+      BAE_HIP(hipStreamSynchronize(s2));
+      e->imu_frozen.release(); e->imu_cov_done.release();
+      e->imu_frozen = fz; e->imu_cov_done = dn;
+    } else if (e->imu_cov_count == 0) {
+      BAE_HIP(hipMemsetAsync(e->imu_cov_done.p, 0, e->imu_cov_done.n, s2));
+    }
+    e->imu_cov_count = ni;
+  }
+  if (ni) {
+    e->prof_begin(e->ev_imu, s2);
+    hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, s2, (int)ni, 1, e->pose_dim,
+                       e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
+                       e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
+                       e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
+                       e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
+                       e->imu_frozen.p, e->imu_cov_done.p);
+    e->prof_end(e->ev_imu, s2);
+    BAE_HIP(hipGetLastError());
+  }
+  BAE_HIP(hipEventRecord(e->ev_imu_done, s2));
+  e->imu_early_pending = true;
+  return 0;
+}
+
 // BuildProblem part of the pose-pose residuals + scatter (after launch_gather_S).
 int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
   const Problem& pb = e->prob;
@@ -325,37 +379,11 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, nb, e->pp_err.p + nu, &errs->binary_error))) return rc;
-  if (ni && e->imu_cov_once) {
-    // frozen integration covariances survive re-uploads of the same (append-only) residual list
-    if (ni < e->imu_cov_count) e->imu_cov_count = 0;  // the list was rebuilt: forget everything
-    if (e->imu_cov_done.n < ni) {
-      DBuf<double> fz; DBuf<uint8_t> dn;
-      BAE_HIP(fz.alloc((size_t)ni * 160));
-      BAE_HIP(dn.alloc(ni));
-      BAE_HIP(hipMemsetAsync(dn.p, 0, ni, e->stream));
-      if (e->imu_cov_count) {
-        BAE_HIP(hipMemcpyAsync(fz.p, e->imu_frozen.p, (size_t)e->imu_cov_count * 160 * sizeof(double),
-                               hipMemcpyDeviceToDevice, e->stream));
-        BAE_HIP(hipMemcpyAsync(dn.p, e->imu_cov_done.p, e->imu_cov_count, hipMemcpyDeviceToDevice, e->stream));
-      }
-      BAE_HIP(hipStreamSynchronize(e->stream));
-      e->imu_frozen.release(); e->imu_cov_done.release();
-      e->imu_frozen = fz; e->imu_cov_done = dn;
-    } else if (e->imu_cov_count == 0) {
-      BAE_HIP(hipMemsetAsync(e->imu_cov_done.p, 0, e->imu_cov_done.n, e->stream));
-    }
-    e->imu_cov_count = ni;
-  }
-  if (ni) {
-    e->prof_begin(e->ev_imu);
-    hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 1, e->pose_dim,
-                       e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
-                       e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
-                       e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
-                       e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
-                       e->imu_frozen.p, e->imu_cov_done.p);
-    e->prof_end(e->ev_imu);
-    BAE_HIP(hipGetLastError());
+  // k_imu was started on the second stream right after the Huber constant was known
+  // (launch_imu_early): join it here
+  if (ni && e->imu_early_pending) {
+    BAE_HIP(hipStreamWaitEvent(e->stream, e->ev_imu_done, 0));
+    e->imu_early_pending = false;
   }
   if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
   if (e->st.n_pp_entries > 0) {

@@ -203,14 +203,14 @@ k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_order, const uin
 // terms after it the Schur part,
 //   S_ii += (-W V^-1)_k W_k^T,   rhs_sc_i += (-W V^-1)_k b_l             (:468-484)
 // Fixed reduction order (strided terms per thread, xor-butterfly per wave, waves in order): bitwise
-// reproducible.  Also writes the fixed entries of the block: 1e6 on masked parameters (shard 0 only,
-// so that the cross-shard sum leaves them exact).  Runs after k_assemble_tiles (stream order), which
-// zeroed the block's place.
+// reproducible.  The block goes to a side buffer (k_write_diag places it after the tile assembly):
+// the kernel depends on the factor rows only and runs on the engine's second stream, concurrently
+// with k_assemble_tiles.
 __global__ void __launch_bounds__(256)
 k_pose_blocks(const uint32_t* __restrict__ pose_ptr, const uint32_t* __restrict__ pose_mid,
               const uint32_t* __restrict__ pose_ent, const double* __restrict__ frow,
-              const double* __restrict__ scal, int D, uint32_t ld, const uint16_t* __restrict__ mask_opt,
-              int write_fixed, double* __restrict__ A, double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
+              const double* __restrict__ scal, int D, double* __restrict__ diag_out,
+              double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
   __shared__ double red[4][48];
   const uint32_t i = blockIdx.x;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -246,10 +246,7 @@ k_pose_blocks(const uint32_t* __restrict__ pose_ptr, const uint32_t* __restrict_
   if (tid < 48) {
     double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     if (tid < 36) {
-      const int rr = tid / 6, cc = tid - 6 * rr;
-      const uint16_t m = mask_opt[i];
-      if (rr == cc && (m & (1u << rr))) v = write_fixed ? 1e6 : 0.0;
-      A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] = v;
+      diag_out[(size_t)i * 36 + tid] = v;
     } else if (tid < 42) {
       rhs_p[(size_t)i * D + (tid - 36)] = v;
       red[0][tid] = v;  // (own slot: read back below by the thread that owns the Schur part)
@@ -259,9 +256,25 @@ k_pose_blocks(const uint32_t* __restrict__ pose_ptr, const uint32_t* __restrict_
   if (tid >= 42 && tid < 48) {
     const double sb = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     rhs_sc[(size_t)i * D + (tid - 42)] = red[0][tid - 6] + sb;
-  } else if (tid >= 48 && tid - 48 < D - 6) {
-    const uint16_t m = mask_opt[i];
-    const int k = 6 + (tid - 48);
+  }
+}
+
+// Places the diagonal blocks formed by k_pose_blocks into S — after k_assemble_tiles, which zeroed
+// their place — and writes the fixed entries: 1e6 on masked parameters (BundleAdjuster.cpp:587-598;
+// shard 0 only, so that the cross-shard sum leaves them exact).  One wavefront per pose.
+__global__ void __launch_bounds__(64)
+k_write_diag(const double* __restrict__ diag, int D, uint32_t ld, const uint16_t* __restrict__ mask_opt,
+             int write_fixed, double* __restrict__ A) {
+  const uint32_t i = blockIdx.x;
+  const int tid = threadIdx.x;
+  const uint16_t m = mask_opt[i];
+  if (tid < 36) {
+    const int rr = tid / 6, cc = tid - 6 * rr;
+    double v = diag[(size_t)i * 36 + tid];
+    if (rr == cc && (m & (1u << rr))) v = write_fixed ? 1e6 : 0.0;
+    A[((size_t)i * D + rr) * ld + (size_t)i * D + cc] = v;
+  } else if (tid - 36 < D - 6) {
+    const int k = 6 + (tid - 36);
     if ((m & (1u << k)) && write_fixed) A[((size_t)i * D + k) * ld + (size_t)i * D + k] = 1e6;
   }
 }
@@ -323,6 +336,25 @@ int launch_gather_S(Engine* e) {
     int rc = build_tile_order(e);
     if (rc) return rc;
   }
+  BAE_HIP(hipMemsetAsync(e->rhs_p.p, 0, e->rhs_p.bytes(), e->stream));
+  BAE_HIP(hipMemsetAsync(e->rhs_sc.p, 0, e->rhs_sc.bytes(), e->stream));
+  // fork: the per-pose blocks and right-hand sides (they read the factor rows only) on the second
+  // stream, concurrently with the tile assembly
+  if (st.Pact > 0) {
+    if (!e->ev_fork) {
+      BAE_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+      BAE_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    BAE_HIP(e->diag_blocks.alloc((size_t)st.Pact * 36));
+    BAE_HIP(hipEventRecord(e->ev_fork, e->stream));
+    BAE_HIP(hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+    e->prof_begin(e->ev_pose, e->stream2);
+    hipLaunchKernelGGL(k_pose_blocks, dim3(st.Pact), dim3(256), 0, e->stream2, e->pose_ptr.p, e->pose_mid.p,
+                       e->pose_ent.p, e->frow.p, e->scal.p, e->pose_dim, e->diag_blocks.p, e->rhs_p.p, e->rhs_sc.p);
+    e->prof_end(e->ev_pose, e->stream2);
+    BAE_HIP(hipGetLastError());
+    BAE_HIP(hipEventRecord(e->ev_join, e->stream2));
+  }
   e->prof_begin(e->ev_gather);
 #define BAE_ASM(V)                                                                                       \
   hipLaunchKernelGGL(k_assemble_tiles<V>, dim3(e->n_tile_order), dim3(256), 0, e->stream, nt, e->tile_order.p, \
@@ -343,15 +375,12 @@ int launch_gather_S(Engine* e) {
                        ld, e->A.p);
     BAE_HIP(hipGetLastError());
   }
-  BAE_HIP(hipMemsetAsync(e->rhs_p.p, 0, e->rhs_p.bytes(), e->stream));
-  BAE_HIP(hipMemsetAsync(e->rhs_sc.p, 0, e->rhs_sc.bytes(), e->stream));
   if (st.Pact > 0) {
+    // join: diagonal blocks into the assembled matrix
+    BAE_HIP(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     const uint16_t* masks = e->pose_mask.p + st.P;  // masks by opt id live after the by-id masks
-    e->prof_begin(e->ev_pose);
-    hipLaunchKernelGGL(k_pose_blocks, dim3(st.Pact), dim3(256), 0, e->stream, e->pose_ptr.p, e->pose_mid.p,
-                       e->pose_ent.p, e->frow.p, e->scal.p, e->pose_dim, ld, masks, write_fixed, e->A.p,
-                       e->rhs_p.p, e->rhs_sc.p);
-    e->prof_end(e->ev_pose);
+    hipLaunchKernelGGL(k_write_diag, dim3(st.Pact), dim3(64), 0, e->stream, (const double*)e->diag_blocks.p,
+                       e->pose_dim, ld, masks, write_fixed, e->A.p);
     BAE_HIP(hipGetLastError());
   }
   return 0;

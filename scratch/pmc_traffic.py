@@ -18,8 +18,8 @@ def demangle(name):
         try:
             d = subprocess.run([tool, name], capture_output=True, text=True).stdout.strip()
             if d:
-                d = d.split("(")[0]
-                return d.split(" ")[-1]
+                d = d.split("(")[0]          # drop the parameter list
+                return d[5:] if d.startswith("void ") else d   # template arguments may contain spaces
         except OSError:
             pass
     return name
