@@ -93,6 +93,7 @@ struct Engine {
   uint32_t n_tile_order = 0;
   uint64_t tile_order_version = ~0ull;
   int dbg_assemble_variant = 5;          // k_assemble_tiles<VAR> (ba_hip_debug_set key 1)
+  int dbg_host_structure = 0;            // 1: build the static lists on the host (structure.h) (key 5)
   int dbg_linearize_variant = 0;         // 0 LDS-staged factor rows, 1 direct stores (key 4)
   int dbg_tile_order = 0;                // 0 row-major tiles, 1 XCD-aware columns (key 2)
   int dbg_all_tiles = 0;                 // 1: assemble / zero every lower tile, not only the factor's pattern (key 3)
@@ -211,6 +212,8 @@ bool dist_solve_enabled(const Engine* e);
 int dist_reduce_scatter_S(Engine* e);
 int launch_imu_residual_vectors(Engine* e, double* d_r15);
 int build_tile_order(Engine* e);
+// the static lists built on the device (structure_dev.hip); same contents as structure.h's host builder
+int build_lists_device(Engine* e, const std::function<void(const char*)>& stage);
 // broadcast of `count` doubles from `root`, ordered into `s`: native RCCL enqueues without a host
 // round trip; with a caller-supplied hook the stream is drained first (hook contract)
 int dist_broadcast(Engine* e, double* buf, size_t count, int root, hipStream_t s);

@@ -109,14 +109,21 @@ static int build_structure(Engine* e) {
     t_stage = now;
   };
   const int LM = e->lm_dim;
-  {
+  // the static lists: on the device (structure_dev.hip) unless BA_HIP_HOST_STRUCTURE / debug key 5
+  // asks for the host builder (structure.h: the executable specification, same lists)
+  static const bool env_host = getenv("BA_HIP_HOST_STRUCTURE") != nullptr;
+  const bool host_build = env_host || e->dbg_host_structure;
+  if (host_build) {
     std::string err;
     if (!build_lists(pb, LM, e->pose_dim, st, err, stage)) {
       e->err = err;
       return -1;
     }
-    st.n_pp_entries = 0;
+  } else {
+    const int brc = build_lists_device(e, stage);
+    if (brc) return brc;
   }
+  st.n_pp_entries = 0;
   // ---- pose-pose residuals: slots [unary | binary | imu], scatter lists per active pose ------
   const uint32_t nu = pb.num_unary, nbn = pb.num_binary, ni = pb.num_imu, nres = nu + nbn + ni;
   std::vector<uint32_t> res_p1(nres), res_p2(nres, 0xffffffffu);
@@ -170,36 +177,38 @@ static int build_structure(Engine* e) {
   // ---- upload ------------------------------------------------------------------------------
   int rc;
 #define UP(buf, vec) if ((rc = upload(e, e->buf, vec))) return rc
-  UP(pose_opt, st.pose_opt); UP(lm_opt, st.lm_opt);
-  UP(lm_ref_pose, pb.lm_ref_pose); UP(lm_ref_cam, pb.lm_ref_cam);
-  UP(lm_ptr, st.lm_ptr); UP(obs_z, st.obs_z); UP(obs_pose, st.obs_pose); UP(obs_cam, st.obs_cam);
-  UP(obs_lm, st.obs_lm); UP(obs_rid, st.obs_rid); UP(obs_w0, st.obs_w0);
-  UP(tile_ptr, st.tile_ptr); UP(pose_ptr, st.pose_ptr); UP(pose_mid, st.pose_mid);
-  static_assert(sizeof(U2) == sizeof(uint2) && sizeof(U3) == 3 * sizeof(uint32_t), "list records are plain words");
-  BAE_HIP(e->pair_ent.alloc(std::max<size_t>(st.n_pair_entries, 1)));
-  if (st.n_pair_entries)
-    BAE_HIP(hipMemcpyAsync(e->pair_ent.p, st.pair_ent.get(), st.n_pair_entries * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
-  BAE_HIP(e->wave_rng.alloc(std::max<size_t>(st.n_chunks, 1)));
-  if (st.n_chunks)
-    BAE_HIP(hipMemcpyAsync(e->wave_rng.p, st.wave_rng.data(), (size_t)st.n_chunks * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
-  BAE_HIP(e->tile_ref.alloc(std::max<size_t>(st.n_tile_refs, 1)));
-  if (st.n_tile_refs)
-    BAE_HIP(hipMemcpyAsync(e->tile_ref.p, st.tile_ref.data(), st.n_tile_refs * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
-  BAE_HIP(e->pose_ent.alloc(std::max<size_t>(3 * st.n_pose_entries, 1)));
-  if (st.n_pose_entries)
-    BAE_HIP(hipMemcpyAsync(e->pose_ent.p, st.pose_ent.data(), st.n_pose_entries * sizeof(U3), hipMemcpyHostToDevice, e->stream));
-  BAE_HIP(hipStreamSynchronize(e->stream));
-  // the big host lists are only needed on the device from here on
-  st.pair_ent.reset();
-  std::vector<U2>().swap(st.tile_ref);
-  std::vector<U3>().swap(st.pose_ent);
-  std::vector<double>().swap(st.obs_z);
-  {
-    // conditioning residuals (BundleAdjuster.h:503-510): flags in sorted order
-    std::vector<uint8_t> is_cond(st.O, 0), cond_sorted(std::max<uint32_t>(st.O, 1), 0);
-    for (uint32_t id : pb.proj_cond) if (id < st.O) is_cond[id] = 1;
-    for (uint32_t s = 0; s < st.O; ++s) cond_sorted[s] = is_cond[st.obs_rid[s]];
-    UP(obs_cond, cond_sorted);
+  if (host_build) {
+    UP(pose_opt, st.pose_opt); UP(lm_opt, st.lm_opt);
+    UP(lm_ref_pose, pb.lm_ref_pose); UP(lm_ref_cam, pb.lm_ref_cam);
+    UP(lm_ptr, st.lm_ptr); UP(obs_z, st.obs_z); UP(obs_pose, st.obs_pose); UP(obs_cam, st.obs_cam);
+    UP(obs_lm, st.obs_lm); UP(obs_rid, st.obs_rid); UP(obs_w0, st.obs_w0);
+    UP(tile_ptr, st.tile_ptr); UP(pose_ptr, st.pose_ptr); UP(pose_mid, st.pose_mid);
+    static_assert(sizeof(U2) == sizeof(uint2) && sizeof(U3) == 3 * sizeof(uint32_t), "list records are plain words");
+    BAE_HIP(e->pair_ent.alloc(std::max<size_t>(st.n_pair_entries, 1)));
+    if (st.n_pair_entries)
+      BAE_HIP(hipMemcpyAsync(e->pair_ent.p, st.pair_ent.get(), st.n_pair_entries * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
+    BAE_HIP(e->wave_rng.alloc(std::max<size_t>(st.n_chunks, 1)));
+    if (st.n_chunks)
+      BAE_HIP(hipMemcpyAsync(e->wave_rng.p, st.wave_rng.data(), (size_t)st.n_chunks * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
+    BAE_HIP(e->tile_ref.alloc(std::max<size_t>(st.n_tile_refs, 1)));
+    if (st.n_tile_refs)
+      BAE_HIP(hipMemcpyAsync(e->tile_ref.p, st.tile_ref.data(), st.n_tile_refs * sizeof(uint2), hipMemcpyHostToDevice, e->stream));
+    BAE_HIP(e->pose_ent.alloc(std::max<size_t>(3 * st.n_pose_entries, 1)));
+    if (st.n_pose_entries)
+      BAE_HIP(hipMemcpyAsync(e->pose_ent.p, st.pose_ent.data(), st.n_pose_entries * sizeof(U3), hipMemcpyHostToDevice, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+    // the big host lists are only needed on the device from here on
+    st.pair_ent.reset();
+    std::vector<U2>().swap(st.tile_ref);
+    std::vector<U3>().swap(st.pose_ent);
+    std::vector<double>().swap(st.obs_z);
+    {
+      // conditioning residuals (BundleAdjuster.h:503-510): flags in sorted order
+      std::vector<uint8_t> is_cond(st.O, 0), cond_sorted(std::max<uint32_t>(st.O, 1), 0);
+      for (uint32_t id : pb.proj_cond) if (id < st.O) is_cond[id] = 1;
+      for (uint32_t s = 0; s < st.O; ++s) cond_sorted[s] = is_cond[st.obs_rid[s]];
+      UP(obs_cond, cond_sorted);
+    }
   }
   UP(pose_active, pb.pose_active);
   UP(un_pose, pb.un_pose); UP(un_t, pb.un_t); UP(un_cov_inv, pb.un_cov_inv); UP(un_rot, pb.un_rot);
@@ -265,8 +274,8 @@ static int build_structure(Engine* e) {
   const int LM1 = std::max(LM, 1);
   BAE_HIP(e->obs_e.alloc(O1)); BAE_HIP(e->obs_w.alloc(O1));
   BAE_HIP(e->obs_jl.alloc(O1 * 2 * LM1));
-  if (st.O) BAE_HIP(hipMemcpyAsync(e->obs_w.p, st.obs_w0.data(), (size_t)st.O * sizeof(double),
-                                   hipMemcpyHostToDevice, e->stream));
+  if (st.O && host_build) BAE_HIP(hipMemcpyAsync(e->obs_w.p, st.obs_w0.data(), (size_t)st.O * sizeof(double),
+                                                 hipMemcpyHostToDevice, e->stream));
   BAE_HIP(e->frow.alloc((size_t)st.n_rows * kRow));
   BAE_HIP(hipMemsetAsync(e->frow.p, 0, e->frow.bytes(), e->stream));
   BAE_HIP(e->scal.alloc(std::max<size_t>(st.n_scalars, 2 * O1 + L1 * LM1 + 1)));  // last: the zero scalar
@@ -1099,6 +1108,7 @@ int ba_hip_debug_set(ba_hip_engine* h, int key, int value) {
     case 1: e->dbg_assemble_variant = value; break;
     case 2: e->dbg_tile_order = value; e->tile_order_version = ~0ull; break;
     case 4: e->dbg_linearize_variant = value; break;
+    case 5: e->dbg_host_structure = value; e->finalized = false; break;
     case 3: e->dbg_all_tiles = value; e->tile_order_version = ~0ull; e->A_cleared = nullptr; break;
     default: return e->fail_msg("ba_hip_debug_set: unknown key");
   }

@@ -380,19 +380,23 @@ def main():
         # timed with HIP events on the stream it is launched on (the engine's second stream)
         syrk_tf = ks.syrk_flops / (ks.syrk_ms * 1e-3) / 1e12 if ks.syrk_ms > 0 else 0.0
         # HBM-bound kernels, algorithmic bytes per launch: every input read once,
-        # every output written once.  Linearisation: observation records, landmarks, poses in;
-        # factor rows + landmark blocks out.  Gather: the rank-1 term lists and the two 48-byte rows
-        # of every term in; the nonzero pose-pair blocks out (NOT the whole lower triangle: the
-        # zero-fill of the remaining tiles belongs to the clear kernel).
+        # every output written once.  k_linearize: observation records, landmarks, poses in; the
+        # observation-major factor rows, weights, scaled residuals and landmark blocks out.
+        # k_assemble_tiles: the rank-1 term lists, the two 48-byte rows of every term and the tile
+        # references in; every 64x64 tile of the FACTOR's pattern out (the zero-fill is part of it).
+        # k_pose_blocks: its term list (12 B) and two rows per term in.
         ell = lm_dim
-        b_landmarks = (O / world * 32 + (L / world) * 36 + P * 56 + (L / world) * 8 * (ell * ell + ell)
-                       + (stats.get("factor_rows", 0) * 48 if stats else 0))
+        R = 6 if lm_dim == 1 else 8
+        Ow, Lw = O / world, L / world
+        b_landmarks = (Ow * 32 + Lw * 36 + P * 56) + Ow * (R * 48 + 8 + 16 + 16 * ell) + Lw * ((96 if ell == 1 else 0) + 8 * (ell * ell + 2 * ell))
         if stats:
-            b_gather = stats["pair_entries"] * (8 + 96) + stats["pair_blocks"] * (288 + 12)
+            b_gather = stats["tiles_L"] * 32768.0 + stats["pair_entries"] * (8 + 96) + stats["tile_refs"] * 8
+            b_pose = stats["pose_entries"] * (12 + 96)
         else:
-            b_gather = 0.0
+            b_gather = b_pose = 0.0
         lm_gbs = b_landmarks * ks.landmarks_launches / (ks.landmarks_ms * 1e-3) / 1e9 if ks.landmarks_ms > 0 else 0.0
         ga_gbs = b_gather * ks.gather_launches / (ks.gather_ms * 1e-3) / 1e9 if ks.gather_ms > 0 else 0.0
+        po_gbs = b_pose * ks.pose_blocks_launches / (ks.pose_blocks_ms * 1e-3) / 1e9 if ks.pose_blocks_ms > 0 else 0.0
         # HBM-side traffic of the dominant kernel: not measurable live; taken from the committed
         # rocprofv3 --pmc passes of this same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
         # per launch), null if no summary exists for this configuration
@@ -403,6 +407,12 @@ def main():
         def pmc_bytes(name):
             try:
                 return pmc[name]["traffic_bytes_per_launch_corrected"]
+            except KeyError:
+                return None
+
+        def pmc_raw(name):
+            try:
+                return (pmc[name].get("FETCH_SIZE_KB_per_launch", 0.0) + pmc[name].get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
             except KeyError:
                 return None
         out = {
@@ -439,16 +449,25 @@ def main():
                          "launches": ks.syrk_launches,
                          "avg_launch_us": 1e3 * ks.syrk_ms / max(ks.syrk_launches, 1)},
             "hbm_kernels": {
-                # achieved_GBs: algorithmic bytes / time; pmc_traffic_bytes: what the kernel really
-                # moved, from the committed PMC passes
-                "k_landmarks": {"achieved_GBs": lm_gbs, "frac_of_8TBs": lm_gbs / HBM_PEAK_GBS,
+                # achieved_GBs: algorithmic bytes / live launch time; pmc_traffic_bytes: what the kernel
+                # really moved, from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE: the guide's
+                # gfx950 correction is calibrated for 16-B streaming reads and OVER-counts the 48-byte
+                # row gathers of the assembly kernels — pmc_raw_bytes is FETCH + WRITE as reported)
+                "k_linearize": {"achieved_GBs": lm_gbs, "frac_of_8TBs": lm_gbs / HBM_PEAK_GBS,
                                 "avg_launch_us": 1e3 * ks.landmarks_ms / max(ks.landmarks_launches, 1),
                                 "algorithmic_bytes": b_landmarks,
-                                "pmc_traffic_bytes": pmc_bytes("bae::k_landmarks<%d>" % lm_dim)},
-                "k_gather_S": {"achieved_GBs": ga_gbs, "frac_of_8TBs": ga_gbs / HBM_PEAK_GBS,
-                               "avg_launch_us": 1e3 * ks.gather_ms / max(ks.gather_launches, 1),
-                               "algorithmic_bytes": b_gather,
-                               "pmc_traffic_bytes": pmc_bytes("bae::k_gather_S")}},
+                                "pmc_traffic_bytes": pmc_bytes("bae::k_linearize<%d, 2, false, true>" % lm_dim),
+                                "pmc_raw_bytes": pmc_raw("bae::k_linearize<%d, 2, false, true>" % lm_dim)},
+                "k_assemble_tiles": {"achieved_GBs": ga_gbs, "frac_of_8TBs": ga_gbs / HBM_PEAK_GBS,
+                                     "avg_launch_us": 1e3 * ks.gather_ms / max(ks.gather_launches, 1),
+                                     "algorithmic_bytes": b_gather,
+                                     "pmc_traffic_bytes": pmc_bytes("bae::k_assemble_tiles<5>"),
+                                     "pmc_raw_bytes": pmc_raw("bae::k_assemble_tiles<5>")},
+                "k_pose_blocks": {"achieved_GBs": po_gbs, "frac_of_8TBs": po_gbs / HBM_PEAK_GBS,
+                                  "avg_launch_us": 1e3 * ks.pose_blocks_ms / max(ks.pose_blocks_launches, 1),
+                                  "algorithmic_bytes": b_pose, "concurrent_with": "k_assemble_tiles (second stream)",
+                                  "pmc_traffic_bytes": pmc_bytes("bae::k_pose_blocks"),
+                                  "pmc_raw_bytes": pmc_raw("bae::k_pose_blocks")}},
             "phase_ms_last_step": {k: round(v, 4) for k, v in timers.items()},
             "structure": stats,
             # one-off per graph: PCIe uploads of the scene + host-side structure build (gather

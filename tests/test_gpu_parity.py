@@ -1623,3 +1623,66 @@ def test_rank_deficiency_guard_reports_factorization_error(oracle_lib):
     fill(o, sc, active=pa)
     o.Solve(1)
     assert rel_err(b.delta_p(), o.delta_p()) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_structure_built_on_device_equals_host_build(lm_dim):
+    """ba_hip_finalize builds the static lists on the GPU (structure_dev.hip: radix sorts, scans,
+    generation kernels that mirror the host loops); the host builder (structure.h — checked on the
+    CPU against a dense Schur complement, tests/test_structure_lists.py) is the specification.  Same
+    scene through both: identical list sizes and, because every list has the same order, a bitwise
+    identical S, rhs and Gauss-Newton step.  Includes inactive poses / landmarks, duplicate
+    observations, observations from the reference pose and a landmark with more than 64 observations."""
+    sc = scene.make_scene(60, 300, 7, lm_dim=lm_dim, seed=123)
+    nsel = sc.obs_per_landmark + (1 if lm_dim == 1 else 0)
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    if lm_dim == 1:
+        keep[::nsel] = False
+    z, pose, lm = sc.obs_z[keep].copy(), sc.obs_pose[keep].copy(), sc.obs_lm[keep].copy()
+    rng = np.random.default_rng(4)
+    # duplicates, reference-pose observations (second camera semantics), a 150-observation landmark
+    dup = rng.choice(len(pose), 40, replace=False)
+    z, pose, lm = np.concatenate([z, z[dup] + 0.3]), np.concatenate([pose, pose[dup]]), np.concatenate([lm, lm[dup]])
+    big = rng.integers(0, sc.num_poses, 150).astype(pose.dtype)
+    zb = sc.obs_z[keep][:150] + rng.normal(0, 1.0, (150, 2))
+    z, pose, lm = np.concatenate([z, zb]), np.concatenate([pose, big]), np.concatenate([lm, np.full(150, 7, dtype=lm.dtype)])
+    perm = rng.permutation(len(pose))
+    z, pose, lm = z[perm], pose[perm], lm[perm]
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[[0, 9, 31]] = 0
+    la = np.ones(sc.num_landmarks, dtype=np.uint8)
+    la[[2, 50, 51]] = 0
+
+    def run(host):
+        eng = hipapi.Engine(lm_dim, 6)
+        o = hipapi.Options()
+        o.projection_outlier_threshold = 1.0
+        o.use_robust_norm_for_proj_residuals = 1
+        o.use_triangular_matrices = 1
+        o.keep_reduced_system = 1
+        eng.set_options(o)
+        eng.debug_set(5, 1 if host else 0)
+        eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+        eng.set_poses(sc.poses, is_active=pa)
+        eng.set_landmarks(sc.landmarks, sc.lm_ref_pose, is_active=la)
+        eng.set_projection_residuals(z, pose, lm)
+        eng.finalize()
+        eng.begin_solve()
+        eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+        e0 = eng.linearize()
+        S, (rhs, rhs_p, rhs_l) = eng.get_S(), eng.get_rhs()
+        rc = eng.solve_gn()
+        dp, dl = eng.get_delta_gn()
+        w = eng.get_proj_weights(len(pose))
+        st = eng.structure_stats()
+        eng.close()
+        return e0.proj_error, S, rhs, rhs_p, rhs_l, rc, dp, dl, w, st
+    h, d = run(True), run(False)
+    for k in ("observations", "incidences", "factor_rows", "pair_blocks", "pair_entries", "tile_refs", "pose_entries",
+              "linearize_waves", "tiles_S", "tiles_L"):
+        assert h[9][k] == d[9][k], k
+    assert h[0] == d[0] and h[5] == d[5]
+    for a, b in zip(h[1:5], d[1:5]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(h[6], d[6]) and np.array_equal(h[7], d[7]) and np.array_equal(h[8], d[8])
