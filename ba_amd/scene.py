@@ -92,8 +92,10 @@ def quat_exp(w):
     return np.concatenate([s * w, np.cos(half)], -1)
 
 
-def trajectory(P, radius=7.5, height=-1.5):
-    """Ground-truth poses on a closed curvy square; camera z along the direction of travel."""
+def trajectory(P, radius=7.5, height=-1.5, roll_amp=0.0):
+    """Ground-truth poses on a closed curvy square; camera z along the direction of travel.
+    roll_amp > 0 banks the frames about the direction of travel by roll_amp sin(5 s): a nearly
+    planar trajectory leaves a mount's translation along the turning axis unobservable."""
     s = np.arange(P) / float(P) * 2 * np.pi
     r = radius * (1.0 + 0.15 * np.cos(4 * s))
     pos = np.stack([r * np.cos(s), r * np.sin(s), height + 0.3 * np.sin(3 * s)], -1)
@@ -105,6 +107,10 @@ def trajectory(P, radius=7.5, height=-1.5):
     xc = np.cross(np.broadcast_to(down, zc.shape), zc)
     xc /= np.linalg.norm(xc, axis=-1, keepdims=True)
     yc = np.cross(zc, xc)
+    if roll_amp:
+        a = roll_amp * np.sin(5 * s)
+        xc, yc = (np.cos(a)[:, None] * xc + np.sin(a)[:, None] * yc,
+                  -np.sin(a)[:, None] * xc + np.cos(a)[:, None] * yc)
     R = np.stack([xc, yc, zc], -1)  # columns = camera axes in the world
     return np.concatenate([pos, rot_to_quat(R)], -1), vel
 
@@ -127,7 +133,7 @@ class Scene:
 
 def make_scene(num_poses, num_landmarks, obs_per_landmark=10, lm_dim=1, seed=0,
                pixel_sigma=1.5, outlier_frac=0.02, trans_sigma=0.05, rot_sigma=0.01,
-               depth_sigma=0.05, lm_range=None, window=None, chunk=200000, anchors=None):
+               depth_sigma=0.05, lm_range=None, window=None, chunk=200000, anchors=None, roll_amp=0.0):
     """Build a scene with exactly `obs_per_landmark` ACCEPTED projection residuals per landmark.
 
     lm_dim == 1 (inverse depth): the first chosen pose is the landmark's reference pose; its
@@ -143,7 +149,7 @@ def make_scene(num_poses, num_landmarks, obs_per_landmark=10, lm_dim=1, seed=0,
     lo, hi = (0, Ltot) if lm_range is None else lm_range
     L = hi - lo
     nsel = k + 1 if lm_dim == 1 else k
-    gt_poses, vel = trajectory(P)
+    gt_poses, vel = trajectory(P, roll_amp=roll_amp)
     if window is None:
         window = max(nsel + 2, min(P // 2 - 1, max(24, P // 8)))
     ncand = min(2 * window, max(4 * nsel, 48))
@@ -325,6 +331,44 @@ def relative_pose(a, b):
     """T_ab = T_wa^-1 T_wb for poses [t, q(xyzw)]."""
     ra, rb = quat_to_rot(np.asarray(a)[3:7]), quat_to_rot(np.asarray(b)[3:7])
     return np.concatenate([ra.T @ (np.asarray(b)[:3] - np.asarray(a)[:3]), rot_to_quat(ra.T @ rb)])
+
+
+def mount_camera(sc, t_vs):
+    """Re-express a Scene for a camera mounted at T_vs on the vehicle: the scene's poses are the
+    camera frames the observations were rendered from, so the vehicle poses are T_wc T_vs^-1
+    (ground truth and initial guess alike).  Returns sc; sc.gt_t_vs holds the mount."""
+    t_vs = np.asarray(t_vs, dtype=np.float64)
+    rv = quat_to_rot(t_vs[3:])
+    inv = np.concatenate([-rv.T @ t_vs[:3], t_vs[3:] * np.array([-1.0, -1.0, -1.0, 1.0])])
+    for arr in (sc.poses, sc.gt_poses):
+        for i in range(arr.shape[0]):
+            r = quat_to_rot(arr[i, 3:7])
+            arr[i, :3] = r @ inv[:3] + arr[i, :3]
+            arr[i, 3:7] = quat_mul(arr[i, 3:7], inv[3:])
+    sc.gt_t_vs = t_vs
+    return sc
+
+
+def _se3_mul(a, b):
+    return np.concatenate([quat_to_rot(a[3:7]) @ b[:3] + a[:3], quat_mul(a[3:7], b[3:7])])
+
+
+def _se3_apply(t, x3, w=1.0):
+    return quat_to_rot(t[3:7]) @ x3 + t[:3] * w
+
+
+def remount_landmarks(sc, t_vs_from, t_vs_to):
+    """World points of the landmarks for a different mount guess, keeping every landmark's
+    coordinates in the frame of its reference CAMERA (what a front end that unprojects z_ref with
+    its current T_vs guess hands to AddLandmark).  Returns the new (L, 4) array."""
+    out = sc.landmarks.copy()
+    for l in range(out.shape[0]):
+        ref = sc.poses[sc.lm_ref_pose[l]]
+        t_ws0 = _se3_mul(ref, np.asarray(t_vs_from, dtype=np.float64))
+        r0 = quat_to_rot(t_ws0[3:7])
+        xs = r0.T @ (out[l, :3] - t_ws0[:3] * out[l, 3])
+        out[l, :3] = _se3_apply(_se3_mul(ref, np.asarray(t_vs_to, dtype=np.float64)), xs, out[l, 3])
+    return out
 
 
 def populate(ba, sc, active=None, imu=False, priors=False, unary_every=100, seed=4):

@@ -77,6 +77,7 @@ struct ProjectionResidual {  // Types.h:282-298
   Mat<2, 3> dz_dlm;  // first LmDim columns used
   Mat<2, 6> dz_dx_meas, dz_dx_ref;
   Mat<2, 6> dz_dx_meas_raw, dz_dx_ref_raw;  // taps: before column masking
+  Mat<2, 6> dz_dtvs;  // Types.h:295, d residual / d T_vs (DoTvs instantiations only)
   double mahalanobis_distance = 0, weight = 1, orig_weight = 1;
   bool is_conditioning = false;
 };
@@ -111,7 +112,7 @@ struct ImuResidual {  // Types.h:300-321 (kResSize = PoseSize; 15x15 storage)
   double mahalanobis_distance = 0, weight = 1, orig_weight = 1;
 };
 
-struct Delta { std::vector<double> delta_p, delta_l; };  // BundleAdjuster.h:157-162
+struct Delta { std::vector<double> delta_p, delta_l, delta_k; };  // BundleAdjuster.h:157-162
 
 double sq_norm(const std::vector<double>& v) {
   double s = 0;
@@ -228,6 +229,13 @@ bool ldlt_solve_upper(uint32_t n, const double* s, const double* rhs, double* x)
 struct orc_ba {
   const int kLmDim, kPoseDim;
   const bool kVelInState, kBiasInState;
+  // BundleAdjuster.h:121-134: kCalibDim = CalibSize + (DoTvs ? 6 : 0), kTvsOffset = CalibSize.
+  // Only CalibSize = 0 is restated: the intrinsics columns need the camera model's
+  // dTransfer_dparams, and the reference's one use of them (its 5-parameter FOV camera) wipes them
+  // again when DoTvs is set (BundleAdjuster.cpp:1775 setZero() on the shared block).
+  const bool kTvsInCalib;
+  const int kCalibDim;
+  uint32_t num_total_params() const { return num_active_poses_ * kPoseDim + kCalibDim; }
   static const int kPrPoseDim = 6;
   int imu_res_size() const { return kPoseDim; }  // ImuResidualT<S, kPoseDim, kPoseDim>
 
@@ -267,16 +275,18 @@ struct orc_ba {
 
   // linear system of the current iteration
   std::vector<double> r_pr_, r_pp_, r_u_, r_i_;
-  std::vector<double> rhs_p_, rhs_l_, rhs_p_sc_;
-  std::vector<double> s_;                 // dense n x n, row-major
+  std::vector<double> rhs_p_, rhs_l_, rhs_p_sc_, rhs_k_;
+  std::vector<double> s_;                 // dense (n + kCalibDim)^2, row-major
+  std::vector<double> jt_l_j_kpr_;        // per active landmark LmDim x kCalibDim (:532-536)
   std::vector<double> vi_;                // per active landmark LmDim x LmDim
   // W = jt_pr * j_l: per active landmark, list of (pose opt_id, 6 x LmDim block)
   struct WBlock { uint32_t pose; Mat<6, 3> w; };
   std::vector<std::vector<WBlock>> w_;
   Delta last_delta_;
 
-  orc_ba(int lm, int pd)
-      : kLmDim(lm), kPoseDim(pd), kVelInState(pd >= 9), kBiasInState(pd >= 15) {
+  orc_ba(int lm, int pd, bool do_tvs = false)
+      : kLmDim(lm), kPoseDim(pd), kVelInState(pd >= 9), kBiasInState(pd >= 15),
+        kTvsInCalib(do_tvs), kCalibDim(do_tvs ? 6 : 0) {
     orc_default_options(&options_);
     memset(&summary_, 0, sizeof(summary_));
     memset(&timers_, 0, sizeof(timers_));
@@ -487,6 +497,13 @@ struct orc_ba {
                             dt1_t2_dt2(t_sw_m) * dexp_decoupled_dx(ref_pose.t_wp));
         } else {
           res.dz_dx_ref = Mat<2, 6>::Zero();
+        }
+        if (kTvsInCalib) {  // parallel_algos.h:120-131, total derivative of the transfer
+          const SE3 t_pm_pr = pose.t_wp.inverse() * ref_pose.t_wp;
+          res.dz_dtvs =
+              -(dt_dp_m * dt_x_dt(t_sw_m * t_ws_r, lm.x_s) *
+                (dt1_t2_dt2(t_vs_m.inverse()) * dt1_t2_dt2(t_pm_pr) * dexp_decoupled_dx(t_vs_r) +
+                 dt1_t2_dt1(t_vs_m.inverse(), t_pm_pr * t_vs_r) * dinv_exp_decoupled_dx(t_vs_m)));
         }
       }
     }
@@ -800,7 +817,7 @@ struct orc_ba {
   // use_triangular_matrices is off.
   template <int N>
   void s_add_pair(uint32_t bi, uint32_t bj, const Mat<N, N>& blk_ij, double sign) {
-    const uint32_t n = num_active_poses_ * kPoseDim;
+    const uint32_t n = num_total_params();
     const int lim = N < kPoseDim ? N : kPoseDim;
     auto put = [&](uint32_t ri, uint32_t cj, bool transpose) {
       for (int r = 0; r < lim; ++r)
@@ -827,9 +844,13 @@ struct orc_ba {
     const uint32_t n = num_poses * kPoseDim;
     const uint32_t num_lm = num_active_landmarks_;
     const int D = kPoseDim, L = kLmDim, RS = imu_res_size();
+    const int K = kCalibDim;
+    const uint32_t nt = n + K;  // :316-322
     rhs_p_.assign(n, 0.0);
-    rhs_p_sc_.assign(n, 0.0);
-    s_.assign((size_t)n * n, 0.0);
+    rhs_k_.assign(K, 0.0);
+    rhs_p_sc_.assign(nt, 0.0);
+    s_.assign((size_t)nt * nt, 0.0);
+    jt_l_j_kpr_.assign((size_t)num_lm * L * K, 0.0);
     vi_.assign((size_t)num_lm * L * L, 0.0);
     rhs_l_.assign((size_t)num_lm * L, 0.0);
     w_.assign(num_lm, std::vector<WBlock>());
@@ -930,7 +951,36 @@ struct orc_ba {
 
     // ---- :408-491  Schur complement ---------------------------------------
     t0 = now_s();
-    rhs_p_sc_ = rhs_p_;
+    std::copy(rhs_p_.begin(), rhs_p_.end(), rhs_p_sc_.begin());
+    // ---- :493-529  calibration border: S_kk = Jk^T Jk, S_pk = Jp^T Jk, rhs_k = Jk^T r.
+    // j_kpr_ holds sqrt(w) dz_dtvs of EVERY residual (:1769-1783); jt_pr only the blocks of
+    // listed residuals at active poses.
+    if (K > 0) {
+      for (const ProjectionResidual& res : proj_residuals_) {
+        const double w = res.weight, sw = std::sqrt(w);
+        for (int a = 0; a < K; ++a) {
+          for (int b = 0; b < K; ++b)
+            s_[(size_t)(n + a) * nt + n + b] +=
+                (res.dz_dtvs(0, a) * res.dz_dtvs(0, b) + res.dz_dtvs(1, a) * res.dz_dtvs(1, b)) * w;
+          rhs_k_[a] += res.dz_dtvs(0, a) * sw * r_pr_[res.residual_offset] +
+                       res.dz_dtvs(1, a) * sw * r_pr_[res.residual_offset + 1];
+        }
+        const bool listed = (res.x_meas_id != res.x_ref_id) || kLmDim != 1;
+        if (!listed || num_poses == 0) continue;
+        auto border = [&](const Pose& p, const Mat<2, 6>& jp) {
+          if (!p.is_active) return;
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < K; ++c) {
+              const double v = (jp(0, r) * res.dz_dtvs(0, c) + jp(1, r) * res.dz_dtvs(1, c)) * w;
+              s_[(size_t)(p.opt_id * D + r) * nt + n + c] += v;
+              if (!options_.use_triangular_matrices) s_[(size_t)(n + c) * nt + p.opt_id * D + r] += v;
+            }
+        };
+        border(poses_[res.x_meas_id], res.dz_dx_meas);
+        if (kLmDim == 1) border(poses_[res.x_ref_id], res.dz_dx_ref);
+      }
+      for (int a = 0; a < K; ++a) rhs_p_sc_[n + a] = rhs_k_[a];  // :526-528
+    }
     if (L > 0 && num_lm > 0) {
       for (Landmark& lm : landmarks_) {
         if (!lm.is_active) continue;
@@ -948,6 +998,15 @@ struct orc_ba {
           }
         }
         for (int a = 0; a < L; ++a) rhs_l_[lm.opt_id * L + a] = jtr_l[a];
+        if (K > 0)  // jt_kpr_ * j_l_ (:534-536), transposed: L x K per landmark
+          for (int id : lm.proj_residuals) {
+            const ProjectionResidual& res = proj_residuals_[id];
+            for (int a = 0; a < L; ++a)
+              for (int c = 0; c < K; ++c)
+                jt_l_j_kpr_[((size_t)lm.opt_id * L + a) * K + c] +=
+                    (res.dz_dlm(0, a) * res.dz_dtvs(0, c) + res.dz_dlm(1, a) * res.dz_dtvs(1, c)) *
+                    res.weight;
+          }
         // Quirk Q11 (:431-440)
         if (L == 1) {
           if (std::fabs(lm.jtj(0, 0)) < 1e-6) lm.jtj(0, 0) += 1e-6;
@@ -1012,11 +1071,43 @@ struct orc_ba {
                   for (int k = 0; k < L; ++k) s += wvi[a](r, k) * wl[b].w(c, k);
                   blk(r, c) = s;
                 }
-              const uint32_t nn = n;
+              const uint32_t nn = nt;
               for (int r = 0; r < 6; ++r)
                 for (int c = 0; c < 6; ++c)
                   s_[(size_t)(wl[a].pose * D + r) * nn + wl[b].pose * D + c] -= blk(r, c);
             }
+          // :538-556  S_pk -= (W V^-1) (Jl^T Jk)
+          for (size_t a = 0; a < wl.size() && K > 0; ++a)
+            for (int r = 0; r < 6; ++r)
+              for (int c = 0; c < K; ++c) {
+                double s = 0;
+                for (int k = 0; k < L; ++k)
+                  s += wvi[a](r, k) * jt_l_j_kpr_[((size_t)lm.opt_id * L + k) * K + c];
+                s_[(size_t)(wl[a].pose * D + r) * nt + n + c] -= s;
+                if (!options_.use_triangular_matrices)
+                  s_[(size_t)(n + c) * nt + wl[a].pose * D + r] -= s;
+              }
+        }
+      }
+      // :558-582  S_kk -= (Jk^T Jl) V^-1 (Jl^T Jk), rhs_k_sc = rhs_k - (Jk^T Jl) V^-1 b_l
+      if (K > 0) {
+        for (const Landmark& lm : landmarks_) {
+          if (!lm.is_active) continue;
+          const double* e = &jt_l_j_kpr_[(size_t)lm.opt_id * L * K];
+          for (int a = 0; a < K; ++a) {
+            double ev[3] = {0, 0, 0};  // row a of (Jk^T Jl) V^-1
+            for (int c = 0; c < L; ++c)
+              for (int k = 0; k < L; ++k)
+                ev[c] += e[k * K + a] * vi_[(size_t)lm.opt_id * L * L + k * L + c];
+            for (int b = 0; b < K; ++b) {
+              double s = 0;
+              for (int c = 0; c < L; ++c) s += ev[c] * e[c * K + b];
+              s_[(size_t)(n + a) * nt + n + b] -= s;
+            }
+            double s = 0;
+            for (int c = 0; c < L; ++c) s += ev[c] * rhs_l_[lm.opt_id * L + c];
+            rhs_p_sc_[n + a] -= s;
+          }
         }
       }
     }
@@ -1029,7 +1120,7 @@ struct orc_ba {
           for (uint32_t ii = 0; ii < pose.param_mask.size(); ++ii) {
             if (!pose.param_mask[ii]) {
               const size_t idx = (size_t)pose.opt_id * D + ii;
-              s_[idx * n + idx] = 1e6;
+              s_[idx * nt + idx] = 1e6;
             }
           }
         }
@@ -1042,11 +1133,16 @@ struct orc_ba {
     summary_.result = Success;
     const uint32_t n = rhs_p.size();
     delta.delta_p.assign(n, 0.0);
+    delta.delta_k.clear();
     if (n == 0) return;
     double t0 = now_s();
     const bool ok = ldlt_solve_upper(n, s_.data(), rhs_p.data(), delta.delta_p.data());
     timers_.solve += now_s() - t0;
     if (!ok) summary_.result = FactorizationError;
+    if (kCalibDim) {  // :766-769: the solution is [delta_p ; delta_k]
+      delta.delta_k.assign(delta.delta_p.end() - kCalibDim, delta.delta_p.end());
+      delta.delta_p.resize(n - kCalibDim);
+    }
   }
 
   // BundleAdjuster.cpp:709-744
@@ -1063,6 +1159,14 @@ struct orc_ba {
             for (int c = 0; c < L; ++c) {
               double s = 0;
               for (int r = 0; r < 6; ++r) s += b.w(r, c) * delta.delta_p[b.pose * D + r];
+              rhs_l_sc[l * L + c] -= s;
+            }
+        if (kCalibDim && !delta.delta_k.empty())  // :729-733
+          for (uint32_t l = 0; l < num_lm; ++l)
+            for (int c = 0; c < L; ++c) {
+              double s = 0;
+              for (int k = 0; k < kCalibDim; ++k)
+                s += jt_l_j_kpr_[((size_t)l * L + c) * kCalibDim + k] * delta.delta_k[k];
               rhs_l_sc[l * L + c] -= s;
             }
       }
@@ -1086,6 +1190,14 @@ struct orc_ba {
     summary_.delta_norm = std::sqrt(sq_norm(delta.delta_l)) + std::sqrt(sq_norm(delta.delta_p));
     const double coef = (do_rollback ? -1.0 : 1.0) * damping;
     const int D = kPoseDim, L = kLmDim;
+    // :72-83: the extrinsics of camera 0 take -delta_k; no `coef` here (neither the rollback sign
+    // nor the damping reaches T_vs), and the copies SolveInternal restores on a rejected step do
+    // not include the rig — a rejected step's T_vs update stays.
+    if (kTvsInCalib && !delta.delta_k.empty() && !rig_.empty()) {
+      Vec6 d;
+      for (int i = 0; i < 6; ++i) d[i] = -delta.delta_k[i];
+      rig_[0].t_vs = exp_decoupled(rig_[0].t_vs, d);
+    }
     for (Pose& pose : poses_) {
       if (pose.is_active) {
         const uint32_t p_offset = pose.opt_id * D;
@@ -1196,6 +1308,12 @@ struct orc_ba {
       double v[2] = {0, 0};
       const bool listed = (res.x_meas_id != res.x_ref_id) || kLmDim != 1;
       const double sw = std::sqrt(res.weight);
+      if (kCalibDim && num_active_poses_ > 0) {  // j_kp_rhs_k (:883-886): its own squared norm
+        double u[2] = {0, 0};
+        for (int r = 0; r < 2; ++r)
+          for (int c = 0; c < kCalibDim; ++c) u[r] += res.dz_dtvs(r, c) * sw * rhs_k_[c];
+        denom += u[0] * u[0] + u[1] * u[1];
+      }
       if (num_active_poses_ > 0 && listed) {
         const Pose& pm = poses_[res.x_meas_id];
         const Pose& pr = poses_[res.x_ref_id];
@@ -1252,12 +1370,16 @@ struct orc_ba {
   struct Snapshot {
     std::vector<SE3> t; std::vector<Vec3> v; std::vector<Vec6> b;
     std::vector<Vec4> xs, xw; std::vector<bool> reliable;
+    std::vector<std::vector<SE3>> t_sw;
   };
   // The reference deep-copies landmarks_, poses_, imu_ (:1022-1028, :1096-1102);
   // only the fields ApplyUpdate can change need restoring.
   Snapshot TakeSnapshot() const {
     Snapshot s;
-    for (const Pose& p : poses_) { s.t.push_back(p.t_wp); s.v.push_back(p.v_w); s.b.push_back(p.b); }
+    for (const Pose& p : poses_) {
+      s.t.push_back(p.t_wp); s.v.push_back(p.v_w); s.b.push_back(p.b);
+      if (kTvsInCalib) s.t_sw.push_back(p.t_sw);
+    }
     for (const Landmark& l : landmarks_) {
       s.xs.push_back(l.x_s); s.xw.push_back(l.x_w); s.reliable.push_back(l.is_reliable);
     }
@@ -1267,8 +1389,12 @@ struct orc_ba {
     for (size_t i = 0; i < poses_.size(); ++i) {
       poses_[i].t_wp = s.t[i]; poses_[i].v_w = s.v[i]; poses_[i].b = s.b[i];
       // the copies were taken before ApplyUpdate cleared t_sw; restoring the poses
-      // restores those caches too, which equals recomputing them from t_wp.
-      poses_[i].t_sw.clear();
+      // restores those caches too, which equals recomputing them from t_wp — unless T_vs is a
+      // parameter: the rig is not part of the copies, so the restored caches are those of the
+      // T_vs BEFORE the rejected step while rig_[0].t_vs keeps the step (a reference quirk the
+      // restatement keeps: the next evaluation reads the caches, the next Jacobian both).
+      if (kTvsInCalib) poses_[i].t_sw = s.t_sw[i];
+      else poses_[i].t_sw.clear();
     }
     for (size_t i = 0; i < landmarks_.size(); ++i) {
       landmarks_[i].x_s = s.xs[i]; landmarks_[i].x_w = s.xw[i];
@@ -1283,12 +1409,14 @@ struct orc_ba {
     Delta delta_sd, delta_dl, delta_gn;
     double proj_error, binary_error, unary_error, inertial_error;
     if (use_dogleg) {
-      const double numerator = sq_norm(rhs_p_) + sq_norm(rhs_l_);
+      const double numerator = sq_norm(rhs_p_) + sq_norm(rhs_l_) + sq_norm(rhs_k_);
       const double denominator = SteepestDescentDenominator();
       const double factor = numerator / denominator;
-      delta_sd.delta_p = rhs_p_; delta_sd.delta_l = rhs_l_;
+      delta_sd.delta_p = rhs_p_; delta_sd.delta_l = rhs_l_; delta_sd.delta_k = rhs_k_;
       for (double& x : delta_sd.delta_p) x *= factor;
       for (double& x : delta_sd.delta_l) x *= factor;
+      for (double& x : delta_sd.delta_k) x *= factor;
+      // :927-929: the steepest-descent norm leaves delta_k out
       const double delta_sd_norm =
           std::sqrt(sq_norm(delta_sd.delta_p) + sq_norm(delta_sd.delta_l));
       uint32_t iteration_count = 0;
@@ -1300,6 +1428,7 @@ struct orc_ba {
           delta_dl = delta_sd;
           for (double& x : delta_dl.delta_p) x *= f;
           for (double& x : delta_dl.delta_l) x *= f;
+          for (double& x : delta_dl.delta_k) x *= f;
         } else {
           if (!gn_computed) {
             if (num_active_poses_ > 0) {
@@ -1311,8 +1440,10 @@ struct orc_ba {
                              delta_gn.delta_l);
             gn_computed = true;
           }
-          const double delta_gn_norm =
-              std::sqrt(sq_norm(delta_gn.delta_p) + sq_norm(delta_gn.delta_l));
+          if (delta_gn.delta_k.size() != delta_sd.delta_k.size())  // no active pose: no GN step
+            delta_gn.delta_k.assign(delta_sd.delta_k.size(), 0.0);
+          const double delta_gn_norm = std::sqrt(sq_norm(delta_gn.delta_p) + sq_norm(delta_gn.delta_k) +
+                                                 sq_norm(delta_gn.delta_l));
           const bool delta_gn_good = !std::isnan(delta_gn_norm) && !std::isinf(delta_gn_norm);
           if (delta_gn_good && trust_region_size_ == kTrustRegionAuto)
             trust_region_size_ = delta_gn_norm;
@@ -1322,12 +1453,15 @@ struct orc_ba {
             Delta diff = delta_gn;
             for (size_t i = 0; i < diff.delta_p.size(); ++i) diff.delta_p[i] -= delta_sd.delta_p[i];
             for (size_t i = 0; i < diff.delta_l.size(); ++i) diff.delta_l[i] -= delta_sd.delta_l[i];
-            const double a = sq_norm(diff.delta_p) + sq_norm(diff.delta_l);
+            for (size_t i = 0; i < diff.delta_k.size(); ++i) diff.delta_k[i] -= delta_sd.delta_k[i];
+            const double a = sq_norm(diff.delta_p) + sq_norm(diff.delta_l) + sq_norm(diff.delta_k);
             double dot = 0;
             for (size_t i = 0; i < diff.delta_p.size(); ++i) dot += diff.delta_p[i] * delta_sd.delta_p[i];
+            for (size_t i = 0; i < diff.delta_k.size(); ++i) dot += diff.delta_k[i] * delta_sd.delta_k[i];
             for (size_t i = 0; i < diff.delta_l.size(); ++i) dot += diff.delta_l[i] * delta_sd.delta_l[i];
             const double b = 2 * dot;
-            const double c = (sq_norm(delta_sd.delta_p) + sq_norm(delta_sd.delta_l)) -
+            const double c = (sq_norm(delta_sd.delta_p) + sq_norm(delta_sd.delta_k) +
+                              sq_norm(delta_sd.delta_l)) -
                              trust_region_size_ * trust_region_size_;
             double beta = 0;
             // Quirk Q3 (:1006-1013): -(b*b), not -b.
@@ -1336,6 +1470,7 @@ struct orc_ba {
             delta_dl = delta_sd;
             for (size_t i = 0; i < diff.delta_p.size(); ++i) delta_dl.delta_p[i] += beta * diff.delta_p[i];
             for (size_t i = 0; i < diff.delta_l.size(); ++i) delta_dl.delta_l[i] += beta * diff.delta_l[i];
+            for (size_t i = 0; i < diff.delta_k.size(); ++i) delta_dl.delta_k[i] += beta * diff.delta_k[i];
           }
         }
         const Snapshot snap = TakeSnapshot();
@@ -1366,6 +1501,7 @@ struct orc_ba {
       const Snapshot snap = TakeSnapshot();
       GetLandmarkDelta(delta, num_active_poses_, num_active_landmarks_, delta.delta_l);
       for (double& x : delta.delta_l) x *= gn_damping;
+      for (double& x : delta.delta_k) x *= gn_damping;
       for (double& x : delta.delta_p) x *= gn_damping;
       EvaluateResiduals(&proj_error, &binary_error, &unary_error, &inertial_error);
       const double prev_error = proj_error + inertial_error + binary_error + unary_error;
@@ -1466,10 +1602,13 @@ void orc_default_options(orc_options* o) {
   o->use_robust_norm_for_proj_residuals = 1; o->use_robust_norm_for_inertial_residuals = 0;
 }
 
-orc_ba* orc_create(int lm_dim, int pose_dim) {
+orc_ba* orc_create(int lm_dim, int pose_dim) { return orc_create_calib(lm_dim, pose_dim, 0, 0); }
+orc_ba* orc_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs) {
   if (!(lm_dim == 0 || lm_dim == 1 || lm_dim == 3)) return nullptr;
   if (!(pose_dim == 6 || pose_dim == 9 || pose_dim == 15)) return nullptr;
-  return new orc_ba(lm_dim, pose_dim);
+  if (calib_size != 0) return nullptr;           // intrinsics columns: not restated (see orc_ba)
+  if (do_tvs && lm_dim != 1) return nullptr;     // dz_dtvs exists for LmSize 1 only (parallel_algos.h:102)
+  return new orc_ba(lm_dim, pose_dim, do_tvs != 0);
 }
 void orc_destroy(orc_ba* h) { delete h; }
 void orc_init(orc_ba* h, const orc_options* o) { h->Init(*o); }
@@ -1611,6 +1750,16 @@ void orc_get_delta_p(const orc_ba* h, double* d) {
 }
 void orc_get_delta_l(const orc_ba* h, double* d) {
   memcpy(d, h->last_delta_.delta_l.data(), h->last_delta_.delta_l.size() * 8);
+}
+uint32_t orc_num_calib_params(const orc_ba* h) { return h->kCalibDim; }
+void orc_get_delta_k(const orc_ba* h, double* d) {
+  memcpy(d, h->last_delta_.delta_k.data(), h->last_delta_.delta_k.size() * 8);
+}
+void orc_get_rhs_k(const orc_ba* h, double* r) { memcpy(r, h->rhs_k_.data(), h->rhs_k_.size() * 8); }
+void orc_get_camera_pose(const orc_ba* h, uint32_t cam_id, double t_vs[7]) { se3_to7(h->rig_[cam_id].t_vs, t_vs); }
+void orc_get_proj_tvs_jacobians(const orc_ba* h, double* j_tvs) {
+  for (size_t i = 0; i < h->proj_residuals_.size(); ++i)
+    memcpy(j_tvs + 12 * i, h->proj_residuals_[i].dz_dtvs.a, 12 * 8);
 }
 void orc_get_proj_weights(const orc_ba* h, double* w) {
   for (size_t i = 0; i < h->proj_residuals_.size(); ++i) w[i] = h->proj_residuals_[i].weight;

@@ -51,6 +51,11 @@ typedef struct {
 void orc_default_options(orc_options* o);
 
 orc_ba* orc_create(int lm_dim, int pose_dim);
+/* BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs> (BundleAdjuster.h:110-134).  Restated:
+   calib_size = 0 with do_tvs = 0 | 1 (LmSize 1 only); anything else returns NULL.  With do_tvs the
+   reduced system is (n + 6) x (n + 6): the last six unknowns are the decoupled update of the
+   extrinsics T_vs of camera 0 (BundleAdjuster.cpp:72-83, 493-583). */
+orc_ba* orc_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs);
 void orc_destroy(orc_ba* h);
 void orc_init(orc_ba* h, const orc_options* o);
 void orc_set_gravity(orc_ba* h, const double g[3]);
@@ -118,6 +123,11 @@ void orc_get_rhs_p(const orc_ba* h, double* rhs_n);      /* rhs_p_ (before Schur
 void orc_get_rhs_l(const orc_ba* h, double* rhs_l);
 void orc_get_delta_p(const orc_ba* h, double* d);        /* applied pose step */
 void orc_get_delta_l(const orc_ba* h, double* d);
+uint32_t orc_num_calib_params(const orc_ba* h);          /* kCalibDim: orc_get_S / orc_get_rhs are (n + kCalibDim) wide */
+void orc_get_delta_k(const orc_ba* h, double* d);        /* applied calibration step */
+void orc_get_rhs_k(const orc_ba* h, double* r);          /* rhs_k_ (before Schur) */
+void orc_get_camera_pose(const orc_ba* h, uint32_t cam_id, double t_vs[7]);
+void orc_get_proj_tvs_jacobians(const orc_ba* h, double* j_tvs); /* dz_dtvs 2x6 per residual id */
 void orc_get_proj_weights(const orc_ba* h, double* w);   /* per residual id */
 void orc_get_proj_residuals(const orc_ba* h, double* r2);/* per residual id, 2 each */
 void orc_get_imu_residuals(const orc_ba* h, double* r15);/* ImuResidualT::residual, 15 each (first PoseSize used) */

@@ -79,11 +79,13 @@ def lib():
         L = _lib
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int]
+        L.orc_create_calib.restype = C.c_void_p
+        L.orc_create_calib.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         for name in ("orc_add_camera", "orc_add_pose", "orc_add_landmark",
                      "orc_add_projection_residual", "orc_add_unary_constraint",
                      "orc_add_binary_constraint", "orc_add_imu_residual", "orc_num_poses",
                      "orc_num_landmarks", "orc_num_proj_residuals", "orc_num_pose_params",
-                     "orc_num_lm_params"):
+                     "orc_num_lm_params", "orc_num_calib_params"):
             getattr(L, name).restype = C.c_uint32
         L.orc_landmark_outlier_ratio.restype = C.c_double
     return _lib
@@ -104,14 +106,14 @@ def default_options():
 
 
 class OracleBundleAdjuster:
-    """CPU restatement of ba::BundleAdjuster<double, lm_dim, pose_dim, 0>."""
+    """CPU restatement of ba::BundleAdjuster<double, lm_dim, pose_dim, 0, do_tvs>."""
 
-    def __init__(self, lm_dim=1, pose_dim=6):
+    def __init__(self, lm_dim=1, pose_dim=6, do_tvs=False):
         self.L = lib()
-        self.lm_dim, self.pose_dim = lm_dim, pose_dim
-        self.h = C.c_void_p(self.L.orc_create(lm_dim, pose_dim))
+        self.lm_dim, self.pose_dim, self.do_tvs = lm_dim, pose_dim, bool(do_tvs)
+        self.h = C.c_void_p(self.L.orc_create_calib(lm_dim, pose_dim, 0, int(do_tvs)))
         if not self.h:
-            raise ValueError("unsupported (lm_dim, pose_dim)")
+            raise ValueError("unsupported (lm_dim, pose_dim, do_tvs)")
 
     def __del__(self):
         try:
@@ -279,8 +281,28 @@ class OracleBundleAdjuster:
     def num_lm_params(self):
         return self.L.orc_num_lm_params(self.h)
 
+    def num_calib_params(self):
+        return self.L.orc_num_calib_params(self.h)
+
+    def delta_k(self):
+        return self._vec(self.L.orc_get_delta_k, self.num_calib_params())
+
+    def rhs_k(self):
+        return self._vec(self.L.orc_get_rhs_k, self.num_calib_params())
+
+    def camera_pose(self, cam_id=0):
+        t = np.empty(7)
+        self.L.orc_get_camera_pose(self.h, int(cam_id), _dp(t))
+        return t
+
+    def proj_tvs_jacobians(self):
+        j = np.empty((self.GetNumProjResiduals(), 2, 6))
+        self.L.orc_get_proj_tvs_jacobians(self.h, _dp(j))
+        return j
+
     def S(self):
-        n = self.num_pose_params()
+        """(n + kCalibDim)^2: the pose block, then the calibration border."""
+        n = self.num_pose_params() + self.num_calib_params()
         s = np.empty((n, n))
         self.L.orc_get_S(self.h, _dp(s))
         return s
@@ -291,7 +313,7 @@ class OracleBundleAdjuster:
         return v
 
     def rhs(self):
-        return self._vec(self.L.orc_get_rhs, self.num_pose_params())
+        return self._vec(self.L.orc_get_rhs, self.num_pose_params() + self.num_calib_params())
 
     def rhs_p(self):
         return self._vec(self.L.orc_get_rhs_p, self.num_pose_params())

@@ -138,3 +138,97 @@ def test_gn_iterations_converge(oracle_lib):
     assert (r ** 2).sum() / len(r) < 8.0
     p, _, _ = ba.poses()
     assert np.abs(p[:, :3] - sc.gt_poses[:, :3]).max() < 0.5
+
+
+T_VS_MOUNT = np.concatenate([[0.05, -0.02, 0.1], scene.quat_exp(np.array([0.02, -0.03, 0.01]))])
+
+
+def _calib_oracle(po, sc, t_vs, pose_active, **opts):
+    ba = po.OracleBundleAdjuster(1, 6, do_tvs=True)
+    ba.Init(gn_options(po, **opts))
+    ba.AddCamera(sc.cam_params, t_vs)
+    ba.add_poses(sc.poses, is_active=pose_active.astype(np.uint8))
+    ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    return ba
+
+
+@pytest.mark.parametrize("triangular", [1, 0])
+def test_calibration_border_matches_dense_algebra(oracle_lib, triangular):
+    """DoTvs: the (n + 6)^2 system of BundleAdjuster.cpp:493-583 equals the Schur complement of
+    the dense normal equations over [poses | T_vs | landmarks] built from the same Jacobians."""
+    po = oracle_lib
+    sc = scene.mount_camera(scene.make_scene(30, 60, 5, lm_dim=1, seed=7), T_VS_MOUNT)
+    P = sc.num_poses
+    pose_active = np.ones(P, dtype=bool)
+    pose_active[[0, 3, 4, 15, 17]] = False
+    ba = _calib_oracle(po, sc, T_VS_MOUNT, pose_active, apply_results=0,
+                       use_triangular_matrices=triangular)
+    ba.Solve(1)
+    jm, jr, jl = ba.proj_jacobians()
+    jk = ba.proj_tvs_jacobians()
+    w, r = ba.proj_weights(), ba.proj_residuals()
+    acc = accepted_obs(sc)
+    opt = -np.ones(P, dtype=int)
+    opt[pose_active] = np.arange(pose_active.sum())
+    n, K, nl = 6 * pose_active.sum(), 6, sc.num_landmarks
+    J = np.zeros((2 * len(acc), n + K + nl))
+    rr = np.zeros(2 * len(acc))
+    for i, (m, ref, l) in enumerate(acc):
+        sw = np.sqrt(w[i])
+        if opt[m] >= 0:
+            J[2 * i:2 * i + 2, 6 * opt[m]:6 * opt[m] + 6] += sw * jm[i]
+        if opt[ref] >= 0:
+            J[2 * i:2 * i + 2, 6 * opt[ref]:6 * opt[ref] + 6] += sw * jr[i]
+        J[2 * i:2 * i + 2, n:n + K] = sw * jk[i]
+        J[2 * i:2 * i + 2, n + K + l] = sw * jl[i][:, 0]
+        rr[2 * i:2 * i + 2] = sw * r[i]
+    H, g = J.T @ J, J.T @ rr
+    m = n + K
+    Vi = np.diag(1.0 / np.diag(H[m:, m:]))
+    S = H[:m, :m] - H[:m, m:] @ Vi @ H[m:, :m]
+    rhs = g[:m] - H[:m, m:] @ Vi @ g[m:]
+    So = ba.S()
+    assert So.shape == (m, m)
+    if triangular:
+        keep = np.ones((m, m), dtype=bool)
+        keep[:n, :n] = np.kron(np.triu(np.ones((n // 6, n // 6))), np.ones((6, 6))) > 0
+        keep[n:, :n] = False  # S_kp is not formed (BundleAdjuster.cpp:515-518)
+        assert np.all(So[~keep] == 0)
+        assert rel_err(So[keep], S[keep]) < 1e-11
+    else:
+        assert rel_err(So, S) < 1e-11
+    assert np.abs(So[:n, n:]).max() > 1 and np.abs(So[n:, n:]).max() > 1
+    assert rel_err(ba.rhs(), rhs) < 1e-10
+    assert rel_err(ba.rhs_k(), g[n:m]) < 1e-11
+    assert np.linalg.cond(S) < 1e12
+    d = np.linalg.solve(S, rhs)
+    assert rel_err(ba.delta_p(), d[:n]) < 1e-7
+    assert rel_err(ba.delta_k(), d[n:]) < 1e-7
+    dl = Vi @ (g[m:] - H[m:, :m] @ d)
+    assert rel_err(ba.delta_l(), dl) < 1e-7
+
+
+@pytest.mark.parametrize("dogleg", [0, 1])
+def test_extrinsics_are_recovered(oracle_lib, dogleg):
+    """A wrong initial T_vs converges to the mount the observations were rendered with when a
+    third of the vehicle poses is held at ground truth (ApplyUpdate, BundleAdjuster.cpp:72-83).
+    The trajectory is banked (roll_amp): on a planar one the mount's translation along the
+    turning axis is a gauge freedom."""
+    po = oracle_lib
+    sc = scene.mount_camera(scene.make_scene(40, 160, 8, lm_dim=1, seed=2, outlier_frac=0.0,
+                                             pixel_sigma=0.3, roll_amp=0.6), T_VS_MOUNT)
+    pose_active = np.ones(sc.num_poses, dtype=bool)
+    pose_active[::3] = False
+    sc.poses[::3] = sc.gt_poses[::3]
+    t0 = po.exp_decoupled(T_VS_MOUNT, np.array([0.06, -0.05, 0.05, 0.02, -0.03, 0.02]))
+    sc.landmarks = scene.remount_landmarks(sc, T_VS_MOUNT, t0)
+    ba = _calib_oracle(po, sc, t0, pose_active, use_dogleg=dogleg)
+    err0 = np.linalg.norm(po.log_decoupled(t0, T_VS_MOUNT))
+    errs = []
+    for _ in range(10):
+        ba.Solve(1)
+        errs.append(ba.summary().proj_error)
+    err = np.linalg.norm(po.log_decoupled(ba.camera_pose(0), T_VS_MOUNT))
+    assert err < 0.2 * err0, (err0, err)
+    assert errs[-1] < 0.5 * errs[0]

@@ -128,6 +128,48 @@ def test_projection_pose_jacobians(oracle_lib, lm_dim, per_pose_cam):
     assert np.abs(jm).max() > 10  # the check is not vacuous
 
 
+def test_projection_extrinsics_jacobian(oracle_lib):
+    """dz_dtvs of the DoTvs instantiations (parallel_algos.h:120-131): the derivative of the
+    residual w.r.t. the decoupled update of T_vs, with every landmark's sensor-frame x_s held
+    fixed (x_s, not x_w, is what the inverse-depth parameterisation keeps)."""
+    po = oracle_lib
+    sc = scene.make_scene(24, 12, 4, lm_dim=1, seed=8)
+    t_vs = np.concatenate([[0.05, -0.02, 0.1], scene.quat_exp(np.array([0.02, -0.03, 0.01]))])
+
+    def run(tv):
+        # x_w such that T_sw(ref; tv) x_w equals T_sw(ref; t_vs) x_w0 for every landmark
+        lm = sc.landmarks.copy()
+        for l in range(sc.num_landmarks):
+            ref = sc.poses[sc.lm_ref_pose[l]]
+            t_sw0 = po.se3_inv(po.se3_mul(ref, t_vs))
+            t_ws1 = po.se3_mul(ref, tv)
+            xs = scene.quat_to_rot(t_sw0[3:]) @ lm[l, :3] + t_sw0[:3] * lm[l, 3]
+            lm[l, :3] = scene.quat_to_rot(t_ws1[3:]) @ xs + t_ws1[:3] * lm[l, 3]
+        ba = po.OracleBundleAdjuster(1, 6, do_tvs=True)
+        o = po.default_options()
+        o.use_dogleg = 0
+        o.apply_results = 0
+        o.use_robust_norm_for_proj_residuals = 0
+        ba.Init(o)
+        ba.AddCamera(sc.cam_params, tv)
+        ba.add_poses(sc.poses)
+        ba.add_landmarks(lm, sc.lm_ref_pose)
+        ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+        ba.Solve(1)
+        return ba
+
+    jk = run(t_vs).proj_tvs_jacobians()
+    fd = np.zeros_like(jk)
+    for j in range(6):
+        d = np.zeros(6)
+        d[j] = EPS
+        fd[:, :, j] = (run(po.exp_decoupled(t_vs, d)).proj_residuals() -
+                       run(po.exp_decoupled(t_vs, -d)).proj_residuals()) / (2 * EPS)
+    assert np.abs(jk).max() > 10
+    for rid in range(jk.shape[0]):
+        assert np.linalg.norm(jk[rid] - fd[rid]) < NORM_THRESHOLD * max(1.0, np.abs(jk[rid]).max()), rid
+
+
 @pytest.mark.parametrize("lm_dim", [1, 3])
 def test_projection_landmark_jacobian(oracle_lib, lm_dim):
     po = oracle_lib
