@@ -64,7 +64,8 @@ SYMBOLS = [
     "ba_adjuster_is_landmark_reliable", "ba_adjuster_landmark_outlier_ratio",
     "ba_adjuster_get_projection_residual", "ba_adjuster_get_imu_residual",
     "ba_adjuster_get_summary", "ba_adjuster_get_cond_errors", "ba_adjuster_get_timers", "ba_adjuster_engine",
-    "ba_adjuster_set_allreduce",
+    "ba_adjuster_set_allreduce", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
+    "ba_adjuster_get_last_calib_step",
 ]
 
 _lib = None
@@ -79,6 +80,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         L = _lib
         L.ba_adjuster_create.restype = C.c_void_p
+        L.ba_adjuster_create_calib.restype = C.c_void_p
         L.ba_adjuster_engine.restype = C.c_void_p
         L.ba_adjuster_landmark_outlier_ratio.restype = C.c_double
         for n in ("ba_adjuster_add_camera", "ba_adjuster_add_pose", "ba_adjuster_add_landmark",
@@ -118,14 +120,14 @@ class _EngineView(hipapi.Engine):
 
 
 class BundleAdjuster:
-    """ba::BundleAdjuster<double, lm_dim, pose_dim, 0> on the MI355X engine."""
+    """ba::BundleAdjuster<double, lm_dim, pose_dim, 0, do_tvs> on the MI355X engine."""
 
-    def __init__(self, lm_dim=1, pose_dim=6):
+    def __init__(self, lm_dim=1, pose_dim=6, do_tvs=False):
         self.L = lib()
-        self.lm_dim, self.pose_dim = lm_dim, pose_dim
-        self.h = C.c_void_p(self.L.ba_adjuster_create(lm_dim, pose_dim))
+        self.lm_dim, self.pose_dim, self.do_tvs = lm_dim, pose_dim, bool(do_tvs)
+        self.h = C.c_void_p(self.L.ba_adjuster_create_calib(lm_dim, pose_dim, 0, int(do_tvs)))
         if not self.h:
-            raise ValueError("unsupported (lm_dim, pose_dim)")
+            raise ValueError("unsupported (lm_dim, pose_dim, do_tvs)")
         self._cb = None
 
     def __del__(self):
@@ -326,7 +328,28 @@ class BundleAdjuster:
         return self.engine().get_rhs()[2]
 
     def delta_p(self):
-        return self.engine().get_step()[0]
+        e = self.engine()
+        return e.get_step()[0][:e.num_pose_params()]
+
+    def delta_k(self):
+        e = self.engine()
+        return e.get_step()[0][e.num_pose_params():]
+
+    def rhs_k(self):
+        e = self.engine()
+        return e.get_rhs()[1][e.num_pose_params():]
+
+    def num_pose_params(self):
+        return self.engine().num_pose_params()
+
+    def proj_tvs_jacobians(self):
+        return self.engine().get_calib_jacobians(self.GetNumProjResiduals())
+
+    def camera_pose(self, cam_id=0):
+        """rig()->cameras_[cam_id]->Pose()"""
+        t = np.empty(7)
+        self.L.ba_adjuster_get_camera_pose(self.h, int(cam_id), t.ctypes.data_as(C.POINTER(C.c_double)))
+        return t
 
     def delta_l(self):
         return self.engine().get_step()[1]

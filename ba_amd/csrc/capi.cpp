@@ -38,11 +38,13 @@ struct Iface {
   virtual void timers(ba_hip_timers* t) const = 0;
   virtual ba_hip_engine* engine() = 0;
   virtual void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) = 0;
+  virtual void camera_pose(uint32_t cam, double* t7) const = 0;
+  virtual void last_calib_step(double* d6) const = 0;
 };
 
-template <int LM, int PD>
+template <int LM, int PD, bool TVS = false>
 struct Impl : Iface {
-  typedef ba::BundleAdjuster<double, LM, PD, 0> BA;
+  typedef ba::BundleAdjuster<double, LM, PD, 0, TVS> BA;
   BA ba;
   void init(const ba_options* o) override {
     ba::Options<double> opt;
@@ -171,13 +173,23 @@ struct Impl : Iface {
   void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) override {
     ba.SetAllReduce(fn, ctx, rank, nranks);
   }
+  void camera_pose(uint32_t cam, double* t7) const override { ba.rig()->cameras_[cam]->Pose().to7(t7); }
+  void last_calib_step(double* d6) const override {
+    const auto& d = ba.GetLastStep().delta_k;
+    for (size_t i = 0; i < 6; ++i) d6[i] = i < d.size() ? d[i] : 0.0;
+  }
 };
 
-Iface* make(int lm, int pd) {
-#define CASE(L, P) if (lm == L && pd == P) return new Impl<L, P>()
+Iface* make(int lm, int pd, int do_tvs) {
+#define CASE(L, P) if (lm == L && pd == P && !do_tvs) return new Impl<L, P>()
   CASE(0, 6); CASE(0, 9); CASE(0, 15); CASE(1, 6); CASE(1, 9); CASE(1, 15);
   CASE(3, 6); CASE(3, 9); CASE(3, 15);
 #undef CASE
+  // DoTvs instantiations (reference BundleAdjuster.cpp:1816-1822 instantiates <1,6,5,true> and
+  // <1,15,5,true>; here with CalibSize 0)
+  if (do_tvs && lm == 1 && pd == 6) return new Impl<1, 6, true>();
+  if (do_tvs && lm == 1 && pd == 9) return new Impl<1, 9, true>();
+  if (do_tvs && lm == 1 && pd == 15) return new Impl<1, 15, true>();
   return nullptr;
 }
 
@@ -205,8 +217,10 @@ void ba_default_options(ba_options* o) {
   o->device = d.device;
   o->factorization_pivot_tolerance = d.factorization_pivot_tolerance;
 }
-ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim) {
-  Iface* p = make(lm_dim, pose_dim);
+ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim) { return ba_adjuster_create_calib(lm_dim, pose_dim, 0, 0); }
+ba_adjuster* ba_adjuster_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs) {
+  if (calib_size != 0) return nullptr;
+  Iface* p = make(lm_dim, pose_dim, do_tvs);
   if (!p) return nullptr;
   ba_adjuster* a = new ba_adjuster();
   a->p = p;
@@ -270,6 +284,8 @@ uint32_t ba_adjuster_get_imu_residual(const ba_adjuster* a, uint32_t id, double*
 void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s) { a->p->summary(s); }
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t) { a->p->timers(t); }
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a) { return a->p->engine(); }
+void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]) { a->p->camera_pose(cam_id, t_vs); }
+void ba_adjuster_get_last_calib_step(const ba_adjuster* a, double delta_k[6]) { a->p->last_calib_step(delta_k); }
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) { a->p->set_allreduce(fn, ctx, rank, nranks); }
 
 }  // extern "C"

@@ -243,9 +243,18 @@ BA_HD void proj_jacobians(const Cam& cam, const double* z, const double* x,
 // so T_wp of the measuring pose and T_vs of the reference camera are not needed.
 //   LM == 1: x = (ray, rho) in the reference sensor frame, t_ws_r / t_wp_r of the reference pose;
 //   LM == 3: x = homogeneous world point, t_ws_r / t_wp_r unused.
-template <int LM>
+//
+// jk (CAL, LM == 1): the two rows of dz_dtvs (parallel_algos.h:120-131), the derivative w.r.t. the
+// decoupled update of the camera mount, T_vs <- (R_vs exp(w), t_vs + dt), entering through both the
+// measuring and the reference camera: with T = T_vs_m^-1 A T_vs_r, A = T_wp_m^-1 T_wp_r,
+//   dP/d(dt) = rho R_vs_m^T (R_A - I),   dP/dw = [P]x - R_T [ray]x
+//   =>  row = -(dP/d.)^T d :   translation  -rho (R_wp_r^T a - R_vs_m d),   a = R_sw_m^T d
+//                              rotation      P x d - ray x (R_ws_r^T a)
+// (identically zero when both poses coincide; `keep` makes that exact).
+template <int LM, bool CAL = false>
 BA_HD void proj_linearize(const Cam& cam, const double* z, const double* x, const Rt& t_sw_m, const M3& R_vs_m,
-                          V3 t_sv_m, const Rt& t_ws_r, const Rt& t_wp_r, bool same_pose, ProjJac<LM>* out) {
+                          V3 t_sv_m, const Rt& t_ws_r, const Rt& t_wp_r, bool same_pose, ProjJac<LM>* out,
+                          double* jk = nullptr) {
   const V3 xv = v3(x[0], x[1], x[2]);
   const double rho = x[3];
   V3 Xw = xv;  // world point, scaled by rho for LM == 1
@@ -285,6 +294,13 @@ BA_HD void proj_linearize(const Cam& cam, const double* z, const double* x, cons
     const V3 f0 = mulT(t_wp_r.R, cross(a0, y)), f1 = mulT(t_wp_r.R, cross(a1, y));
     out->jr[3] = f0.x; out->jr[4] = f0.y; out->jr[5] = f0.z;
     out->jr[9] = f1.x; out->jr[10] = f1.y; out->jr[11] = f1.z;
+    if (CAL) {
+      const V3 g0 = (mulT(t_wp_r.R, a0) - mul(R_vs_m, d0)) * (-rk), g1 = (mulT(t_wp_r.R, a1) - mul(R_vs_m, d1)) * (-rk);
+      const V3 h0 = (cross(P, d0) - cross(xv, mulT(t_ws_r.R, a0))) * keep;
+      const V3 h1 = (cross(P, d1) - cross(xv, mulT(t_ws_r.R, a1))) * keep;
+      jk[0] = g0.x; jk[1] = g0.y; jk[2] = g0.z; jk[3] = h0.x; jk[4] = h0.y; jk[5] = h0.z;
+      jk[6] = g1.x; jk[7] = g1.y; jk[8] = g1.z; jk[9] = h1.x; jk[10] = h1.y; jk[11] = h1.z;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 12; ++i) out->jr[i] = 0.0;

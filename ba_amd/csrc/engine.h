@@ -45,6 +45,9 @@ struct Structure : Lists {
 
 struct Engine {
   int lm_dim = 1, pose_dim = 6, device = 0;
+  // Calibration unknowns behind the pose unknowns of the reduced system (ba_hip_set_calibration):
+  // 0, or 6 = the decoupled update of T_vs of camera 0 (the reference's DoTvs instantiations).
+  int calib_dim = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // bulk trailing updates of the factorisation (look-ahead)
   const double* A_cleared = nullptr;  // the allocation of A whose whole square has been zeroed once
@@ -74,7 +77,14 @@ struct Engine {
   bool sharded() const { return allreduce && (nranks > 1 || comm_force); }
 
   // ---- device: static problem data
-  DBuf<double> cam;                 // [C][4 + 12 (T_vs) + 12 (T_sv)]
+  DBuf<double> cam;                 // [C][4 + 12 (T_vs) + 12 (T_sv) + 7 (T_vs as t, q)]
+  // With T_vs a parameter the reference reads it in two places: the rig (Jacobian chains) and the
+  // per-pose caches of T_sw (PoseT::GetTsw, Types.h:61-70), and a rejected step restores the caches
+  // but not the rig (BundleAdjuster.cpp:1060-1068).  `cam` is the rig; cam_eval feeds k_pose_prep
+  // (the caches) and differs from it only between a rollback and the next accepted/applied step.
+  DBuf<double> cam_eval;
+  std::vector<double> tvs_eval, tvs_eval_prev;   // host copies, [C][7]
+  const double* cam_eval_ptr() const { return calib_dim ? cam_eval.p : cam.p; }
   DBuf<double> pose_cam;            // [P][4] per-pose intrinsics (Options::use_per_pose_cam_params)
   const double* pose_cam_ptr() const { return prob.pose_cam_params.empty() ? nullptr : pose_cam.p; }
   DBuf<int32_t> pose_opt, lm_opt;
@@ -143,6 +153,11 @@ struct Engine {
   DBuf<double> obs_e, obs_w;             // error for the median, robust weight
   DBuf<double> obs_jl;                   // [O][2*lm] sqrt(w) * dz_dlm (dogleg J_l * rhs_l)
   DBuf<double> diag_blocks;              // [Pact][36] diagonal blocks of S (k_pose_blocks -> k_write_diag)
+  DBuf<double> crow;                     // [n_scalars][6] calibration rows, indexed like `scal`: sqrt(w) dz_dtvs
+                                         // (u, v row) of observation a at 2a, 2a+1; E_l = sum w Jl^T Jk of
+                                         // landmark l at 2O + l; the last row stays zero
+  DBuf<double> border_blocks;            // [Pact][36] S_pk blocks (k_pose_border -> k_write_border)
+  DBuf<double> calib_partials;           // block partials of k_calib_reduce
   DBuf<double> frow;                     // [n_rows][6] observation-major factor rows (structure.h)
   DBuf<double> scal;                     // scalars: [2*O] sqrt(w) r, then [L*lm] b_l, then one 0
   DBuf<double> lm_vinv, lm_bl;           // [L][lm*lm], [L][lm]
@@ -186,6 +201,9 @@ struct Engine {
 
 // ---- kernel launchers (defined in k_*.hip); all enqueue on e->stream -------------
 int launch_pose_prep(Engine* e);                       // T_sw, T_ws, T_wp of the current state
+int upload_cameras(Engine* e, bool eval_only);         // camera table(s) from prob.cam_* / tvs_eval
+int launch_calib_border(Engine* e);                    // S_pk, S_kk, rhs_k into A / rhs (after k_write_diag)
+int launch_calib_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out);
 int launch_begin_solve(Engine* e);                     // x_s from x_w
 int launch_end_solve(Engine* e);                       // x_w from x_s
 int launch_residual_vectors(Engine* e, double* d_r2);  // z - pi per observation at the current state

@@ -115,7 +115,7 @@ static int build_structure(Engine* e) {
   const bool host_build = env_host || e->dbg_host_structure;
   if (host_build) {
     std::string err;
-    if (!build_lists(pb, LM, e->pose_dim, st, err, stage)) {
+    if (!build_lists(pb, LM, e->pose_dim, st, err, stage, e->calib_dim)) {
       e->err = err;
       return -1;
     }
@@ -170,6 +170,11 @@ static int build_structure(Engine* e) {
       const int32_t o2 = res_p2[s] != 0xffffffffu ? st.pose_opt[res_p2[s]] : -1;
       if (o1 >= 0 && o2 >= 0) mark((uint32_t)o1, (uint32_t)o2);
     }
+    // calibration border: rows np .. np + K - 1 are dense (every pose with a projection residual
+    // couples to T_vs, BundleAdjuster.cpp:501-518)
+    if (st.K)
+      for (uint32_t r = st.np / 64; r <= (st.n - 1) / 64; ++r)
+        for (uint32_t c = 0; c <= r; ++c) { st.tile_nz[(size_t)r * nt + c] = 1; st.tile_nz[(size_t)c * nt + r] = 1; }
     e->nzL_valid = false;
   }
 
@@ -228,24 +233,9 @@ static int build_structure(Engine* e) {
     BAE_HIP(e->imu_cov_inv.alloc(std::max<size_t>(ni, 1) * 225));
     BAE_HIP(hipMemsetAsync(e->imu_cov_inv.p, 0, e->imu_cov_inv.bytes(), e->stream));
   }
-  // cameras: params(4) | T_vs Rt(12) | T_sv Rt(12) | T_vs as t,q (7)
-  {
-    std::vector<double> cam((size_t)st.C * 35, 0.0);
-    for (uint32_t c = 0; c < st.C; ++c) {
-      double* o = &cam[(size_t)c * 35];
-      const double* t = &pb.cam_tvs[(size_t)c * 7];
-      for (int i = 0; i < 4; ++i) o[i] = pb.cam_params[(size_t)c * 4 + i];
-      bad::Rt vs;
-      vs.R = bad::quat_to_rot(t[3], t[4], t[5], t[6]);
-      vs.t = bad::v3(t[0], t[1], t[2]);
-      const bad::Rt sv = bad::inverse(vs);
-      for (int i = 0; i < 9; ++i) { o[4 + i] = vs.R.m[i]; o[16 + i] = sv.R.m[i]; }
-      o[13] = vs.t.x; o[14] = vs.t.y; o[15] = vs.t.z;
-      o[25] = sv.t.x; o[26] = sv.t.y; o[27] = sv.t.z;
-      for (int i = 0; i < 7; ++i) o[28 + i] = t[i];
-    }
-    if ((rc = upload(e, e->cam, cam))) return rc;
-  }
+  e->tvs_eval = pb.cam_tvs;
+  e->tvs_eval_prev = pb.cam_tvs;
+  if ((rc = upload_cameras(e, false))) return rc;
   // state
   e->cur = 0;
   e->has_snapshot = false;
@@ -280,6 +270,11 @@ static int build_structure(Engine* e) {
   BAE_HIP(hipMemsetAsync(e->frow.p, 0, e->frow.bytes(), e->stream));
   BAE_HIP(e->scal.alloc(std::max<size_t>(st.n_scalars, 2 * O1 + L1 * LM1 + 1)));  // last: the zero scalar
   BAE_HIP(hipMemsetAsync(e->scal.p, 0, e->scal.bytes(), e->stream));
+  if (st.K) {
+    BAE_HIP(e->crow.alloc((size_t)std::max<size_t>(st.n_scalars, 1) * kRow));
+    BAE_HIP(hipMemsetAsync(e->crow.p, 0, e->crow.bytes(), e->stream));
+    BAE_HIP(e->border_blocks.alloc(std::max<size_t>((size_t)st.Pact * 36, 1)));
+  }
   BAE_HIP(e->lm_vinv.alloc(L1 * LM1 * LM1)); BAE_HIP(e->lm_bl.alloc(L1 * LM1));
   BAE_HIP(hipMemsetAsync(e->lm_vinv.p, 0, e->lm_vinv.bytes(), e->stream));
   BAE_HIP(hipMemsetAsync(e->lm_bl.p, 0, e->lm_bl.bytes(), e->stream));
@@ -343,6 +338,34 @@ int build_tile_order(Engine* e) {
   int rc = upload(e, e->tile_order, order);
   if (rc) return rc;
   e->tile_order_version = e->nzL_version;
+  return 0;
+}
+
+// cameras: params(4) | T_vs Rt(12) | T_sv Rt(12) | T_vs as t,q (7); `cam` from the rig (prob.cam_tvs),
+// cam_eval (calibration only) from tvs_eval
+int upload_cameras(Engine* e, bool eval_only) {
+  const Problem& pb = e->prob;
+  const uint32_t C = pb.num_cams;
+  auto table = [&](const std::vector<double>& tvs) {
+    std::vector<double> cam((size_t)C * 35, 0.0);
+    for (uint32_t c = 0; c < C; ++c) {
+      double* o = &cam[(size_t)c * 35];
+      const double* t = &tvs[(size_t)c * 7];
+      for (int i = 0; i < 4; ++i) o[i] = pb.cam_params[(size_t)c * 4 + i];
+      bad::Rt vs;
+      vs.R = bad::quat_to_rot(t[3], t[4], t[5], t[6]);
+      vs.t = bad::v3(t[0], t[1], t[2]);
+      const bad::Rt sv = bad::inverse(vs);
+      for (int i = 0; i < 9; ++i) { o[4 + i] = vs.R.m[i]; o[16 + i] = sv.R.m[i]; }
+      o[13] = vs.t.x; o[14] = vs.t.y; o[15] = vs.t.z;
+      o[25] = sv.t.x; o[26] = sv.t.y; o[27] = sv.t.z;
+      for (int i = 0; i < 7; ++i) o[28 + i] = t[i];
+    }
+    return cam;
+  };
+  int rc;
+  if (!eval_only && (rc = upload(e, e->cam, table(pb.cam_tvs)))) return rc;
+  if (e->calib_dim && (rc = upload(e, e->cam_eval, table(e->tvs_eval)))) return rc;
   return 0;
 }
 
@@ -659,6 +682,11 @@ int ba_hip_begin_solve(ba_hip_engine* h) {
     return e->fail_msg("per-pose camera parameters: one [fx,fy,u0,v0] per pose expected");
   int rc = upload_imu_consts(e);
   if (rc) return rc;
+  if (e->calib_dim) {  // a new Solve() starts from the rig's T_vs (see DESIGN.md §4c on the one deviation)
+    e->tvs_eval = e->prob.cam_tvs;
+    e->tvs_eval_prev = e->prob.cam_tvs;
+    if ((rc = upload_cameras(e, true))) return rc;
+  }
   rc = launch_pose_prep(e);
   if (rc) return rc;
   rc = launch_begin_solve(e);
@@ -760,7 +788,11 @@ int ba_hip_solve_gn(ba_hip_engine* h) {
   const Structure& st = e->st;
   int status = 0, rc;
   EventTimer t(e->stream);
-  if (st.n > 0) {
+  // CalculateGn runs only with active poses (BundleAdjuster.cpp:959-964, 1089-1094): with none, the
+  // calibration unknowns are not solved for either (delta_k stays empty in the reference)
+  const bool skip = st.K && st.Pact == 0;
+  if (skip) BAE_HIP(hipMemsetAsync(e->gn_p.p, 0, e->gn_p.bytes(), e->stream));
+  if (st.n > 0 && !skip) {
     if (e->opt.keep_reduced_system) {
       BAE_HIP(e->A_keep.alloc((size_t)st.ld * st.ld));
       BAE_HIP(hipMemcpyAsync(e->A_keep.p, e->A.p, (size_t)st.ld * st.ld * sizeof(double),
@@ -811,6 +843,23 @@ int ba_hip_apply_step(ba_hip_engine* h) {
   if (rc) return rc;
   e->cur = 1 - e->cur;
   e->has_snapshot = true;
+  if (e->calib_dim && e->st.C > 0) {
+    // BundleAdjuster.cpp:72-83: T_vs of camera 0 <- exp_decoupled(T_vs, -delta_k); the step's tail
+    // is delta_k.  The pose caches are rebuilt from the new rig below (t_sw.clear(), :114).
+    double dk[6];
+    BAE_HIP(hipMemcpyAsync(dk, e->step_p.p + e->st.np, sizeof(dk), hipMemcpyDeviceToHost, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+    double* t = e->prob.cam_tvs.data();
+    for (int i = 0; i < 3; ++i) t[i] -= dk[i];
+    double qe[4], q[4];
+    bad::so3_exp(bad::v3(-dk[3], -dk[4], -dk[5]), qe);
+    bad::quat_mul(t + 3, qe, q);
+    bad::quat_normalize(q);
+    for (int i = 0; i < 4; ++i) t[3 + i] = q[i];
+    e->tvs_eval_prev = e->tvs_eval;
+    e->tvs_eval = e->prob.cam_tvs;
+    if ((rc = upload_cameras(e, false))) return rc;
+  }
   rc = launch_pose_prep(e);
   if (rc) return rc;
   e->timers.apply_update = t.stop_ms();
@@ -824,7 +873,14 @@ int ba_hip_rollback(ba_hip_engine* h) {
   BAE_HIP(hipSetDevice(e->device));
   e->cur = 1 - e->cur;
   e->has_snapshot = false;
-  int rc = launch_pose_prep(e);
+  int rc;
+  if (e->calib_dim) {
+    // the reference restores the poses WITH their cached T_sw but not the rig (:1060-1068): the
+    // tables go back to the T_vs they were built with, `cam` keeps the rejected update
+    e->tvs_eval = e->tvs_eval_prev;
+    if ((rc = upload_cameras(e, true))) return rc;
+  }
+  rc = launch_pose_prep(e);
   if (rc) return rc;
   BAE_HIP(hipStreamSynchronize(e->stream));
   return 0;
@@ -895,7 +951,24 @@ int ba_hip_get_landmark_flags(ba_hip_engine* h, uint8_t* is_reliable, uint32_t* 
 }
 
 uint32_t ba_hip_num_pose_params(const ba_hip_engine* h) {
-  return reinterpret_cast<const Engine*>(h)->st.n;
+  return reinterpret_cast<const Engine*>(h)->st.np;
+}
+uint32_t ba_hip_num_calib_params(const ba_hip_engine* h) {
+  return reinterpret_cast<const Engine*>(h)->st.K;
+}
+int ba_hip_set_calibration(ba_hip_engine* h, int calib_size, int do_tvs) {
+  ENG(h);
+  if (calib_size != 0) return e->fail_msg("camera-intrinsics calibration columns (CalibSize > 0) are not implemented");
+  if (do_tvs && e->lm_dim != 1) return e->fail_msg("T_vs calibration needs LmSize 1 (dz_dtvs, parallel_algos.h:102-131)");
+  e->calib_dim = do_tvs ? 6 : 0;
+  e->finalized = false;
+  return 0;
+}
+int ba_hip_get_cameras(ba_hip_engine* h, double* t_vs7) {
+  ENG(h);
+  const std::vector<double>& t = e->prob.cam_tvs;
+  for (size_t i = 0; i < t.size(); ++i) t_vs7[i] = t[i];
+  return 0;
 }
 uint32_t ba_hip_num_lm_params(const ba_hip_engine* h) {
   const Engine* e = reinterpret_cast<const Engine*>(h);
@@ -907,6 +980,7 @@ int ba_hip_get_S(ba_hip_engine* h, double* s_nxn) {
   NEED_FINAL();
   const Structure& st = e->st;
   const uint32_t n = st.n, ld = st.ld, D = e->pose_dim;
+  auto block_of = [&](uint32_t r) { return r < st.np ? r / D : st.Pact; };  // the calibration border is one more block
   std::vector<double> a((size_t)n * ld);
   BAE_HIP(hipStreamSynchronize(e->stream));
   if (e->factored && !(e->opt.keep_reduced_system && e->A_keep.p))
@@ -917,7 +991,7 @@ int ba_hip_get_S(ba_hip_engine* h, double* s_nxn) {
   // use_triangular_matrices (SparseBlockMatrixOps.h:236-238), full symmetric otherwise
   for (uint32_t r = 0; r < n; ++r)
     for (uint32_t c = 0; c < n; ++c) {
-      const uint32_t bi = r / D, bj = c / D;
+      const uint32_t bi = block_of(r), bj = block_of(c);
       double v;
       if (bi == bj) v = a[(size_t)r * ld + c];
       else if (bi < bj) v = a[(size_t)c * ld + r];
@@ -1017,6 +1091,21 @@ int ba_hip_get_proj_jacobians(ba_hip_engine* h, double* j_meas12, double* j_ref1
     if (j_lm) for (int i = 0; i < 2 * LM; ++i) j_lm[2 * LM * a + i] = jl[(size_t)s * 2 * LM + i];
     if (r2) { r2[2 * a] = sc[2 * (size_t)s]; r2[2 * a + 1] = sc[2 * (size_t)s + 1]; }
   }
+  return 0;
+}
+
+int ba_hip_get_calib_jacobians(ba_hip_engine* h, double* j_k12) {
+  ENG(h);
+  NEED_FINAL();
+  const Structure& st = e->st;
+  if (!st.K) return e->fail_msg("no calibration columns (ba_hip_set_calibration)");
+  if (st.O == 0) return 0;
+  BAE_HIP(hipSetDevice(e->device));
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  std::vector<double> rows((size_t)2 * st.O * kRow);
+  BAE_HIP(hipMemcpy(rows.data(), e->crow.p, rows.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (uint32_t s = 0; s < st.O; ++s)
+    for (int i = 0; i < 12; ++i) j_k12[12 * (size_t)st.obs_perm[s] + i] = rows[12 * (size_t)s + i];
   return 0;
 }
 

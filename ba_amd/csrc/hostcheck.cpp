@@ -44,6 +44,20 @@ extern "C" void ba_hostcheck_proj_jacobians(int lm_dim, const double* cam4, cons
   }
 }
 
+// dz_dtvs rows of the DoTvs instantiations as k_linearize<.., CAL> evaluates them (LmSize 1)
+extern "C" void ba_hostcheck_proj_tvs_jacobian(const double* cam4, const double* z, const double* x,
+                                               const double* t_wp_m7, const double* t_vs_m7, const double* t_wp_r7,
+                                               const double* t_vs_r7, int same_pose, double* jk12) {
+  Cam cam = {cam4[0], cam4[1], cam4[2], cam4[3]};
+  const Rt t_wp_m = rt_from7(t_wp_m7), t_vs_m = rt_from7(t_vs_m7);
+  const Rt t_wp_r = rt_from7(t_wp_r7), t_vs_r = rt_from7(t_vs_r7);
+  const Rt t_sw_m = inverse(compose(t_wp_m, t_vs_m));
+  const Rt t_ws_r = compose(t_wp_r, t_vs_r);
+  const Rt t_sv_m = inverse(t_vs_m);
+  ProjJac<1> o;
+  proj_linearize<1, true>(cam, z, x, t_sw_m, t_vs_m.R, t_sv_m.t, t_ws_r, t_wp_r, same_pose != 0, &o, jk12);
+}
+
 // ---- pose-pose residuals (dpose.h) ---------------------------------------------------
 #include "dpose.h"
 

@@ -63,7 +63,7 @@ int launch_pose_prep(Engine* e) {
   const int P = e->st.P, C = e->st.C;
   if (P * C == 0) return 0;
   hipLaunchKernelGGL(k_pose_prep, dim3((P * C + 255) / 256), dim3(256), 0, e->stream, P, C,
-                     e->pose_state[e->cur].p, e->cam.p, e->twp.p, e->tws.p, e->tsw.p);
+                     e->pose_state[e->cur].p, e->cam_eval_ptr(), e->twp.p, e->tws.p, e->tsw.p);
   BAE_HIP(hipGetLastError());
   return 0;
 }
@@ -255,15 +255,16 @@ int launch_residuals(Engine* e, int mode) {
 // A landmark with more than 64 observations gets a wave of its own, which walks it twice (sums,
 // then rows).  The weighted error sum of BuildProblem (proj_error_, :1386) falls out as a per-wave
 // partial.
-template <int LM>
+template <int LM, bool CAL = false>
 struct ObsLin {
   double r[2], jm[12], jr[12], jl[2 * LM];
   double w;     // robust weight
+  double jk[CAL ? 12 : 1];  // dz_dtvs (calibration instantiations)
 };
 
 // Everything one observation contributes, at the current state: residual, Jacobians with the
 // columns of regularised parameters zeroed (BundleAdjuster.cpp:1622-1629), Huber weight.
-template <int LM>
+template <int LM, bool CAL = false>
 __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, double c_huber, int use_robust,
                                               const double* __restrict__ obs_z, const uint32_t* __restrict__ obs_pose,
                                               const uint32_t* __restrict__ obs_cam, const double* __restrict__ obs_w0,
@@ -272,7 +273,7 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
                                               const uint32_t* __restrict__ lm_ref_cam, const double* __restrict__ cam,
                                               const double* __restrict__ pose_cam, const double* __restrict__ tsw,
                                               const double* __restrict__ tws, const double* __restrict__ twp,
-                                              ObsLin<LM>* o) {
+                                              ObsLin<LM, CAL>* o, const int32_t* __restrict__ pose_opt = nullptr) {
   const uint32_t pm = obs_pose[a], cm = obs_cam[a];
   const double* cp = cam + (size_t)cm * 35;
   // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
@@ -295,7 +296,13 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
     const Rt t_ws_r = load_rt(tws + ((size_t)rp * C + rc) * kRt);
     const Rt t_wp_r = load_rt(twp + (size_t)rp * kRt);
     mask_r = pose_mask[rp];
-    proj_linearize<1>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_ws_r, t_wp_r, pm == rp, &J);
+    proj_linearize<1, CAL>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_ws_r, t_wp_r, pm == rp, &J, o->jk);
+    if constexpr (CAL) {
+      // parallel_algos.h:88,120: dz_dtvs is only formed when one of the two poses is active
+      const double keep = (pose_opt[pm] >= 0 || pose_opt[rp] >= 0) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) o->jk[i] *= keep;
+    }
   } else {
     proj_linearize<LM>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_sw_m, t_sw_m, false, &J);
   }
@@ -343,9 +350,11 @@ __device__ __forceinline__ void invert_v(const double* Vs, double* Vi) {
 }
 
 // lane-local contributions to the landmark sums: [V unique | b_l | W_r (LM == 1)]
-template <int LM> struct LmSums { static constexpr int NV = LM * (LM + 1) / 2, N = NV + LM + (LM == 1 ? 6 : 0); };
-template <int LM>
-__device__ __forceinline__ void obs_sums(const ObsLin<LM>& q, double* v) {
+template <int LM, bool CAL = false> struct LmSums {
+  static constexpr int NV = LM * (LM + 1) / 2, NE = NV + LM + (LM == 1 ? 6 : 0), N = NE + (CAL ? 6 : 0);
+};
+template <int LM, bool CAL = false>
+__device__ __forceinline__ void obs_sums(const ObsLin<LM, CAL>& q, double* v) {
   int k = 0;
 #pragma unroll
   for (int p = 0; p < LM; ++p)
@@ -356,12 +365,16 @@ __device__ __forceinline__ void obs_sums(const ObsLin<LM>& q, double* v) {
   if constexpr (LM == 1) {
 #pragma unroll
     for (int x = 0; x < 6; ++x) v[k++] = (q.jr[x] * q.jl[0] + q.jr[6 + x] * q.jl[1]) * q.w;
+    if constexpr (CAL) {  // E_l = sum w J_l^T J_k (jt_kpr_ j_l_, BundleAdjuster.cpp:534-536)
+#pragma unroll
+      for (int x = 0; x < 6; ++x) v[k++] = (q.jk[x] * q.jl[0] + q.jk[6 + x] * q.jl[1]) * q.w;
+    }
   }
 }
 
 // the R rows of one observation (structure.h): J_m (2), [J_r (2)], W_m (LM), -W_m V^-1 (LM)
-template <int LM>
-__device__ __forceinline__ void obs_rows(const ObsLin<LM>& q, const double* Vi, double* rows) {
+template <int LM, bool CAL = false>
+__device__ __forceinline__ void obs_rows(const ObsLin<LM, CAL>& q, const double* Vi, double* rows) {
   const double sw = sqrt(q.w);
 #pragma unroll
   for (int i = 0; i < 12; ++i) rows[i] = q.jm[i] * sw;
@@ -411,7 +424,10 @@ __device__ __forceinline__ void store_landmark(uint32_t l, uint32_t O, uint32_t 
   }
 }
 
-template <int LM, int WAVES, bool BIG, bool STAGE>
+// CAL (calibration instantiations, LM == 1): additionally the calibration rows `crow` (engine.h) —
+// sqrt(w) dz_dtvs of the observation at 2a, 2a+1 and the landmark's E_l = sum w J_l^T J_k at 2O + l
+// (six more components of the segmented sums).
+template <int LM, int WAVES, bool BIG, bool STAGE, bool CAL = false>
 __global__ void __launch_bounds__(64 * WAVES)
 k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_huber, int use_robust,
             const uint2* __restrict__ wave_rng, const uint32_t* __restrict__ lm_ptr,
@@ -424,10 +440,26 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
             const double* __restrict__ tsw, const double* __restrict__ tws, const double* __restrict__ twp,
             double* __restrict__ obs_w, double* __restrict__ frow, double* __restrict__ scal,
             double* __restrict__ lm_vinv, double* __restrict__ lm_bl, double* __restrict__ obs_jl,
-            double* __restrict__ partials) {
+            double* __restrict__ partials, const int32_t* __restrict__ pose_opt, double* __restrict__ crow) {
   constexpr int R = LM == 1 ? 6 : 8, RD = R * 6;   // rows / doubles per observation
   constexpr int STRIDE = RD + 2;                    // LDS stride per lane (even: 16-byte reads; odd multiple of 2 banks)
-  constexpr int NS = LmSums<LM>::N, NV = LmSums<LM>::NV;
+  constexpr int NS = LmSums<LM, CAL>::N, NV = LmSums<LM, CAL>::NV, NE = LmSums<LM, CAL>::NE;
+  // the calibration rows of one observation / of one landmark
+  auto store_calib_obs = [&](uint32_t a, const ObsLin<LM, CAL>& q) {
+    if constexpr (CAL) {
+      const double sw = sqrt(q.w);
+      double* o = crow + 2 * (size_t)a * kRow;
+#pragma unroll
+      for (int i = 0; i < 12; i += 2) *reinterpret_cast<double2*>(o + i) = make_double2(q.jk[i] * sw, q.jk[i + 1] * sw);
+    }
+  };
+  auto store_calib_lm = [&](uint32_t l, const double* tot) {
+    if constexpr (CAL) {
+      double* o = crow + (2 * (size_t)O + l) * kRow;
+#pragma unroll
+      for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(o + i) = make_double2(tot[NE + i], tot[NE + i + 1]);
+    }
+  };
   __shared__ __attribute__((aligned(16))) double stage[(BIG || !STAGE) ? 1 : WAVES][(BIG || !STAGE) ? 2 : 64 * STRIDE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t chunk = blockIdx.x * WAVES + wave;
@@ -443,10 +475,10 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     const uint32_t l = obs_lm[a];
     const bool lm_act = lm_opt[l] >= 0;
     const int s0 = (int)(lm_ptr[l] - a0), s1 = (int)(lm_ptr[l + 1] - 1 - a0);  // lanes of this landmark
-    ObsLin<LM> q;
-    linearize_obs<LM>(a, l, BAE_LIN_ARGS, &q);
+    ObsLin<LM, CAL> q;
+    linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt);
     double v[NS];
-    obs_sums<LM>(q, v);
+    obs_sums<LM, CAL>(q, v);
     if (!valid || !lm_act) {
 #pragma unroll
       for (int i = 0; i < NS; ++i) v[i] = 0.0;
@@ -469,14 +501,14 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     if constexpr (STAGE) {
       double* st = stage[wave] + lane * STRIDE;
       double rows[RD];
-      obs_rows<LM>(q, Vi, rows);
+      obs_rows<LM, CAL>(q, Vi, rows);
 #pragma unroll
       for (int i = 0; i < RD; i += 2) *reinterpret_cast<double2*>(st + i) = make_double2(rows[i], rows[i + 1]);
     } else if (valid) {
       // direct variant: every lane stores its own RD doubles (lane stride RD * 8 bytes); the L2 merges
       // the partial lines of the wave's contiguous span
       double rows[RD];
-      obs_rows<LM>(q, Vi, rows);
+      obs_rows<LM, CAL>(q, Vi, rows);
       double* dst = frow + (size_t)a * RD;
 #pragma unroll
       for (int i = 0; i < RD; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(rows[i], rows[i + 1]);
@@ -488,7 +520,11 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
 #pragma unroll
       for (int i = 0; i < 2 * LM; ++i) obs_jl[(size_t)a * 2 * LM + i] = lm_act ? q.jl[i] * sw : 0.0;
       err = (q.r[0] * q.r[0] + q.r[1] * q.r[1]) * q.w;
-      if (lane == s1 && lm_act) store_landmark<LM>(l, O, lrow_base, tot, Vi, lm_vinv, lm_bl, scal, frow);
+      store_calib_obs(a, q);
+      if (lane == s1 && lm_act) {
+        store_landmark<LM>(l, O, lrow_base, tot, Vi, lm_vinv, lm_bl, scal, frow);
+        store_calib_lm(l, tot);
+      }
     }
     // LDS image -> one contiguous span of the factor rows (16 bytes per lane per store)
     if constexpr (STAGE) {
@@ -512,10 +548,10 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
 #pragma unroll
     for (int i = 0; i < NS; ++i) tot[i] = 0.0;
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
-      ObsLin<LM> q;
-      linearize_obs<LM>(a, l, BAE_LIN_ARGS, &q);
+      ObsLin<LM, CAL> q;
+      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt);
       double v[NS];
-      obs_sums<LM>(q, v);
+      obs_sums<LM, CAL>(q, v);
 #pragma unroll
       for (int i = 0; i < NS; ++i) tot[i] += lm_act ? v[i] : 0.0;
     }
@@ -527,10 +563,11 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     double Vi[LM * LM];
     invert_v<LM>(tot, Vi);
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
-      ObsLin<LM> q;
-      linearize_obs<LM>(a, l, BAE_LIN_ARGS, &q);
+      ObsLin<LM, CAL> q;
+      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt);
       double rows[RD];
-      obs_rows<LM>(q, Vi, rows);
+      obs_rows<LM, CAL>(q, Vi, rows);
+      store_calib_obs(a, q);
       double* dst = frow + (size_t)a * RD;
 #pragma unroll
       for (int i = 0; i < RD; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(rows[i], rows[i + 1]);
@@ -541,14 +578,17 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
       for (int i = 0; i < 2 * LM; ++i) obs_jl[(size_t)a * 2 * LM + i] = lm_act ? q.jl[i] * sw : 0.0;
       err += (q.r[0] * q.r[0] + q.r[1] * q.r[1]) * q.w;
     }
-    if (lane == 0 && lm_act) store_landmark<LM>(l, O, lrow_base, tot, Vi, lm_vinv, lm_bl, scal, frow);
+    if (lane == 0 && lm_act) {
+      store_landmark<LM>(l, O, lrow_base, tot, Vi, lm_vinv, lm_bl, scal, frow);
+      store_calib_lm(l, tot);
+    }
   }
 #undef BAE_LIN_ARGS
   // weighted error of the wave (fixed tree) -> one partial per wave
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) err += __shfl_xor(err, off, 64);
   if (lane == 0) partials[chunk] = err;
-  (void)NV;
+  (void)NV; (void)NE;
 }
 
 int launch_landmarks(Engine* e, double c_huber, int use_robust) {
@@ -562,8 +602,23 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
   count, (int)st.C, st.O, st.lrow_base, c_huber, use_robust, e->wave_rng.p + (first), e->lm_ptr.p, e->obs_z.p, \
       e->obs_pose.p, e->obs_cam.p, e->obs_lm.p, e->obs_w0.p, e->lm_opt.p, e->pose_mask.p, e->lm_x[e->cur].p, \
       e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->twp.p,     \
-      e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p, e->obs_jl.p, e->partials.p + (first)
+      e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p, e->obs_jl.p, e->partials.p + (first),  \
+      (const int32_t*)e->pose_opt.p, e->crow.p
   e->prof_begin(e->ev_landmarks);
+  if (st.K) {  // calibration instantiations (LmSize 1): the CAL kernels, same launch shapes
+    if (n_small) {
+      const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
+      hipLaunchKernelGGL((k_linearize<1, WAVES, false, true, true>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+    }
+    if (st.n_big_chunks) {
+      const dim3 grid((st.n_big_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
+      hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, true>), grid, block, 0, e->stream,
+                         BAE_ARGS(n_small, st.n_big_chunks));
+    }
+    e->prof_end(e->ev_landmarks);
+    BAE_HIP(hipGetLastError());
+    return 0;
+  }
   if (n_small) {
     if (e->dbg_linearize_variant == 0) {
       const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
@@ -597,7 +652,8 @@ __global__ void k_backsub(int L, int D, uint32_t lrow_base, const int32_t* __res
                           const uint32_t* __restrict__ obs_pose, const uint32_t* __restrict__ lm_ref_pose,
                           const double* __restrict__ frow, const double* __restrict__ lm_vinv,
                           const double* __restrict__ lm_bl, const double* __restrict__ delta_p,
-                          double* __restrict__ delta_l) {
+                          double* __restrict__ delta_l, const double* __restrict__ crow_lm,
+                          const double* __restrict__ delta_k) {
   constexpr int R = LM == 1 ? 6 : 8, WO = LM == 1 ? 4 : 2;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L) return;
@@ -632,6 +688,13 @@ __global__ void k_backsub(int L, int D, uint32_t lrow_base, const int32_t* __res
     for (int r = 0; r < 6; ++r) s += wr[r] * dp[r];
     rhs[0] -= s;
   }
+  if (LM == 1 && crow_lm) {  // calibration: rhs_l -= (J_l^T J_k) delta_k (BundleAdjuster.cpp:729-733)
+    const double* er = crow_lm + (size_t)l * kRow;
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) s += er[r] * delta_k[r];
+    rhs[0] -= s;
+  }
 #pragma unroll
   for (int a = 0; a < LM; ++a) {
     double s = 0.0;
@@ -647,7 +710,9 @@ int launch_backsub(Engine* e) {
   const dim3 grid((L + 255) / 256), block(256);
 #define BAE_ARGS                                                                                      \
   L, e->pose_dim, e->st.lrow_base, e->lm_opt.p, e->pose_opt.p, e->lm_ptr.p, e->obs_pose.p, e->lm_ref_pose.p, \
-      e->frow.p, e->lm_vinv.p, e->lm_bl.p, e->gn_p.p, e->gn_l.p
+      e->frow.p, e->lm_vinv.p, e->lm_bl.p, e->gn_p.p, e->gn_l.p,                                    \
+      (const double*)(e->st.K ? e->crow.p + 2 * (size_t)e->st.O * kRow : nullptr),                    \
+      (const double*)(e->gn_p.p + e->st.np)
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_backsub<1>, grid, block, 0, e->stream, BAE_ARGS);
   else hipLaunchKernelGGL(k_backsub<3>, grid, block, 0, e->stream, BAE_ARGS);
 #undef BAE_ARGS

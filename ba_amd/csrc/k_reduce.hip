@@ -279,6 +279,123 @@ k_write_diag(const double* __restrict__ diag, int D, uint32_t ld, const uint16_t
   }
 }
 
+// ---- calibration border (T_vs columns of the DoTvs instantiations, BundleAdjuster.cpp:493-583) ----
+// k_pose_border — the 6 x 6 block S_pk of one active pose from the SAME term list as its diagonal
+// block: a term (rowA, rowB, scalar index si) contributes rowA (x) crow[si], because the calibration
+// rows are indexed like the scalars —
+//   J terms      si = 2a + k      crow = sqrt(w) dz_dtvs row k of observation a:   J_p^T J_k      (:501-518)
+//   Schur terms  si = 2O + l      crow = E_l = sum w J_l^T J_k:                 -(W V^-1) E_l    (:538-556)
+//   same-pose cross terms carry the zero scalar, whose calibration row is zero.
+__global__ void __launch_bounds__(256)
+k_pose_border(const uint32_t* __restrict__ pose_ptr, const uint32_t* __restrict__ pose_ent,
+              const double* __restrict__ frow, const double* __restrict__ crow, double* __restrict__ out) {
+  __shared__ double red[4][36];
+  const uint32_t i = blockIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const uint32_t e0 = pose_ptr[i], e1 = pose_ptr[i + 1];
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (uint32_t e = e0 + tid; e < e1; e += 256) {
+    const uint32_t ra = pose_ent[3 * (size_t)e], si = pose_ent[3 * (size_t)e + 2];
+    const double2* pa = reinterpret_cast<const double2*>(frow + (size_t)ra * kRow);
+    const double2* pc = reinterpret_cast<const double2*>(crow + (size_t)si * kRow);
+    const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], c0 = pc[0], c1 = pc[1], c2 = pc[2];
+    const double a[6] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y};
+    const double c[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a[x] * c[y];
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[w][k] = v;
+  }
+  __syncthreads();
+  if (tid < 36) out[(size_t)i * 36 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// k_calib_reduce — S_kk and rhs_k: one pass over the calibration rows (fixed grid, strided items,
+// fixed trees: reproducible).  33 sums: the 21 unique entries of S_kk, J_k^T r (6), and the Schur part
+// of rhs_k (6):
+//   observation rows:  S_kk += c c^T,          rhs_k += c * sqrt(w) r                     (:494-499, 520-522)
+//   landmark rows:     S_kk -= V^-1 E E^T,     rhs_k_sc -= E V^-1 b_l                     (:558-582)
+__global__ void __launch_bounds__(256)
+k_calib_reduce(uint32_t n_obs_rows, uint32_t L, const double* __restrict__ crow, const double* __restrict__ scal,
+               const double* __restrict__ lm_vinv, const int32_t* __restrict__ lm_opt,
+               double* __restrict__ partials, uint32_t nparts) {
+  __shared__ double red[4][33];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  double acc[33];
+#pragma unroll
+  for (int k = 0; k < 33; ++k) acc[k] = 0.0;
+  const size_t total = (size_t)n_obs_rows + L;
+  for (size_t idx = (size_t)blockIdx.x * 256 + tid; idx < total; idx += (size_t)gridDim.x * 256) {
+    const double2* pc = reinterpret_cast<const double2*>(crow + idx * kRow);
+    const double2 c0 = pc[0], c1 = pc[1], c2 = pc[2];
+    const double c[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
+    double f = 1.0, s_raw = scal[idx], s_sc = 0.0;
+    if (idx >= n_obs_rows) {
+      const size_t l = idx - n_obs_rows;
+      const double vi = lm_opt[l] >= 0 ? lm_vinv[l] : 0.0;
+      f = -vi; s_sc = -vi * s_raw; s_raw = 0.0;
+    }
+    int k = 0;
+#pragma unroll
+    for (int x = 0; x < 6; ++x)
+#pragma unroll
+      for (int y = x; y < 6; ++y) acc[k++] += f * c[x] * c[y];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) { acc[21 + x] += c[x] * s_raw; acc[27 + x] += c[x] * s_sc; }
+  }
+#pragma unroll
+  for (int k = 0; k < 33; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[w][k] = v;
+  }
+  __syncthreads();
+  if (tid < 33) partials[(size_t)tid * nparts + blockIdx.x] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// Sums the block partials of k_calib_reduce in block order and places S_kk (both triangles of the
+// 6 x 6 block, like the pose blocks), rhs_k (unreduced, tail of rhs_p) and its reduced form (tail of
+// rhs_sc); k_write_border places the S_pk blocks as rows np .. np+5 of the lower storage.
+__global__ void __launch_bounds__(64)
+k_calib_finish(uint32_t nparts, const double* __restrict__ partials, uint32_t np, uint32_t ld,
+               double* __restrict__ A, double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
+  __shared__ double tot[33];
+  const int tid = threadIdx.x;
+  if (tid < 33) {
+    double s = 0.0;
+    for (uint32_t b = 0; b < nparts; ++b) s += partials[(size_t)tid * nparts + b];
+    tot[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int r = tid / 6, c = tid - 6 * r, x = r < c ? r : c, y = r < c ? c : r;
+    A[((size_t)np + r) * ld + np + c] = tot[x * 6 - x * (x - 1) / 2 + (y - x)];
+  } else if (tid < 42) {
+    const int k = tid - 36;
+    rhs_p[np + k] = tot[21 + k];
+    rhs_sc[np + k] = tot[21 + k] + tot[27 + k];
+  }
+}
+__global__ void __launch_bounds__(64)
+k_write_border(const double* __restrict__ border, int D, uint32_t np, uint32_t ld, double* __restrict__ A) {
+  const uint32_t i = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid < 36) {
+    const int r = tid / 6, c = tid - 6 * r;
+    A[((size_t)np + c) * ld + (size_t)i * D + r] = border[(size_t)i * 36 + tid];
+  }
+}
+
 // rows n..n_pad-1 of the padded system: identity
 __global__ void k_pad_diag(uint32_t n, uint32_t n_pad, uint32_t ld, double* __restrict__ A) {
   const uint32_t k = n + blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,6 +470,11 @@ int launch_gather_S(Engine* e) {
                        e->pose_ent.p, e->frow.p, e->scal.p, e->pose_dim, e->diag_blocks.p, e->rhs_p.p, e->rhs_sc.p);
     e->prof_end(e->ev_pose, e->stream2);
     BAE_HIP(hipGetLastError());
+    if (st.K) {
+      hipLaunchKernelGGL(k_pose_border, dim3(st.Pact), dim3(256), 0, e->stream2, e->pose_ptr.p, e->pose_ent.p,
+                         e->frow.p, e->crow.p, e->border_blocks.p);
+      BAE_HIP(hipGetLastError());
+    }
     BAE_HIP(hipEventRecord(e->ev_join, e->stream2));
   }
   e->prof_begin(e->ev_gather);
@@ -382,7 +504,32 @@ int launch_gather_S(Engine* e) {
     hipLaunchKernelGGL(k_write_diag, dim3(st.Pact), dim3(64), 0, e->stream, (const double*)e->diag_blocks.p,
                        e->pose_dim, ld, masks, write_fixed, e->A.p);
     BAE_HIP(hipGetLastError());
+    if (st.K) {
+      hipLaunchKernelGGL(k_write_border, dim3(st.Pact), dim3(64), 0, e->stream, (const double*)e->border_blocks.p,
+                         e->pose_dim, st.np, ld, e->A.p);
+      BAE_HIP(hipGetLastError());
+    }
   }
+  if (st.K) {
+    int rc = launch_calib_border(e);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// S_kk and rhs_k (k_calib_reduce, k_calib_finish): after the tile assembly zeroed the border tiles
+int launch_calib_border(Engine* e) {
+  const Structure& st = e->st;
+  const size_t total = 2 * (size_t)st.O + st.L;
+  const uint32_t nb = (uint32_t)std::min<size_t>(1024, std::max<size_t>((total + 255) / 256, 1));
+  DBuf<double>& part = e->calib_partials;
+  BAE_HIP(part.alloc(33 * 1024));
+  hipLaunchKernelGGL(k_calib_reduce, dim3(nb), dim3(256), 0, e->stream, 2 * st.O, st.L, e->crow.p, e->scal.p,
+                     e->lm_vinv.p, e->lm_opt.p, part.p, nb);
+  BAE_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_calib_finish, dim3(1), dim3(64), 0, e->stream, nb, (const double*)part.p, st.np, st.ld,
+                     e->A.p, e->rhs_p.p, e->rhs_sc.p);
+  BAE_HIP(hipGetLastError());
   return 0;
 }
 
@@ -716,9 +863,14 @@ __global__ void k_compose_lm(uint32_t L, int LM, double a, double b,
 int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norms2_host) {
   const Structure& st = e->st;
   norms2_host[0] = norms2_host[1] = 0.0;
-  if (st.n > 0) {
-    const uint32_t nb = (st.n + 255) / 256;
-    hipLaunchKernelGGL(k_compose, dim3(nb), dim3(256), 0, e->stream, st.n, coef_rhs, coef_gn,
+  if (st.K) {  // delta_k: composed like the pose part, left out of the norm (BundleAdjuster.cpp:26)
+    hipLaunchKernelGGL(k_compose, dim3(1), dim3(256), 0, e->stream, st.K, coef_rhs, coef_gn, e->rhs_p.p + st.np,
+                       e->gn_p.p + st.np, e->step_p.p + st.np, e->partials.p);
+    BAE_HIP(hipGetLastError());
+  }
+  if (st.np > 0) {
+    const uint32_t nb = (st.np + 255) / 256;
+    hipLaunchKernelGGL(k_compose, dim3(nb), dim3(256), 0, e->stream, st.np, coef_rhs, coef_gn,
                        e->rhs_p.p, e->gn_p.p, e->step_p.p, e->partials.p);
     BAE_HIP(hipGetLastError());
     // the pose step is replicated on every shard: no cross-shard sum
@@ -837,9 +989,9 @@ int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
   memset(out, 0, sizeof(*out));
   double h[3];
   int rc;
-  if (st.n > 0) {  // pose parts: replicated on every shard
-    const uint32_t nb = (st.n + 255) / 256;
-    hipLaunchKernelGGL(k_dots_pose, dim3(nb), dim3(256), 0, e->stream, st.n, gn_available,
+  if (st.np > 0) {  // pose parts: replicated on every shard
+    const uint32_t nb = (st.np + 255) / 256;
+    hipLaunchKernelGGL(k_dots_pose, dim3(nb), dim3(256), 0, e->stream, st.np, gn_available,
                        e->rhs_p.p, e->gn_p.p, e->partials.p, nb);
     BAE_HIP(hipGetLastError());
     if ((rc = sum_partials(e, nb, 3, h, false))) return rc;
@@ -866,6 +1018,51 @@ int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
     if ((rc = sum_partials(e, nb, 1, h, true))) return rc;
     out->j_rhs_sq = h[0];
   }
+  if (st.K && (rc = launch_calib_dogleg(e, gn_available, out))) return rc;
+  return 0;
+}
+
+// Calibration part of the dogleg scalars (BundleAdjuster.cpp:858-859, 883-886, 906-910, 971-1002):
+// squared norms / dot of rhs_k and the Gauss-Newton delta_k (replicated: tails of rhs_p / gn_p), and
+// || J_k rhs_k ||^2 over the observations, which the reference adds to the denominator as a term of
+// its own.
+__global__ void __launch_bounds__(256)
+k_jk_rhs(uint32_t O, const double* __restrict__ crow, const double* __restrict__ rhs_k, double* __restrict__ partials) {
+  __shared__ double red[256];
+  const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double sq = 0.0;
+  if (a < O) {
+    double u0 = 0, u1 = 0;
+    const double* r0 = crow + 2 * a * kRow;
+    for (int c = 0; c < 6; ++c) { u0 += r0[c] * rhs_k[c]; u1 += r0[kRow + c] * rhs_k[c]; }
+    sq = u0 * u0 + u1 * u1;
+  }
+  red[threadIdx.x] = sq;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+int launch_calib_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
+  const Structure& st = e->st;
+  double rk[6], gk[6] = {0, 0, 0, 0, 0, 0};
+  BAE_HIP(hipMemcpyAsync(rk, e->rhs_p.p + st.np, sizeof(rk), hipMemcpyDeviceToHost, e->stream));
+  if (gn_available) BAE_HIP(hipMemcpyAsync(gk, e->gn_p.p + st.np, sizeof(gk), hipMemcpyDeviceToHost, e->stream));
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < 6; ++i) { out->rhs_k_sq += rk[i] * rk[i]; out->gn_k_sq += gk[i] * gk[i]; out->rhs_gn_k += rk[i] * gk[i]; }
+  const uint32_t nb = (st.O > 0 && st.Pact > 0) ? (st.O + 255) / 256 : 0;  // :881-886: only with active poses
+  if (nb) {
+    hipLaunchKernelGGL(k_jk_rhs, dim3(nb), dim3(256), 0, e->stream, st.O, (const double*)e->crow.p,
+                       (const double*)(e->rhs_p.p + st.np), e->partials.p);
+    BAE_HIP(hipGetLastError());
+  }
+  double h = 0.0;
+  int rc = sum_partials(e, nb, 1, &h, true);
+  if (rc) return rc;
+  out->j_rhs_sq += h;
   return 0;
 }
 

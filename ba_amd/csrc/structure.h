@@ -79,7 +79,8 @@ static const int kRefBias = 8;  // bias of the (possibly negative) block offsets
 
 struct Lists {
   uint32_t P = 0, Pact = 0, L = 0, Lact = 0, O = 0, C = 0;
-  uint32_t n = 0, ld = 0;
+  uint32_t n = 0, ld = 0;       // unknowns of the reduced system (np + K) and its padded leading dimension
+  uint32_t np = 0, K = 0;       // pose unknowns (Pact * D); calibration unknowns behind them (0, or 6 = T_vs)
   uint32_t R = 0;               // rows per observation
   uint32_t lrow_base = 0;       // first landmark row (LM == 1)
   uint32_t n_rows = 0;          // factor rows incl. the trailing all-zero row
@@ -115,7 +116,7 @@ inline unsigned structure_threads() {
 
 // Returns false and sets `err` on an inconsistent graph.
 inline bool build_lists(const Problem& pb, int LM, int D, Lists& st, std::string& err,
-                        const std::function<void(const char*)>& stage = nullptr) {
+                        const std::function<void(const char*)>& stage = nullptr, int K = 0) {
   auto mark_stage = [&](const char* s) { if (stage) stage(s); };
   st = Lists();
   st.P = pb.num_poses; st.L = pb.num_lms; st.O = pb.num_proj; st.C = pb.num_cams;
@@ -128,7 +129,8 @@ inline bool build_lists(const Problem& pb, int LM, int D, Lists& st, std::string
   st.lm_opt.assign(st.L, -1);
   for (uint32_t l = 0; l < st.L; ++l)
     if (pb.lm_active[l] && LM > 0) st.lm_opt[l] = (int32_t)st.Lact++;
-  st.n = st.Pact * D;
+  st.np = st.Pact * D; st.K = (uint32_t)K;
+  st.n = st.np + st.K;
   st.ld = ((st.n + 63) / 64) * 64;
   if (st.ld == 0) st.ld = 64;
   for (uint32_t a = 0; a < st.O; ++a)

@@ -318,7 +318,8 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
   st.lm_opt.assign(st.L, -1);
   for (uint32_t l = 0; l < st.L; ++l)
     if (pb.lm_active[l] && LM > 0) st.lm_opt[l] = (int32_t)st.Lact++;
-  st.n = st.Pact * D;
+  st.np = st.Pact * D; st.K = (uint32_t)e->calib_dim;
+  st.n = st.np + st.K;
   st.ld = ((st.n + 63) / 64) * 64;
   if (st.ld == 0) st.ld = 64;
   for (uint32_t a = 0; a < st.O; ++a)

@@ -38,7 +38,8 @@ class Errors(C.Structure):
 
 class DoglegScalars(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("rhs_p_sq", "rhs_l_sq", "j_rhs_sq", "gn_p_sq",
-                                          "gn_l_sq", "rhs_gn_p", "rhs_gn_l")]
+                                          "gn_l_sq", "rhs_gn_p", "rhs_gn_l",
+                                          "rhs_k_sq", "gn_k_sq", "rhs_gn_k")]
 
 
 class StepNorms(C.Structure):
@@ -83,6 +84,7 @@ SYMBOLS = [
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
     "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set", "ba_hip_set_conditioning_residuals",
     "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host", "ba_hip_get_proj_jacobians",
+    "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians",
 ]
 
 
@@ -120,6 +122,7 @@ def lib():
         _lib.ba_hip_last_error.restype = C.c_char_p
         _lib.ba_hip_num_pose_params.restype = C.c_uint32
         _lib.ba_hip_num_lm_params.restype = C.c_uint32
+        _lib.ba_hip_num_calib_params.restype = C.c_uint32
     return _lib
 
 
@@ -273,26 +276,45 @@ class Engine:
         self._chk(self.L.ba_hip_get_landmark_flags(self.h, _p(r, u8p), _p(o, u32p)))
         return r, o
 
+    def num_calib_params(self):
+        return self.L.ba_hip_num_calib_params(self.h)
+
+    def set_calibration(self, calib_size=0, do_tvs=True):
+        """CalibSize / DoTvs of the reference's class template; before finalize()."""
+        self._chk(self.L.ba_hip_set_calibration(self.h, int(calib_size), int(do_tvs)))
+
+    def get_cameras(self, n):
+        t = np.empty((n, 7))
+        self._chk(self.L.ba_hip_get_cameras(self.h, _p(t, dp)))
+        return t
+
+    def get_calib_jacobians(self, n):
+        """sqrt(w) dz_dtvs (2x6) per residual id of the last linearisation."""
+        j = np.empty((n, 2, 6))
+        self._chk(self.L.ba_hip_get_calib_jacobians(self.h, _p(j, dp)))
+        return j
+
     def get_S(self):
-        n = self.num_pose_params()
+        """(n + K)^2 with K calibration unknowns behind the n pose unknowns."""
+        n = self.num_pose_params() + self.num_calib_params()
         s = np.empty((n, n))
         self._chk(self.L.ba_hip_get_S(self.h, _p(s, dp)))
         return s
 
     def get_rhs(self):
-        n, nl = self.num_pose_params(), self.num_lm_params()
+        n, nl = self.num_pose_params() + self.num_calib_params(), self.num_lm_params()
         a, b, c = np.empty(n), np.empty(n), np.zeros(max(nl, 1))
         self._chk(self.L.ba_hip_get_rhs(self.h, _p(a, dp), _p(b, dp), _p(c, dp)))
         return a, b, c[:nl]
 
     def get_delta_gn(self):
-        n, nl = self.num_pose_params(), self.num_lm_params()
+        n, nl = self.num_pose_params() + self.num_calib_params(), self.num_lm_params()
         a, c = np.empty(n), np.zeros(max(nl, 1))
         self._chk(self.L.ba_hip_get_delta_gn(self.h, _p(a, dp), _p(c, dp)))
         return a, c[:nl]
 
     def get_step(self):
-        n, nl = self.num_pose_params(), self.num_lm_params()
+        n, nl = self.num_pose_params() + self.num_calib_params(), self.num_lm_params()
         a, c = np.empty(n), np.zeros(max(nl, 1))
         self._chk(self.L.ba_hip_get_step(self.h, _p(a, dp), _p(c, dp)))
         return a, c[:nl]

@@ -11,8 +11,10 @@
 // this class: without a usable MI355X Solve() reports SolverError and prints the
 // engine's message.
 //
-// Supported instantiations: LmSize in {0,1,3}, PoseSize in {6,9,15}, CalibSize == 0,
-// DoTvs == false (the self-calibration columns are out of scope).
+// Supported instantiations: LmSize in {0,1,3}, PoseSize in {6,9,15}, CalibSize == 0; DoTvs (the
+// extrinsics T_vs of camera 0 as six more unknowns, reference :121-134, BundleAdjuster.cpp:72-83,
+// 493-583) with LmSize 1.  CalibSize > 0 (camera intrinsics) needs the camera model's parameter
+// Jacobian and stays out.
 #pragma once
 #include <algorithm>
 #include <cassert>
@@ -95,7 +97,8 @@ class BundleAdjuster {
   static_assert(std::is_same<Scalar, double>::value, "the engine computes in FP64 (REAL_TYPE=double)");
   static_assert(LmSize == 0 || LmSize == 1 || LmSize == 3, "LmSize must be 0, 1 or 3");
   static_assert(PoseSize == 6 || PoseSize == 9 || PoseSize == 15, "PoseSize must be 6, 9 or 15");
-  static_assert(CalibSize == 0 && !DoTvs, "calibration columns are not part of this path");
+  static_assert(CalibSize == 0, "camera-intrinsics calibration columns are not part of this path");
+  static_assert(!DoTvs || LmSize == 1, "T_vs calibration exists for inverse-depth landmarks only (parallel_algos.h:102-131)");
 
  public:
   int debug_level_threshold = 0;
@@ -104,7 +107,9 @@ class BundleAdjuster {
   static constexpr uint32_t kPrPoseDim = 6;
   static constexpr uint32_t kLmDim = LmSize;
   static constexpr uint32_t kPoseDim = PoseSize;
-  static constexpr uint32_t kCalibDim = 0;
+  static constexpr uint32_t kCalibDim = CalibSize + (DoTvs ? 6 : 0);  // reference :123-124
+  static constexpr bool kTvsInCalib = DoTvs;
+  static constexpr uint32_t kTvsOffset = CalibSize;
   static constexpr bool kVelInState = (kPoseDim >= 9);
   static constexpr bool kBiasInState = (kPoseDim >= 15);
   static constexpr bool kGravityInCalib = false;
@@ -425,8 +430,11 @@ class BundleAdjuster {
   const Delta& GetLastStep() const {  // fetched from the device on first use after a Solve()
     if (last_step_stale_ && engine_) {
       const uint32_t n = ba_hip_num_pose_params(engine_), nl = ba_hip_num_lm_params(engine_);
-      last_step_.delta_p.assign(n, 0); last_step_.delta_l.assign(nl, 0);
+      const uint32_t nk = ba_hip_num_calib_params(engine_);
+      last_step_.delta_p.assign(n + nk, 0); last_step_.delta_l.assign(nl, 0);
       ba_hip_get_step(engine_, last_step_.delta_p.data(), last_step_.delta_l.data());
+      last_step_.delta_k.assign(last_step_.delta_p.begin() + n, last_step_.delta_p.end());  // the tail (:766-769)
+      last_step_.delta_p.resize(n);
       last_step_stale_ = false;
     }
     return last_step_;
@@ -550,6 +558,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
       summary_.result = SolverError;
       return false;
     }
+    if (DoTvs && !Check(ba_hip_set_calibration(engine_, CalibSize, 1), "ba_hip_set_calibration")) return false;
     engine_device_ = options_.device;
     structure_dirty_ = true;
   }
@@ -670,12 +679,12 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
 // j_pr.txt, r_pr.txt, j_l.txt of the working directory, so that a build of the original can be
 // diffed against this one (ba_amd/dumps.py loads and cross-checks them).  j_pr.txt is
 // (2 x residuals) x (6 x active poses), j_l.txt (2 x residuals) x (LmSize x active landmarks) — dense:
-// a debug tool for small problems, as in the reference.  The calibration dumps (j_kpr.txt,
-// jt_kpr_j_kpr.txt) do not exist here: CalibSize is 0.
+// a debug tool for small problems, as in the reference.  With DoTvs s.txt / rhs.txt are the bordered
+// (n + 6) system and j_kpr.txt ((2 x residuals) x 6) and jt_kpr_j_kpr.txt (6 x 6) follow (:619-626).
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
 void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::WriteReducedCameraMatrix() {
-  const uint32_t n = ba_hip_num_pose_params(engine_);
-  std::cerr << "Writing reduced camera matrix for " << n << " pose parameters and " << kCalibDim
+  const uint32_t n_pose = ba_hip_num_pose_params(engine_), n = n_pose + ba_hip_num_calib_params(engine_);
+  std::cerr << "Writing reduced camera matrix for " << n_pose << " pose parameters and " << kCalibDim
             << " calib  parameters " << std::endl;
   auto put_row = [](FILE* f, const double* v, size_t cnt) {
     for (size_t c = 0; c < cnt; ++c) std::fprintf(f, c ? ", %.17g" : "%.17g", v[c]);
@@ -728,6 +737,21 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::WriteReducedCam
   if (fp) std::fclose(fp);
   if (fl) std::fclose(fl);
   if (fr) std::fclose(fr);
+  if (DoTvs) {
+    std::vector<double> jk(12 * O), jtj(36, 0.0);
+    if (!Check(ba_hip_get_calib_jacobians(engine_, jk.data()), "ba_hip_get_calib_jacobians")) return;
+    if (FILE* f = std::fopen("j_kpr.txt", "w")) {
+      for (size_t r = 0; r < 2 * O; ++r) put_row(f, &jk[6 * r], 6);
+      std::fclose(f);
+    }
+    for (size_t r = 0; r < 2 * O; ++r)
+      for (int x = 0; x < 6; ++x)
+        for (int y = 0; y < 6; ++y) jtj[6 * x + y] += jk[6 * r + x] * jk[6 * r + y];
+    if (FILE* f = std::fopen("jt_kpr_j_kpr.txt", "w")) {
+      for (int x = 0; x < 6; ++x) put_row(f, &jtj[6 * x], 6);
+      std::fclose(f);
+    }
+  }
 }
 
 template <typename Scalar, int LmSize, int PoseSize, int CalibSize, bool DoTvs>
@@ -840,10 +864,12 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SolveInternal(
     bool gn_computed = false;
     ba_hip_dogleg_scalars s;
     if (!Check(ba_hip_dogleg_terms(engine_, 0, &s), "ba_hip_dogleg_terms")) return false;
-    const Scalar numerator = s.rhs_p_sq + s.rhs_l_sq;        // :858
+    // the calibration terms (rhs_k, delta_k) are zero without DoTvs
+    const Scalar numerator = s.rhs_p_sq + s.rhs_l_sq + s.rhs_k_sq;  // :858-859
     const Scalar factor = numerator / s.j_rhs_sq;             // :919
-    const Scalar sd_sq = factor * factor * numerator;
-    const Scalar delta_sd_norm = std::sqrt(sd_sq);            // :928
+    const Scalar sd_sq = factor * factor * numerator;         // |delta_sd|^2 over p, k and l (:1001-1003)
+    // :927-929 — the steepest-descent norm leaves delta_k out
+    const Scalar delta_sd_norm = std::sqrt(factor * factor * (s.rhs_p_sq + s.rhs_l_sq));
     uint32_t iteration_count = 0;
     while (1) {
       iteration_count++;
@@ -865,7 +891,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SolveInternal(
           if (!Check(ba_hip_dogleg_terms(engine_, 1, &s), "ba_hip_dogleg_terms")) return false;
           gn_computed = true;
         }
-        const Scalar gn_sq = s.gn_p_sq + s.gn_l_sq;
+        const Scalar gn_sq = s.gn_p_sq + s.gn_k_sq + s.gn_l_sq;
         const Scalar delta_gn_norm = std::sqrt(gn_sq);  // :971-973
         const bool delta_gn_good = !std::isnan(delta_gn_norm) && !std::isinf(delta_gn_norm);
         if (delta_gn_good && trust_region_size_ == kTrustRegionAuto) trust_region_size_ = delta_gn_norm;
@@ -873,7 +899,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SolveInternal(
           coef_gn = 1.0;  // :985
         } else {
           // :991-1017 with sd = factor * rhs:  diff = gn - sd
-          const Scalar rhs_gn = s.rhs_gn_p + s.rhs_gn_l;
+          const Scalar rhs_gn = s.rhs_gn_p + s.rhs_gn_k + s.rhs_gn_l;
           const Scalar a = gn_sq - 2 * factor * rhs_gn + sd_sq;
           const Scalar b = 2 * (factor * rhs_gn - sd_sq);
           const Scalar c = sd_sq - trust_region_size_ * trust_region_size_;
@@ -980,6 +1006,11 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     }
   }
   if (!Check(ba_hip_end_solve(engine_), "ba_hip_end_solve")) return;  // :672-678
+  if (DoTvs && rig_->NumCams() > 0) {
+    // :72-83 moved the rig's camera 0 on every applied step (host-side copy in the engine: no transfer)
+    std::vector<double> tv(7 * (size_t)rig_->NumCams());
+    if (Check(ba_hip_get_cameras(engine_, tv.data()), "ba_hip_get_cameras")) rig_->cameras_[0]->SetPose(SE3::from7(tv.data()));
+  }
   last_step_stale_ = true;
   uploaded_once_ = true;
   proj_view_dirty_ = true;  // GetProjectionResidual re-reads the device on its next call

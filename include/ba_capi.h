@@ -43,6 +43,9 @@ typedef struct { /* ba::SolutionSummary<double> + GetErrors, reference :48-70,59
 
 void ba_default_options(ba_options* o);
 ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim);
+/* ba::BundleAdjuster<double, lm_dim, pose_dim, calib_size, do_tvs>: calib_size must be 0; do_tvs
+ * needs lm_dim 1 (the extrinsics of camera 0 become six more unknowns).  NULL otherwise. */
+ba_adjuster* ba_adjuster_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs);
 void ba_adjuster_destroy(ba_adjuster* a);
 void ba_adjuster_init(ba_adjuster* a, const ba_options* o);
 void ba_adjuster_set_gravity(ba_adjuster* a, const double g[3]);
@@ -101,6 +104,10 @@ void ba_adjuster_get_cond_errors(const ba_adjuster* a, double out2[2]);
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
 /* the engine behind the adjuster (valid after the first Solve) for the debug taps of ba_hip.h */
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a);
+/* rig()->cameras_[cam_id]->Pose(): with do_tvs camera 0 moves with every applied step */
+void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]);
+/* GetLastStep().delta_k (zeros without do_tvs) */
+void ba_adjuster_get_last_calib_step(const ba_adjuster* a, double delta_k[6]);
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);
 
 #ifdef __cplusplus

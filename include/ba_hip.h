@@ -72,6 +72,10 @@ typedef struct {
   double j_rhs_sq;             /* :906-910 denominator */
   double gn_p_sq, gn_l_sq;     /* :971-973 */
   double rhs_gn_p, rhs_gn_l;   /* dot products for a, b of :994-998 */
+  /* calibration part (ba_hip_set_calibration; zeros otherwise): |rhs_k|^2 (:859), |delta_k|^2 of
+   * the Gauss-Newton step (:972), their dot product (:997).  j_rhs_sq already includes
+   * |J_k rhs_k|^2 (:883-886, 910). */
+  double rhs_k_sq, gn_k_sq, rhs_gn_k;
 } ba_hip_dogleg_scalars;
 
 /* Norms of the step formed by ba_hip_compose_step (summary_.delta_norm is their sum,
@@ -96,6 +100,16 @@ int ba_hip_create(int lm_dim, int pose_dim, int device, void* stream, ba_hip_eng
 void ba_hip_destroy(ba_hip_engine* e);
 const char* ba_hip_last_error(const ba_hip_engine* e);
 int ba_hip_set_options(ba_hip_engine* e, const ba_hip_options* o);
+/* The reference's CalibSize / DoTvs template parameters (BundleAdjuster.h:110-134).  do_tvs != 0:
+ * the extrinsics T_vs of camera 0 become six more unknowns BEHIND the pose unknowns of the reduced
+ * system (kCalibDim = 6, kTvsOffset = 0; BundleAdjuster.cpp:316-322, 493-583): every vector the
+ * calls below size with ba_hip_num_pose_params() grows by ba_hip_num_calib_params() trailing
+ * entries (rhs, Gauss-Newton delta, step), ba_hip_get_S returns the bordered (n + 6)^2 matrix, and
+ * ba_hip_apply_step moves T_vs by exp_decoupled(T_vs, -delta_k) (:72-83) — read it back with
+ * ba_hip_get_cameras.  As in the reference a rolled-back step does NOT restore T_vs (:1060-1068).
+ * LmSize 1 only (dz_dtvs, parallel_algos.h:102-131).  calib_size > 0 (camera intrinsics) is refused:
+ * not implemented.  Structural: call before ba_hip_finalize. */
+int ba_hip_set_calibration(ba_hip_engine* e, int calib_size, int do_tvs);
 
 /* ---- problem upload (replaces the AoS graph of Types.h:41-321) -------------------- */
 /* calibu::Rig cameras: pinhole params [fx,fy,u0,v0] and T_vs (BundleAdjuster.h:259-263) */
@@ -197,10 +211,17 @@ int ba_hip_end_solve(ba_hip_engine* e);
 int ba_hip_get_poses(ba_hip_engine* e, double* t_wp7, double* v_w3, double* b6);
 int ba_hip_get_landmarks(ba_hip_engine* e, double* x_w4);
 int ba_hip_get_landmark_flags(ba_hip_engine* e, uint8_t* is_reliable, uint32_t* num_outliers);
-uint32_t ba_hip_num_pose_params(const ba_hip_engine* e);
+uint32_t ba_hip_num_pose_params(const ba_hip_engine* e);   /* PoseSize * active poses */
+uint32_t ba_hip_num_calib_params(const ba_hip_engine* e);  /* 0, or 6 with ba_hip_set_calibration(.., do_tvs) */
+/* T_vs of every camera (7 doubles each) as the engine currently holds them: the values of
+ * ba_hip_set_cameras, moved by the calibration steps applied since. */
+int ba_hip_get_cameras(ba_hip_engine* e, double* t_vs7);
 uint32_t ba_hip_num_lm_params(const ba_hip_engine* e);
 /* s_ as the reference leaves it (BundleAdjuster.cpp:473-477,587-598): dense n x n
- * row-major; block (i,j) kept only for i <= j when use_triangular_matrices */
+ * row-major (n = pose + calibration unknowns); block (i,j) kept only for i <= j when
+ * use_triangular_matrices (the calibration border counts as the last block: S_pk is kept, S_kp not,
+ * :513-518).  The vectors of get_rhs / get_delta_gn / get_step sized by the pose unknowns carry the
+ * calibration entries behind them. */
 int ba_hip_get_S(ba_hip_engine* e, double* s_nxn);
 int ba_hip_get_rhs(ba_hip_engine* e, double* rhs_p_sc, double* rhs_p, double* rhs_l);
 int ba_hip_get_delta_gn(ba_hip_engine* e, double* delta_p, double* delta_l);
@@ -216,6 +237,9 @@ int ba_hip_get_proj_residuals(ba_hip_engine* e, double* residual2);
  * Jacobian MATRIX; the host class writes the reference's j_pr.txt / j_l.txt / r_pr.txt from this
  * (write_reduced_camera_matrix, BundleAdjuster.cpp:608-616).  Any pointer may be NULL. */
 int ba_hip_get_proj_jacobians(ba_hip_engine* e, double* j_meas12, double* j_ref12, double* j_lm, double* r2);
+/* Calibration instantiations: sqrt(w) dz_dtvs (2x6) per residual id, what the reference stores in
+ * j_kpr_ (BundleAdjuster.cpp:1769-1783) and writes to j_kpr.txt (:619-622). */
+int ba_hip_get_calib_jacobians(ba_hip_engine* e, double* j_k12);
 int ba_hip_get_timers(ba_hip_engine* e, ba_hip_timers* t);
 /* Test tap for systems too large to download (S is 28.8 GB at BASELINE.json configs[3]): forms
  * || S delta_gn - rhs_p_sc || and || rhs_p_sc || ON THE DEVICE from the copy of S kept before the

@@ -1686,3 +1686,159 @@ def test_structure_built_on_device_equals_host_build(lm_dim):
     for a, b in zip(h[1:5], d[1:5]):
         assert np.array_equal(a, b)
     assert np.array_equal(h[6], d[6]) and np.array_equal(h[7], d[7]) and np.array_equal(h[8], d[8])
+
+
+# ---- camera-extrinsics calibration (DoTvs instantiations) --------------------------
+T_VS_MOUNT = np.concatenate([[0.05, -0.02, 0.1], scene.quat_exp(np.array([0.02, -0.03, 0.01]))])
+
+
+def _calib_scene(P=40, L=160, K=8, seed=2, fixed_every=3, perturb=(0.06, -0.05, 0.05, 0.02, -0.03, 0.02), po=None,
+                 **kw):
+    """A banked trajectory with the camera mounted at T_VS_MOUNT, every `fixed_every`-th vehicle
+    pose held at ground truth (T_vs observable), landmarks handed over for a wrong mount guess."""
+    sc = scene.mount_camera(scene.make_scene(P, L, K, lm_dim=1, seed=seed, roll_amp=0.6, **kw), T_VS_MOUNT)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[::fixed_every] = 0
+    sc.poses[::fixed_every] = sc.gt_poses[::fixed_every]
+    t0 = po.exp_decoupled(T_VS_MOUNT, np.asarray(perturb, dtype=np.float64))
+    sc.landmarks = scene.remount_landmarks(sc, T_VS_MOUNT, t0)
+    return sc, pa, t0
+
+
+def _calib_pair(po, sc, pa, t0, pose_dim=6, imu=False, **kw):
+    o = po.OracleBundleAdjuster(1, pose_dim, do_tvs=True)
+    o.Init(gn_options(po, **kw))
+    h = adjuster.BundleAdjuster(1, pose_dim, do_tvs=True)
+    h.Init(hip_options(**kw))
+    for b in (o, h):
+        if imu:
+            b.SetGravity(sc.gravity)
+        b.AddCamera(sc.cam_params, t0)
+        b.add_poses(sc.poses, v_w=getattr(sc, "init_vel", None), b=getattr(sc, "init_bias", None), is_active=pa,
+                    time=getattr(sc, "pose_time", None))
+        b.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+        b.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+        if imu:
+            for i in range(sc.num_poses - 1):
+                b.AddImuResidual(i, i + 1, sc.imu_meas[i])
+    return o, h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("triangular", [1, 0])
+def test_calibration_reduced_system_and_step(oracle_lib, triangular):
+    """The bordered (n + 6) system of BundleAdjuster.cpp:493-583 — dz_dtvs per residual, S_pk, S_kk,
+    rhs_k before and after the Schur complement — and the Gauss-Newton step [delta_p ; delta_k],
+    delta_l against the oracle."""
+    po = oracle_lib
+    sc, pa, t0 = _calib_scene(P=30, L=90, K=6, seed=7, po=po)
+    o, h = _calib_pair(po, sc, pa, t0, apply_results=0, use_triangular_matrices=triangular)
+    o.Solve(1)
+    h.Solve(1)
+    n = o.num_pose_params()
+    assert h.num_pose_params() == n and h.engine().num_calib_params() == 6
+    w = np.sqrt(o.proj_weights())[:, None, None]
+    assert rel_err(h.proj_tvs_jacobians(), w * o.proj_tvs_jacobians()) < 1e-11
+    So, Sh = o.S(), h.S()
+    assert Sh.shape == (n + 6, n + 6)
+    assert rel_err(Sh[:n, :n], So[:n, :n]) < 1e-12
+    assert rel_err(Sh[:n, n:], So[:n, n:]) < 1e-11 and np.abs(So[:n, n:]).max() > 1
+    assert rel_err(Sh[n:, n:], So[n:, n:]) < 1e-11
+    assert rel_err(Sh[n:, :n], So[n:, :n]) < 1e-11 if not triangular else np.all(Sh[n:, :n] == 0)
+    assert rel_err(h.rhs(), o.rhs()) < 1e-11
+    assert rel_err(h.rhs_k(), o.rhs_k()) < 1e-11
+    assert rel_err(h.delta_p(), o.delta_p()) < 1e-8
+    assert rel_err(h.delta_k(), o.delta_k()) < 1e-8
+    assert rel_err(h.delta_l(), o.delta_l()) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_dogleg", [0, 1])
+def test_calibration_iterations_track_oracle_and_recover_the_mount(oracle_lib, use_dogleg):
+    """Six iterations from a wrong T_vs: per-iteration summaries, the rig's camera pose, poses and
+    landmarks follow the oracle, and T_vs ends close to the mount the scene was rendered with."""
+    po = oracle_lib
+    sc, pa, t0 = _calib_scene(po=po, outlier_frac=0.0, pixel_sigma=0.3)
+    o, h = _calib_pair(po, sc, pa, t0, use_dogleg=use_dogleg)
+    err0 = np.linalg.norm(po.log_decoupled(t0, T_VS_MOUNT))
+    for it in range(6):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result, it
+        assert abs(so.proj_error - sh.proj_error) < 1e-7 * so.proj_error, it
+        assert abs(so.delta_norm - sh.delta_norm) < 1e-6 * max(so.delta_norm, 1e-12), it
+        if use_dogleg:
+            assert abs(so.trust_region_size - sh.trust_region_size) <= 1e-7 * abs(so.trust_region_size)
+        assert rel_err(h.camera_pose(0), o.camera_pose(0)) < 1e-8, it
+    to, _, _ = o.poses()
+    th, _, _ = h.poses()
+    assert rel_err(th, to) < 1e-7
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-7
+    err = np.linalg.norm(po.log_decoupled(h.camera_pose(0), T_VS_MOUNT))
+    assert err < 0.2 * err0, (err0, err)
+
+
+@pytest.mark.gpu
+def test_calibration_multi_iteration_solve_and_rejected_step(oracle_lib):
+    """Solve(4) in one call equals the oracle's; then an overshooting step (gn_damping 40) is rejected:
+    poses and landmarks are restored, T_vs keeps the rejected update exactly as in the reference
+    (BundleAdjuster.cpp:72-83 is outside the copies restored at :1139-1149)."""
+    po = oracle_lib
+    sc, pa, t0 = _calib_scene(P=30, L=90, K=6, seed=11, po=po)
+    o, h = _calib_pair(po, sc, pa, t0)
+    o.Solve(4)
+    h.Solve(4)
+    assert o.summary().iterations_run == h.summary().iterations_run
+    assert rel_err(h.camera_pose(0), o.camera_pose(0)) < 1e-8
+    before_o, before_h = o.camera_pose(0).copy(), h.camera_pose(0).copy()
+    po_before, _, _ = h.poses()
+    o.Solve(1, 40.0)
+    h.Solve(1, 40.0)
+    assert adjuster.RESULT_NAMES[h.summary().result] == "ErrorIncreased"
+    assert o.summary().result == h.summary().result
+    po_after, _, _ = h.poses()
+    assert rel_err(po_after, po_before) < 1e-12                        # poses restored
+    assert np.linalg.norm(o.camera_pose(0) - before_o) > 1e-6           # the oracle's T_vs moved ...
+    assert rel_err(h.camera_pose(0) - before_h, o.camera_pose(0) - before_o) < 1e-5  # ... and so did ours, alike
+
+
+@pytest.mark.gpu
+def test_calibration_with_inertial_residuals(oracle_lib):
+    """<1, 15, 0, true> — the reference's visual-inertial self-calibration instantiation
+    (BundleAdjuster.cpp:1816-1822 with CalibSize 0): the border couples to 15-wide pose blocks."""
+    po = oracle_lib
+    P = 30
+    sc = scene.make_scene(P, 90, 6, lm_dim=1, seed=5)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)  # the IMU of the synthetic scene sits in the camera frame:
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])        # the true mount is the identity
+    pa = np.ones(P, dtype=np.uint8)
+    pa[0] = 0
+    t0 = po.exp_decoupled(ident, np.array([0.02, -0.02, 0.02, 0.01, -0.01, 0.01]))
+    sc.landmarks = scene.remount_landmarks(sc, ident, t0)
+    o, h = _calib_pair(po, sc, pa, t0, pose_dim=15, imu=True)
+    for it in range(3):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result
+        assert abs(so.proj_error - sh.proj_error) < 1e-6 * so.proj_error
+        assert abs(so.inertial_error - sh.inertial_error) < 1e-6 * max(so.inertial_error, 1e-9)
+        assert rel_err(h.camera_pose(0), o.camera_pose(0)) < 1e-7
+    to, vo, bo = o.poses()
+    th, vh, bh = h.poses()
+    assert rel_err(th, to) < 1e-6 and rel_err(vh, vo) < 1e-5
+
+
+@pytest.mark.gpu
+def test_calibration_engine_refuses_what_it_does_not_implement():
+    eng = hipapi.Engine(3, 6)
+    with pytest.raises(hipapi.HipError):
+        eng.set_calibration(0, True)      # dz_dtvs exists for LmSize 1 only
+    eng.close()
+    eng = hipapi.Engine(1, 6)
+    with pytest.raises(hipapi.HipError):
+        eng.set_calibration(5, False)     # camera intrinsics: not implemented
+    eng.close()
+    with pytest.raises(ValueError):
+        adjuster.BundleAdjuster(3, 6, do_tvs=True)

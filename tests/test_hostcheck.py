@@ -86,6 +86,41 @@ def test_projection_jacobians_of_the_kernels_match_the_oracle(oracle_lib, hc, lm
     assert worst < 1e-11, worst
 
 
+def test_extrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc):
+    """dz_dtvs (DoTvs instantiations): the closed form of dmath.h proj_linearize<1, true> against the
+    oracle's chain of parallel_algos.h:120-131."""
+    po = oracle_lib
+    sc = scene.make_scene(30, 60, 5, lm_dim=1, seed=19)
+    t_vs = np.concatenate([[0.05, -0.02, 0.1], scene.quat_exp(np.array([0.2, -0.3, 0.1]))])
+    o = po.OracleBundleAdjuster(1, 6, do_tvs=True)
+    o.Init(gn_options(po, apply_results=0))
+    o.AddCamera(sc.cam_params, t_vs)
+    o.add_poses(sc.poses)
+    o.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    o.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    o.Solve(1)
+    jk_o = o.proj_tvs_jacobians()
+    acc = accepted_obs(sc)
+    cam = np.asarray(sc.cam_params, dtype=np.float64)
+    nsel = sc.obs_per_landmark + 1
+    zs = [sc.obs_z[i] for i in range(len(sc.obs_pose)) if i % nsel != 0]
+    worst = 0.0
+    for rid, (pm, pr, l) in enumerate(acc):
+        xw = np.asarray(sc.landmarks[l], dtype=np.float64)
+        t_sw = po.se3_inv(po.se3_mul(np.asarray(sc.poses[pr], dtype=np.float64), t_vs))
+        p = scene.quat_to_rot(t_sw[3:]) @ xw[:3] + t_sw[:3] * xw[3]
+        nrm = np.linalg.norm(p)
+        x = np.concatenate([p / nrm, [xw[3] / nrm]])
+        jk = np.zeros(12)
+        hc.ba_hostcheck_proj_tvs_jacobian(
+            _dp(cam), _dp(np.asarray(zs[rid], dtype=np.float64)), _dp(x),
+            _dp(np.asarray(sc.poses[pm], dtype=np.float64)), _dp(t_vs),
+            _dp(np.asarray(sc.poses[pr], dtype=np.float64)), _dp(t_vs), 0, _dp(jk))
+        worst = max(worst, rel_err(jk, jk_o[rid].ravel()))
+    assert len(acc) > 100 and np.abs(jk_o).max() > 10
+    assert worst < 1e-11, worst
+
+
 def test_unary_and_binary_blocks_of_the_kernels_match_the_oracle(oracle_lib, hc):
     po = oracle_lib
     rng = np.random.default_rng(5)
