@@ -38,7 +38,8 @@ class BaOptions(C.Structure):
                 ("use_robust_norm_for_proj_residuals", C.c_int32),
                 ("use_robust_norm_for_inertial_residuals", C.c_int32),
                 ("write_reduced_camera_matrix", C.c_int32),
-                ("device", C.c_int32), ("factorization_pivot_tolerance", C.c_double)]
+                ("device", C.c_int32), ("factorization_pivot_tolerance", C.c_double),
+                ("calculate_calibration_marginals", C.c_int32), ("reserved", C.c_int32)]
 
 
 class BaSummary(C.Structure):
@@ -65,7 +66,7 @@ SYMBOLS = [
     "ba_adjuster_get_projection_residual", "ba_adjuster_get_imu_residual",
     "ba_adjuster_get_summary", "ba_adjuster_get_cond_errors", "ba_adjuster_get_timers", "ba_adjuster_engine",
     "ba_adjuster_set_allreduce", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
-    "ba_adjuster_get_last_calib_step",
+    "ba_adjuster_get_last_calib_step", "ba_adjuster_get_calibration_marginals",
 ]
 
 _lib = None
@@ -344,6 +345,13 @@ class BundleAdjuster:
 
     def proj_tvs_jacobians(self):
         return self.engine().get_calib_jacobians(self.GetNumProjResiduals())
+
+    def calibration_marginals(self):
+        """SolutionSummary::calibration_marginals (empty without the option / without do_tvs)."""
+        c = np.zeros(36)
+        self.L.ba_adjuster_get_calibration_marginals.restype = C.c_uint32
+        k = self.L.ba_adjuster_get_calibration_marginals(self.h, c.ctypes.data_as(C.POINTER(C.c_double)))
+        return c[:k * k].reshape(k, k)
 
     def camera_pose(self, cam_id=0):
         """rig()->cameras_[cam_id]->Pose()"""

@@ -40,6 +40,7 @@ struct Iface {
   virtual void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) = 0;
   virtual void camera_pose(uint32_t cam, double* t7) const = 0;
   virtual void last_calib_step(double* d6) const = 0;
+  virtual uint32_t marginals(double* cov) const = 0;
 };
 
 template <int LM, int PD, bool TVS = false>
@@ -66,6 +67,7 @@ struct Impl : Iface {
     opt.keep_reduced_system = o->write_reduced_camera_matrix != 0;
     opt.device = o->device;
     opt.factorization_pivot_tolerance = o->factorization_pivot_tolerance;
+    opt.calculate_calibration_marginals = o->calculate_calibration_marginals != 0;
     ba.Init(opt);
   }
   void set_gravity(const double* g) override { ba.SetGravity(ba::Vector3t({g[0], g[1], g[2]})); }
@@ -174,6 +176,11 @@ struct Impl : Iface {
     ba.SetAllReduce(fn, ctx, rank, nranks);
   }
   void camera_pose(uint32_t cam, double* t7) const override { ba.rig()->cameras_[cam]->Pose().to7(t7); }
+  uint32_t marginals(double* cov) const override {
+    const ba::MatX& m = ba.GetSolutionSummary().calibration_marginals;
+    for (int i = 0; i < m.rows() * m.cols(); ++i) cov[i] = m.data()[i];
+    return (uint32_t)m.rows();
+  }
   void last_calib_step(double* d6) const override {
     const auto& d = ba.GetLastStep().delta_k;
     for (size_t i = 0; i < 6; ++i) d6[i] = i < d.size() ? d[i] : 0.0;
@@ -216,6 +223,8 @@ void ba_default_options(ba_options* o) {
   o->write_reduced_camera_matrix = d.write_reduced_camera_matrix ? 2 : (d.keep_reduced_system ? 1 : 0);
   o->device = d.device;
   o->factorization_pivot_tolerance = d.factorization_pivot_tolerance;
+  o->calculate_calibration_marginals = d.calculate_calibration_marginals;
+  o->reserved = 0;
 }
 ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim) { return ba_adjuster_create_calib(lm_dim, pose_dim, 0, 0); }
 ba_adjuster* ba_adjuster_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs) {
@@ -286,6 +295,7 @@ void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t) { a->p->time
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a) { return a->p->engine(); }
 void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]) { a->p->camera_pose(cam_id, t_vs); }
 void ba_adjuster_get_last_calib_step(const ba_adjuster* a, double delta_k[6]) { a->p->last_calib_step(delta_k); }
+uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[36]) { return a->p->marginals(cov); }
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) { a->p->set_allreduce(fn, ctx, rank, nranks); }
 
 }  // extern "C"

@@ -238,5 +238,6 @@ int dist_broadcast(Engine* e, double* buf, size_t count, int root, hipStream_t s
 void comm_release(Engine* e);
 int check_solve_residual(Engine* e, const double* dS, const double* dx, const double* db, double* out2);
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz);
+int trailing_marginals(Engine* e, const double* dA, uint32_t ld, uint32_t first, uint32_t K, double* cov);
 
 }  // namespace bae

@@ -964,6 +964,15 @@ int ba_hip_set_calibration(ba_hip_engine* h, int calib_size, int do_tvs) {
   e->finalized = false;
   return 0;
 }
+int ba_hip_get_calibration_marginals(ba_hip_engine* h, double* cov) {
+  ENG(h);
+  NEED_FINAL();
+  if (!e->st.K) return e->fail_msg("no calibration columns (ba_hip_set_calibration)");
+  if (!e->factored) return e->fail_msg("ba_hip_get_calibration_marginals needs the factor of the last ba_hip_solve_gn");
+  if (dist_solve_enabled(e)) return e->fail_msg("calibration marginals: not available with the distributed solve");
+  BAE_HIP(hipSetDevice(e->device));
+  return trailing_marginals(e, e->A.p, e->st.ld, e->st.np, e->st.K, cov);
+}
 int ba_hip_get_cameras(ba_hip_engine* h, double* t_vs7) {
   ENG(h);
   const std::vector<double>& t = e->prob.cam_tvs;

@@ -1488,6 +1488,50 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
 
 // Solve on the padded lower storage dA ((n_pad + 1) x ld, n_pad = ld multiple of 64; the
 // rhs is row n_pad).  dx receives n_pad doubles (the first n are the solution).
+// Marginal covariance of the trailing K unknowns from the factor left by cholesky_solve:
+// (S^-1)_kk = G^T D_k G with G = (L_kk)^-1, the inverse of the K x K diagonal block of L (the rows
+// behind it are padding and decoupled).  The diagonal tiles of L exist as their inverse-transposes
+// (linvT); when the K rows straddle a tile boundary, G = [[Ga, 0], [-Gb L_ba Ga, Gb]] with the
+// off-diagonal piece L_ba read from the factorised A.  Replaces the K extra solves with unit vectors
+// of BundleAdjuster.cpp:771-784 (same numbers: the unit vectors only excite these rows).
+int trailing_marginals(Engine* e, const double* dA, uint32_t ld, uint32_t first, uint32_t K, double* cov) {
+  const uint32_t nblk = ld / NB;
+  if (!e->invdiag.p || first + K > ld) return e->fail_msg("no factor to read the marginals from");
+  const double* dsgn = e->invdiag.p;
+  const double* linvT = dsgn + (size_t)nblk * NB;
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  const uint32_t t = first / NB, o = first % NB;
+  const uint32_t a = std::min(K, NB - o), b = K - a;  // rows in tile t / in tile t + 1
+  std::vector<double> G((size_t)K * K, 0.0), sg(K), tile((size_t)NB * NB);
+  BAE_HIP(hipMemcpy(sg.data(), dsgn + first, K * sizeof(double), hipMemcpyDeviceToHost));
+  BAE_HIP(hipMemcpy(tile.data(), linvT + (size_t)t * NB * NB, tile.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (uint32_t r = 0; r < a; ++r)
+    for (uint32_t c = 0; c <= r; ++c) G[(size_t)r * K + c] = tile[(size_t)(o + c) * NB + (o + r)];  // L^-1[r][c] = L^-T[c][r]
+  if (b) {
+    BAE_HIP(hipMemcpy(tile.data(), linvT + (size_t)(t + 1) * NB * NB, tile.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < b; ++r)
+      for (uint32_t c = 0; c <= r; ++c) G[(size_t)(a + r) * K + a + c] = tile[(size_t)c * NB + r];
+    std::vector<double> Lba((size_t)b * a);
+    BAE_HIP(hipMemcpy2D(Lba.data(), a * sizeof(double), dA + (size_t)(t + 1) * NB * ld + (size_t)t * NB + o,
+                        ld * sizeof(double), a * sizeof(double), b, hipMemcpyDeviceToHost));
+    // -Gb Lba Ga
+    for (uint32_t r = 0; r < b; ++r)
+      for (uint32_t c = 0; c < a; ++c) {
+        double s = 0.0;
+        for (uint32_t x = 0; x < b; ++x)
+          for (uint32_t y = 0; y < a; ++y) s += G[(size_t)(a + r) * K + a + x] * Lba[(size_t)x * a + y] * G[(size_t)y * K + c];
+        G[(size_t)(a + r) * K + c] = -s;
+      }
+  }
+  for (uint32_t r = 0; r < K; ++r)
+    for (uint32_t c = 0; c < K; ++c) {
+      double s = 0.0;
+      for (uint32_t j = 0; j < K; ++j) s += G[(size_t)j * K + r] * sg[j] * G[(size_t)j * K + c];
+      cov[(size_t)r * K + c] = s;
+    }
+  return 0;
+}
+
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status,
                    const uint8_t* nz) {
   (void)n;

@@ -84,7 +84,7 @@ SYMBOLS = [
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
     "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set", "ba_hip_set_conditioning_residuals",
     "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host", "ba_hip_get_proj_jacobians",
-    "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians",
+    "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians", "ba_hip_get_calibration_marginals",
 ]
 
 
@@ -282,6 +282,12 @@ class Engine:
     def set_calibration(self, calib_size=0, do_tvs=True):
         """CalibSize / DoTvs of the reference's class template; before finalize()."""
         self._chk(self.L.ba_hip_set_calibration(self.h, int(calib_size), int(do_tvs)))
+
+    def get_calibration_marginals(self):
+        k = self.num_calib_params()
+        c = np.empty((k, k))
+        self._chk(self.L.ba_hip_get_calibration_marginals(self.h, _p(c, dp)))
+        return c
 
     def get_cameras(self, n):
         t = np.empty((n, 7))

@@ -55,6 +55,7 @@ struct SolutionSummary {  // reference BundleAdjuster.h:48-70
   Scalar delta_norm = 0;
   Scalar pre_solve_norm = 0;
   Scalar post_solve_norm = 0;
+  MatX calibration_marginals;  // kCalibDim x kCalibDim block of S^-1 (Options::calculate_calibration_marginals)
   OptimizationResult result = Success;
   bool IsResultGood() const { return (result != SolverError) && (result != FactorizationError); }
 };
@@ -485,6 +486,13 @@ class BundleAdjuster {
   void ComputeMasks(std::vector<uint16_t>& masks);
   void WriteReducedCameraMatrix();
   bool SolveInternal(const Scalar gn_damping, const bool error_increase_allowed, const bool use_dogleg);
+  // reference BundleAdjuster.cpp:771-784 (inside CalculateGn, only with active poses)
+  bool FetchCalibrationMarginals() {
+    if (!DoTvs || !options_.calculate_calibration_marginals || num_active_poses_ == 0) return true;
+    summary_.calibration_marginals = MatX((int)kCalibDim, (int)kCalibDim);
+    return Check(ba_hip_get_calibration_marginals(engine_, summary_.calibration_marginals.data()),
+                 "ba_hip_get_calibration_marginals");
+  }
   bool DownloadState();
 
   // ---- problem graph, flat (ids = insertion order, as the reference returns them) ----
@@ -887,6 +895,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SolveInternal(
             if (rc < 0) { Check(rc, "ba_hip_solve_gn"); return false; }
             if (rc == BA_HIP_FACTORIZATION_ERROR) { summary_.result = FactorizationError; return false; }
             if (rc == BA_HIP_SOLVER_ERROR) { summary_.result = SolverError; return false; }
+            if (!FetchCalibrationMarginals()) return false;
           }
           if (!Check(ba_hip_dogleg_terms(engine_, 1, &s), "ba_hip_dogleg_terms")) return false;
           gn_computed = true;
@@ -937,6 +946,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SolveInternal(
       if (rc < 0) { Check(rc, "ba_hip_solve_gn"); return false; }
       if (rc == BA_HIP_FACTORIZATION_ERROR) { summary_.result = FactorizationError; return false; }
       if (rc == BA_HIP_SOLVER_ERROR) { summary_.result = SolverError; return false; }
+      if (!FetchCalibrationMarginals()) return false;
     }
     if (!Check(ba_hip_compose_step(engine_, 0.0, gn_damping, &norms), "ba_hip_compose_step")) return false;  // :1108-1110
     if (!Check(ba_hip_eval_residuals(engine_, &pre), "ba_hip_eval_residuals")) return false;

@@ -50,6 +50,19 @@ struct Mat {
   static Mat Identity() { Mat a; for (int i = 0; i < (R < C ? R : C); ++i) a.m[i * C + i] = 1.0; return a; }
   double norm() const { double s = 0; for (int i = 0; i < R * C; ++i) s += m[i] * m[i]; return std::sqrt(s); }
 };
+// Run-time sized row-major matrix (SolutionSummary::calibration_marginals is a MatrixXt in the reference)
+struct MatX {
+  int nr = 0, nc = 0;
+  std::vector<double> m;
+  MatX() {}
+  MatX(int r, int c) : nr(r), nc(c), m((size_t)r * c, 0.0) {}
+  int rows() const { return nr; }
+  int cols() const { return nc; }
+  double& operator()(int r, int c) { return m[(size_t)r * nc + c]; }
+  double operator()(int r, int c) const { return m[(size_t)r * nc + c]; }
+  double* data() { return m.data(); }
+  const double* data() const { return m.data(); }
+};
 typedef Mat<2> Vector2t;
 typedef Mat<3> Vector3t;
 typedef Mat<4> Vector4t;

@@ -29,6 +29,8 @@ typedef struct { /* ba::Options<double>, reference BundleAdjuster.h:72-107 */
                                           (the reference's dump, BundleAdjuster.cpp:600-606) */
   int32_t device;
   double factorization_pivot_tolerance; /* extension, 0 = off: ba::Options::factorization_pivot_tolerance */
+  int32_t calculate_calibration_marginals; /* reference BundleAdjuster.h:95 (do_tvs adjusters) */
+  int32_t reserved;
 } ba_options;
 
 typedef struct { /* ba::SolutionSummary<double> + GetErrors, reference :48-70,593-602 */
@@ -106,6 +108,9 @@ void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a);
 /* rig()->cameras_[cam_id]->Pose(): with do_tvs camera 0 moves with every applied step */
 void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]);
+/* SolutionSummary::calibration_marginals (6 x 6, row-major) of the last iteration; returns its
+ * dimension (0 when the option was off or the adjuster has no calibration unknowns) */
+uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[36]);
 /* GetLastStep().delta_k (zeros without do_tvs) */
 void ba_adjuster_get_last_calib_step(const ba_adjuster* a, double delta_k[6]);
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);

@@ -213,6 +213,10 @@ int ba_hip_get_landmarks(ba_hip_engine* e, double* x_w4);
 int ba_hip_get_landmark_flags(ba_hip_engine* e, uint8_t* is_reliable, uint32_t* num_outliers);
 uint32_t ba_hip_num_pose_params(const ba_hip_engine* e);   /* PoseSize * active poses */
 uint32_t ba_hip_num_calib_params(const ba_hip_engine* e);  /* 0, or 6 with ba_hip_set_calibration(.., do_tvs) */
+/* Options::calculate_calibration_marginals (BundleAdjuster.cpp:771-784): the K x K block of S^-1
+ * that belongs to the calibration unknowns (row-major), from the factor left by the last
+ * ba_hip_solve_gn — no extra solves.  Replicated / single-shard solve only. */
+int ba_hip_get_calibration_marginals(ba_hip_engine* e, double* cov_kxk);
 /* T_vs of every camera (7 doubles each) as the engine currently holds them: the values of
  * ba_hip_set_cameras, moved by the calibration steps applied since. */
 int ba_hip_get_cameras(ba_hip_engine* e, double* t_vs7);

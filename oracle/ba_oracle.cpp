@@ -1757,6 +1757,21 @@ void orc_get_delta_k(const orc_ba* h, double* d) {
 }
 void orc_get_rhs_k(const orc_ba* h, double* r) { memcpy(r, h->rhs_k_.data(), h->rhs_k_.size() * 8); }
 void orc_get_camera_pose(const orc_ba* h, uint32_t cam_id, double t_vs[7]) { se3_to7(h->rig_[cam_id].t_vs, t_vs); }
+// SolutionSummary::calibration_marginals (BundleAdjuster.cpp:771-784): solves with the unit vectors
+// of the calibration unknowns, bottom-right block.  Formed on request from the s_ of the last
+// iteration (the reference forms it inside CalculateGn when the option is set: same matrix).
+int orc_get_calibration_marginals(const orc_ba* h, double* cov) {
+  const uint32_t K = h->kCalibDim, nt = h->num_active_poses_ * h->kPoseDim + K;
+  if (K == 0 || h->s_.size() != (size_t)nt * nt) return 0;
+  std::vector<double> unit(nt), x(nt);
+  for (uint32_t i = 0; i < K; ++i) {
+    std::fill(unit.begin(), unit.end(), 0.0);
+    unit[nt - K + i] = 1.0;
+    ldlt_solve_upper(nt, h->s_.data(), unit.data(), x.data());
+    for (uint32_t r = 0; r < K; ++r) cov[(size_t)r * K + i] = x[nt - K + r];
+  }
+  return (int)K;
+}
 void orc_get_proj_tvs_jacobians(const orc_ba* h, double* j_tvs) {
   for (size_t i = 0; i < h->proj_residuals_.size(); ++i)
     memcpy(j_tvs + 12 * i, h->proj_residuals_[i].dz_dtvs.a, 12 * 8);

@@ -128,6 +128,7 @@ void orc_get_delta_k(const orc_ba* h, double* d);        /* applied calibration 
 void orc_get_rhs_k(const orc_ba* h, double* r);          /* rhs_k_ (before Schur) */
 void orc_get_camera_pose(const orc_ba* h, uint32_t cam_id, double t_vs[7]);
 void orc_get_proj_tvs_jacobians(const orc_ba* h, double* j_tvs); /* dz_dtvs 2x6 per residual id */
+int orc_get_calibration_marginals(const orc_ba* h, double* cov_kxk); /* returns kCalibDim */
 void orc_get_proj_weights(const orc_ba* h, double* w);   /* per residual id */
 void orc_get_proj_residuals(const orc_ba* h, double* r2);/* per residual id, 2 each */
 void orc_get_imu_residuals(const orc_ba* h, double* r15);/* ImuResidualT::residual, 15 each (first PoseSize used) */

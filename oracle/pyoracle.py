@@ -295,6 +295,12 @@ class OracleBundleAdjuster:
         self.L.orc_get_camera_pose(self.h, int(cam_id), _dp(t))
         return t
 
+    def calibration_marginals(self):
+        k = self.num_calib_params()
+        c = np.empty((k, k))
+        self.L.orc_get_calibration_marginals(self.h, _dp(c))
+        return c
+
     def proj_tvs_jacobians(self):
         j = np.empty((self.GetNumProjResiduals(), 2, 6))
         self.L.orc_get_proj_tvs_jacobians(self.h, _dp(j))

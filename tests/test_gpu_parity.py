@@ -1842,3 +1842,25 @@ def test_calibration_engine_refuses_what_it_does_not_implement():
     eng.close()
     with pytest.raises(ValueError):
         adjuster.BundleAdjuster(3, 6, do_tvs=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [30, 32], ids=["one_tile", "straddling_tiles"])
+def test_calibration_marginals(oracle_lib, P):
+    """Options::calculate_calibration_marginals (BundleAdjuster.cpp:771-784): the T_vs block of S^-1,
+    read from the factor (no extra solves) — against the oracle's six unit-vector solves and a dense
+    inverse.  P = 32 with every third pose fixed: 21 active poses, n = 126 = 64 + 62, the six
+    calibration rows straddle a tile boundary of the factor."""
+    po = oracle_lib
+    sc, pa, t0 = _calib_scene(P=P, L=90, K=6, seed=7, po=po)
+    o, h = _calib_pair(po, sc, pa, t0, apply_results=0, use_triangular_matrices=0, calculate_calibration_marginals=1)
+    o.Solve(1)
+    h.Solve(1)
+    n = o.num_pose_params()
+    if P == 32:
+        assert n % 64 > 58
+    cov_h, cov_o = h.calibration_marginals(), o.calibration_marginals()
+    assert cov_h.shape == (6, 6)
+    assert rel_err(cov_h, cov_o) < 1e-7
+    assert rel_err(cov_h, np.linalg.inv(o.S())[n:, n:]) < 1e-6
+    assert np.all(np.linalg.eigvalsh(0.5 * (cov_h + cov_h.T)) > 0)
