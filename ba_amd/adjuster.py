@@ -66,7 +66,7 @@ SYMBOLS = [
     "ba_adjuster_get_projection_residual", "ba_adjuster_get_imu_residual",
     "ba_adjuster_get_summary", "ba_adjuster_get_cond_errors", "ba_adjuster_get_timers", "ba_adjuster_engine",
     "ba_adjuster_set_allreduce", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
-    "ba_adjuster_get_last_calib_step", "ba_adjuster_get_calibration_marginals",
+    "ba_adjuster_get_last_calib_step", "ba_adjuster_get_calibration_marginals", "ba_adjuster_get_camera_params",
 ]
 
 _lib = None
@@ -123,12 +123,12 @@ class _EngineView(hipapi.Engine):
 class BundleAdjuster:
     """ba::BundleAdjuster<double, lm_dim, pose_dim, 0, do_tvs> on the MI355X engine."""
 
-    def __init__(self, lm_dim=1, pose_dim=6, do_tvs=False):
+    def __init__(self, lm_dim=1, pose_dim=6, do_tvs=False, calib_size=0):
         self.L = lib()
-        self.lm_dim, self.pose_dim, self.do_tvs = lm_dim, pose_dim, bool(do_tvs)
-        self.h = C.c_void_p(self.L.ba_adjuster_create_calib(lm_dim, pose_dim, 0, int(do_tvs)))
+        self.lm_dim, self.pose_dim, self.do_tvs, self.calib_size = lm_dim, pose_dim, bool(do_tvs), int(calib_size)
+        self.h = C.c_void_p(self.L.ba_adjuster_create_calib(lm_dim, pose_dim, int(calib_size), int(do_tvs)))
         if not self.h:
-            raise ValueError("unsupported (lm_dim, pose_dim, do_tvs)")
+            raise ValueError("unsupported (lm_dim, pose_dim, calib_size, do_tvs)")
         self._cb = None
 
     def __del__(self):
@@ -352,6 +352,17 @@ class BundleAdjuster:
         self.L.ba_adjuster_get_calibration_marginals.restype = C.c_uint32
         k = self.L.ba_adjuster_get_calibration_marginals(self.h, c.ctypes.data_as(C.POINTER(C.c_double)))
         return c[:k * k].reshape(k, k)
+
+    def camera_params(self, cam_id=0):
+        """rig()->cameras_[cam_id]->GetParams()"""
+        p = np.empty(4)
+        self.L.ba_adjuster_get_camera_params(self.h, int(cam_id), p.ctypes.data_as(C.POINTER(C.c_double)))
+        return p
+
+    def proj_calib_jacobians(self):
+        """sqrt(w) dz_dk per residual id in the j_kpr_ layout, 2 x kCalibDim."""
+        e = self.engine()
+        return e.get_calib_jacobians(self.GetNumProjResiduals())[:, :, :e.num_calib_params()]
 
     def camera_pose(self, cam_id=0):
         """rig()->cameras_[cam_id]->Pose()"""

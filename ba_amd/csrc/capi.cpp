@@ -39,13 +39,14 @@ struct Iface {
   virtual ba_hip_engine* engine() = 0;
   virtual void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) = 0;
   virtual void camera_pose(uint32_t cam, double* t7) const = 0;
+  virtual void camera_params(uint32_t cam, double* p4) const = 0;
   virtual void last_calib_step(double* d6) const = 0;
   virtual uint32_t marginals(double* cov) const = 0;
 };
 
-template <int LM, int PD, bool TVS = false>
+template <int LM, int PD, bool TVS = false, int CS = 0>
 struct Impl : Iface {
-  typedef ba::BundleAdjuster<double, LM, PD, 0, TVS> BA;
+  typedef ba::BundleAdjuster<double, LM, PD, CS, TVS> BA;
   BA ba;
   void init(const ba_options* o) override {
     ba::Options<double> opt;
@@ -176,6 +177,10 @@ struct Impl : Iface {
     ba.SetAllReduce(fn, ctx, rank, nranks);
   }
   void camera_pose(uint32_t cam, double* t7) const override { ba.rig()->cameras_[cam]->Pose().to7(t7); }
+  void camera_params(uint32_t cam, double* p4) const override {
+    const ba::Vector4t p = ba.rig()->cameras_[cam]->GetParams();
+    for (int i = 0; i < 4; ++i) p4[i] = p[i];
+  }
   uint32_t marginals(double* cov) const override {
     const ba::MatX& m = ba.GetSolutionSummary().calibration_marginals;
     for (int i = 0; i < m.rows() * m.cols(); ++i) cov[i] = m.data()[i];
@@ -187,7 +192,14 @@ struct Impl : Iface {
   }
 };
 
-Iface* make(int lm, int pd, int do_tvs) {
+Iface* make(int lm, int pd, int do_tvs, int calib_size) {
+  // CalibSize 4 = the pinhole parameters of camera 0 (LmSize 1, without DoTvs)
+  if (calib_size == 4 && !do_tvs && lm == 1) {
+    if (pd == 6) return new Impl<1, 6, false, 4>();
+    if (pd == 9) return new Impl<1, 9, false, 4>();
+    if (pd == 15) return new Impl<1, 15, false, 4>();
+  }
+  if (calib_size != 0) return nullptr;
 #define CASE(L, P) if (lm == L && pd == P && !do_tvs) return new Impl<L, P>()
   CASE(0, 6); CASE(0, 9); CASE(0, 15); CASE(1, 6); CASE(1, 9); CASE(1, 15);
   CASE(3, 6); CASE(3, 9); CASE(3, 15);
@@ -228,8 +240,7 @@ void ba_default_options(ba_options* o) {
 }
 ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim) { return ba_adjuster_create_calib(lm_dim, pose_dim, 0, 0); }
 ba_adjuster* ba_adjuster_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs) {
-  if (calib_size != 0) return nullptr;
-  Iface* p = make(lm_dim, pose_dim, do_tvs);
+  Iface* p = make(lm_dim, pose_dim, do_tvs, calib_size);
   if (!p) return nullptr;
   ba_adjuster* a = new ba_adjuster();
   a->p = p;
@@ -294,6 +305,7 @@ void ba_adjuster_get_summary(const ba_adjuster* a, ba_summary* s) { a->p->summar
 void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t) { a->p->timers(t); }
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a) { return a->p->engine(); }
 void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]) { a->p->camera_pose(cam_id, t_vs); }
+void ba_adjuster_get_camera_params(const ba_adjuster* a, uint32_t cam_id, double params[4]) { a->p->camera_params(cam_id, params); }
 void ba_adjuster_get_last_calib_step(const ba_adjuster* a, double delta_k[6]) { a->p->last_calib_step(delta_k); }
 uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[36]) { return a->p->marginals(cov); }
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) { a->p->set_allreduce(fn, ctx, rank, nranks); }

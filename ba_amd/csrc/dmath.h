@@ -307,4 +307,30 @@ BA_HD void proj_linearize(const Cam& cam, const double* z, const double* x, cons
   }
 }
 
+// dz_dcam_params (CalibSize instantiations, LM == 1; parallel_algos.h:114-118):
+//   -dTransfer_dparams(T_sw_m T_ws_r, z_ref, rho),  Transfer(T, pix, rho) = Project(R Unproject(pix) + rho t),
+// over the pinhole parameters (fx, fy, u0, v0) — both the un-projection of the reference pixel and the
+// projection depend on them.  The ray is Unproject(z_ref) (z = 1), NOT the landmark's x_s ray, paired
+// with the landmark's rho as it stands: the reference's call, kept as written.
+// jk: two rows of six (columns 4, 5 zero).
+BA_HD void proj_intrinsics_rows(const Cam& cam, const double* z_ref, double rho, const Rt& t_sw_m, const Rt& t_ws_r,
+                                double keep, double* jk) {
+  const V3 ray = v3((z_ref[0] - cam.u0) / cam.fx, (z_ref[1] - cam.v0) / cam.fy, 1.0);
+  const V3 P = mul(t_sw_m.R, mul(t_ws_r.R, ray) + t_ws_r.t * rho) + t_sw_m.t * rho;
+  V3 d0, d1;
+  dproject(cam, P, &d0, &d1);
+  // columns 0 and 1 of R_T = R_sw_m R_ws_r
+  const V3 c0 = mul(t_sw_m.R, v3(t_ws_r.R.m[0], t_ws_r.R.m[3], t_ws_r.R.m[6]));
+  const V3 c1 = mul(t_sw_m.R, v3(t_ws_r.R.m[1], t_ws_r.R.m[4], t_ws_r.R.m[7]));
+  const double dx_dfx = -ray.x / cam.fx, dy_dfy = -ray.y / cam.fy;  // d ray / d fx = -(u - u0) / fx^2
+  const double a00 = dot(d0, c0), a01 = dot(d0, c1), a10 = dot(d1, c0), a11 = dot(d1, c1);
+  const double iz = 1.0 / P.z;
+  jk[0] = -keep * (a00 * dx_dfx + P.x * iz); jk[1] = -keep * (a01 * dy_dfy);
+  jk[2] = -keep * (1.0 - a00 / cam.fx);      jk[3] = -keep * (-a01 / cam.fy);
+  jk[4] = 0.0; jk[5] = 0.0;
+  jk[6] = -keep * (a10 * dx_dfx);            jk[7] = -keep * (a11 * dy_dfy + P.y * iz);
+  jk[8] = -keep * (-a10 / cam.fx);           jk[9] = -keep * (1.0 - a11 / cam.fy);
+  jk[10] = 0.0; jk[11] = 0.0;
+}
+
 }  // namespace bad

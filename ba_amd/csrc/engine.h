@@ -48,6 +48,11 @@ struct Engine {
   // Calibration unknowns behind the pose unknowns of the reduced system (ba_hip_set_calibration):
   // 0, or 6 = the decoupled update of T_vs of camera 0 (the reference's DoTvs instantiations).
   int calib_dim = 0;
+  // calib_tvs: the six unknowns are T_vs; otherwise (calib_dim == 4) the pinhole parameters
+  // (fx, fy, u0, v0) of camera 0 (CalibSize = 4; BundleAdjuster.cpp:46-69, parallel_algos.h:114-118)
+  bool calib_tvs = false;
+  std::vector<double> cam_params_prev;   // params_backup of SolveInternal (:1025-1028): restored by a rollback
+  DBuf<double> lm_zref;                  // [L][2] reference pixel of every landmark (LandmarkT::z_ref)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // bulk trailing updates of the factorisation (look-ahead)
   const double* A_cleared = nullptr;  // the allocation of A whose whole square has been zeroed once
@@ -202,6 +207,7 @@ struct Engine {
 // ---- kernel launchers (defined in k_*.hip); all enqueue on e->stream -------------
 int launch_pose_prep(Engine* e);                       // T_sw, T_ws, T_wp of the current state
 int upload_cameras(Engine* e, bool eval_only);         // camera table(s) from prob.cam_* / tvs_eval
+int launch_reset_rays(Engine* e);                      // x_s rays of the current state from the reference pixels
 int launch_calib_border(Engine* e);                    // S_pk, S_kk, rhs_k into A / rhs (after k_write_diag)
 int launch_calib_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out);
 int launch_begin_solve(Engine* e);                     // x_s from x_w

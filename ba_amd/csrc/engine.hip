@@ -270,6 +270,12 @@ static int build_structure(Engine* e) {
   BAE_HIP(hipMemsetAsync(e->frow.p, 0, e->frow.bytes(), e->stream));
   BAE_HIP(e->scal.alloc(std::max<size_t>(st.n_scalars, 2 * O1 + L1 * LM1 + 1)));  // last: the zero scalar
   BAE_HIP(hipMemsetAsync(e->scal.p, 0, e->scal.bytes(), e->stream));
+  if (st.K && !e->calib_tvs) {
+    if (pb.lm_zref.size() != 2 * (size_t)st.L)
+      return e->fail_msg("intrinsics calibration needs the reference pixel of every landmark (ba_hip_set_landmark_ref_pixels)");
+    if ((rc = upload(e, e->lm_zref, pb.lm_zref))) return rc;
+  }
+  e->cam_params_prev = pb.cam_params;
   if (st.K) {
     BAE_HIP(e->crow.alloc((size_t)std::max<size_t>(st.n_scalars, 1) * kRow));
     BAE_HIP(hipMemsetAsync(e->crow.p, 0, e->crow.bytes(), e->stream));
@@ -843,7 +849,18 @@ int ba_hip_apply_step(ba_hip_engine* h) {
   if (rc) return rc;
   e->cur = 1 - e->cur;
   e->has_snapshot = true;
-  if (e->calib_dim && e->st.C > 0) {
+  if (e->calib_dim && !e->calib_tvs && e->st.C > 0) {
+    // BundleAdjuster.cpp:46-69: params of camera 0 -= delta_k, then every x_s ray is re-derived from
+    // the landmark's reference pixel with the new parameters, keeping its length
+    double dk[4];
+    BAE_HIP(hipMemcpyAsync(dk, e->step_p.p + e->st.np, sizeof(dk), hipMemcpyDeviceToHost, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+    e->cam_params_prev = e->prob.cam_params;
+    for (int i = 0; i < 4; ++i) e->prob.cam_params[i] -= dk[i];
+    if ((rc = upload_cameras(e, false))) return rc;
+    if ((rc = launch_reset_rays(e))) return rc;
+  }
+  if (e->calib_tvs && e->st.C > 0) {
     // BundleAdjuster.cpp:72-83: T_vs of camera 0 <- exp_decoupled(T_vs, -delta_k); the step's tail
     // is delta_k.  The pose caches are rebuilt from the new rig below (t_sw.clear(), :114).
     double dk[6];
@@ -874,11 +891,15 @@ int ba_hip_rollback(ba_hip_engine* h) {
   e->cur = 1 - e->cur;
   e->has_snapshot = false;
   int rc;
-  if (e->calib_dim) {
+  if (e->calib_tvs) {
     // the reference restores the poses WITH their cached T_sw but not the rig (:1060-1068): the
     // tables go back to the T_vs they were built with, `cam` keeps the rejected update
     e->tvs_eval = e->tvs_eval_prev;
     if ((rc = upload_cameras(e, true))) return rc;
+  } else if (e->calib_dim) {
+    // the intrinsics ARE restored (params_backup, :1066, :1147); the rays come back with the landmark buffer
+    e->prob.cam_params = e->cam_params_prev;
+    if ((rc = upload_cameras(e, false))) return rc;
   }
   rc = launch_pose_prep(e);
   if (rc) return rc;
@@ -958,9 +979,15 @@ uint32_t ba_hip_num_calib_params(const ba_hip_engine* h) {
 }
 int ba_hip_set_calibration(ba_hip_engine* h, int calib_size, int do_tvs) {
   ENG(h);
-  if (calib_size != 0) return e->fail_msg("camera-intrinsics calibration columns (CalibSize > 0) are not implemented");
-  if (do_tvs && e->lm_dim != 1) return e->fail_msg("T_vs calibration needs LmSize 1 (dz_dtvs, parallel_algos.h:102-131)");
-  e->calib_dim = do_tvs ? 6 : 0;
+  if (calib_size != 0 && calib_size != 4)
+    return e->fail_msg("CalibSize must be 0 or 4: the camera model of this path is the 4-parameter pinhole (fx, fy, u0, v0)");
+  if (calib_size && do_tvs)
+    return e->fail_msg("CalibSize > 0 together with DoTvs is not offered: the reference's T_vs block wipes the intrinsics "
+                       "columns it shares an entry with (BundleAdjuster.cpp:1775-1783)");
+  if ((do_tvs || calib_size) && e->lm_dim != 1)
+    return e->fail_msg("calibration columns need LmSize 1 (parallel_algos.h:102-131)");
+  e->calib_dim = do_tvs ? 6 : calib_size;
+  e->calib_tvs = do_tvs != 0;
   e->finalized = false;
   return 0;
 }
@@ -972,6 +999,18 @@ int ba_hip_get_calibration_marginals(ba_hip_engine* h, double* cov) {
   if (dist_solve_enabled(e)) return e->fail_msg("calibration marginals: not available with the distributed solve");
   BAE_HIP(hipSetDevice(e->device));
   return trailing_marginals(e, e->A.p, e->st.ld, e->st.np, e->st.K, cov);
+}
+int ba_hip_set_landmark_ref_pixels(ba_hip_engine* h, uint32_t n, const double* z_ref2) {
+  ENG(h);
+  e->prob.lm_zref.assign(z_ref2, z_ref2 + 2 * (size_t)n);
+  e->finalized = false;
+  return 0;
+}
+int ba_hip_get_camera_params(ba_hip_engine* h, double* params4) {
+  ENG(h);
+  const std::vector<double>& p = e->prob.cam_params;
+  for (size_t i = 0; i < p.size(); ++i) params4[i] = p[i];
+  return 0;
 }
 int ba_hip_get_cameras(ba_hip_engine* h, double* t_vs7) {
   ENG(h);
@@ -1103,6 +1142,7 @@ int ba_hip_get_proj_jacobians(ba_hip_engine* h, double* j_meas12, double* j_ref1
   return 0;
 }
 
+// 6 doubles per row: with CalibSize 4 the last two columns are zero
 int ba_hip_get_calib_jacobians(ba_hip_engine* h, double* j_k12) {
   ENG(h);
   NEED_FINAL();

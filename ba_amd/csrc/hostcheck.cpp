@@ -58,6 +58,16 @@ extern "C" void ba_hostcheck_proj_tvs_jacobian(const double* cam4, const double*
   proj_linearize<1, true>(cam, z, x, t_sw_m, t_vs_m.R, t_sv_m.t, t_ws_r, t_wp_r, same_pose != 0, &o, jk12);
 }
 
+// dz_dcam_params rows of the CalibSize instantiations (proj_intrinsics_rows, what k_linearize<.., 2> calls)
+extern "C" void ba_hostcheck_proj_intrinsics_jacobian(const double* cam4, const double* z_ref, double rho,
+                                                      const double* t_wp_m7, const double* t_vs_m7,
+                                                      const double* t_wp_r7, const double* t_vs_r7, double* jk12) {
+  Cam cam = {cam4[0], cam4[1], cam4[2], cam4[3]};
+  const Rt t_sw_m = inverse(compose(rt_from7(t_wp_m7), rt_from7(t_vs_m7)));
+  const Rt t_ws_r = compose(rt_from7(t_wp_r7), rt_from7(t_vs_r7));
+  proj_intrinsics_rows(cam, z_ref, rho, t_sw_m, t_ws_r, 1.0, jk12);
+}
+
 // ---- pose-pose residuals (dpose.h) ---------------------------------------------------
 #include "dpose.h"
 

@@ -255,16 +255,16 @@ int launch_residuals(Engine* e, int mode) {
 // A landmark with more than 64 observations gets a wave of its own, which walks it twice (sums,
 // then rows).  The weighted error sum of BuildProblem (proj_error_, :1386) falls out as a per-wave
 // partial.
-template <int LM, bool CAL = false>
+template <int LM, int CAL = 0>
 struct ObsLin {
   double r[2], jm[12], jr[12], jl[2 * LM];
   double w;     // robust weight
-  double jk[CAL ? 12 : 1];  // dz_dtvs (calibration instantiations)
+  double jk[CAL ? 12 : 1];  // dz_dtvs / dz_dcam_params, two rows of six (calibration instantiations)
 };
 
 // Everything one observation contributes, at the current state: residual, Jacobians with the
 // columns of regularised parameters zeroed (BundleAdjuster.cpp:1622-1629), Huber weight.
-template <int LM, bool CAL = false>
+template <int LM, int CAL = 0>
 __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, double c_huber, int use_robust,
                                               const double* __restrict__ obs_z, const uint32_t* __restrict__ obs_pose,
                                               const uint32_t* __restrict__ obs_cam, const double* __restrict__ obs_w0,
@@ -273,7 +273,8 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
                                               const uint32_t* __restrict__ lm_ref_cam, const double* __restrict__ cam,
                                               const double* __restrict__ pose_cam, const double* __restrict__ tsw,
                                               const double* __restrict__ tws, const double* __restrict__ twp,
-                                              ObsLin<LM, CAL>* o, const int32_t* __restrict__ pose_opt = nullptr) {
+                                              ObsLin<LM, CAL>* o, const int32_t* __restrict__ pose_opt = nullptr,
+                                              const double* __restrict__ lm_zref = nullptr) {
   const uint32_t pm = obs_pose[a], cm = obs_cam[a];
   const double* cp = cam + (size_t)cm * 35;
   // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
@@ -296,12 +297,17 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
     const Rt t_ws_r = load_rt(tws + ((size_t)rp * C + rc) * kRt);
     const Rt t_wp_r = load_rt(twp + (size_t)rp * kRt);
     mask_r = pose_mask[rp];
-    proj_linearize<1, CAL>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_ws_r, t_wp_r, pm == rp, &J, o->jk);
-    if constexpr (CAL) {
-      // parallel_algos.h:88,120: dz_dtvs is only formed when one of the two poses is active
+    proj_linearize<1, CAL == 1>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_ws_r, t_wp_r, pm == rp, &J, o->jk);
+    if constexpr (CAL != 0) {
+      // parallel_algos.h:88,114,120: the calibration Jacobians are only formed when one of the two poses is active
       const double keep = (pose_opt[pm] >= 0 || pose_opt[rp] >= 0) ? 1.0 : 0.0;
+      if constexpr (CAL == 1) {
 #pragma unroll
-      for (int i = 0; i < 12; ++i) o->jk[i] *= keep;
+        for (int i = 0; i < 12; ++i) o->jk[i] *= keep;
+      } else {
+        const double zr[2] = {lm_zref[2 * (size_t)l], lm_zref[2 * (size_t)l + 1]};
+        proj_intrinsics_rows(cc, zr, x[3], t_sw_m, t_ws_r, pm == rp ? 0.0 : keep, o->jk);
+      }
     }
   } else {
     proj_linearize<LM>(cc, z, x, t_sw_m, R_vs_m, t_sv_m, t_sw_m, t_sw_m, false, &J);
@@ -350,10 +356,10 @@ __device__ __forceinline__ void invert_v(const double* Vs, double* Vi) {
 }
 
 // lane-local contributions to the landmark sums: [V unique | b_l | W_r (LM == 1)]
-template <int LM, bool CAL = false> struct LmSums {
+template <int LM, int CAL = 0> struct LmSums {
   static constexpr int NV = LM * (LM + 1) / 2, NE = NV + LM + (LM == 1 ? 6 : 0), N = NE + (CAL ? 6 : 0);
 };
-template <int LM, bool CAL = false>
+template <int LM, int CAL = 0>
 __device__ __forceinline__ void obs_sums(const ObsLin<LM, CAL>& q, double* v) {
   int k = 0;
 #pragma unroll
@@ -373,7 +379,7 @@ __device__ __forceinline__ void obs_sums(const ObsLin<LM, CAL>& q, double* v) {
 }
 
 // the R rows of one observation (structure.h): J_m (2), [J_r (2)], W_m (LM), -W_m V^-1 (LM)
-template <int LM, bool CAL = false>
+template <int LM, int CAL = 0>
 __device__ __forceinline__ void obs_rows(const ObsLin<LM, CAL>& q, const double* Vi, double* rows) {
   const double sw = sqrt(q.w);
 #pragma unroll
@@ -427,7 +433,7 @@ __device__ __forceinline__ void store_landmark(uint32_t l, uint32_t O, uint32_t 
 // CAL (calibration instantiations, LM == 1): additionally the calibration rows `crow` (engine.h) —
 // sqrt(w) dz_dtvs of the observation at 2a, 2a+1 and the landmark's E_l = sum w J_l^T J_k at 2O + l
 // (six more components of the segmented sums).
-template <int LM, int WAVES, bool BIG, bool STAGE, bool CAL = false>
+template <int LM, int WAVES, bool BIG, bool STAGE, int CAL = 0>
 __global__ void __launch_bounds__(64 * WAVES)
 k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_huber, int use_robust,
             const uint2* __restrict__ wave_rng, const uint32_t* __restrict__ lm_ptr,
@@ -440,7 +446,8 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
             const double* __restrict__ tsw, const double* __restrict__ tws, const double* __restrict__ twp,
             double* __restrict__ obs_w, double* __restrict__ frow, double* __restrict__ scal,
             double* __restrict__ lm_vinv, double* __restrict__ lm_bl, double* __restrict__ obs_jl,
-            double* __restrict__ partials, const int32_t* __restrict__ pose_opt, double* __restrict__ crow) {
+            double* __restrict__ partials, const int32_t* __restrict__ pose_opt, double* __restrict__ crow,
+            const double* __restrict__ lm_zref) {
   constexpr int R = LM == 1 ? 6 : 8, RD = R * 6;   // rows / doubles per observation
   constexpr int STRIDE = RD + 2;                    // LDS stride per lane (even: 16-byte reads; odd multiple of 2 banks)
   constexpr int NS = LmSums<LM, CAL>::N, NV = LmSums<LM, CAL>::NV, NE = LmSums<LM, CAL>::NE;
@@ -476,7 +483,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     const bool lm_act = lm_opt[l] >= 0;
     const int s0 = (int)(lm_ptr[l] - a0), s1 = (int)(lm_ptr[l + 1] - 1 - a0);  // lanes of this landmark
     ObsLin<LM, CAL> q;
-    linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt);
+    linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref);
     double v[NS];
     obs_sums<LM, CAL>(q, v);
     if (!valid || !lm_act) {
@@ -549,7 +556,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     for (int i = 0; i < NS; ++i) tot[i] = 0.0;
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
       ObsLin<LM, CAL> q;
-      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt);
+      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref);
       double v[NS];
       obs_sums<LM, CAL>(q, v);
 #pragma unroll
@@ -564,7 +571,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     invert_v<LM>(tot, Vi);
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
       ObsLin<LM, CAL> q;
-      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt);
+      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref);
       double rows[RD];
       obs_rows<LM, CAL>(q, Vi, rows);
       store_calib_obs(a, q);
@@ -603,17 +610,20 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
       e->obs_pose.p, e->obs_cam.p, e->obs_lm.p, e->obs_w0.p, e->lm_opt.p, e->pose_mask.p, e->lm_x[e->cur].p, \
       e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->twp.p,     \
       e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p, e->obs_jl.p, e->partials.p + (first),  \
-      (const int32_t*)e->pose_opt.p, e->crow.p
+      (const int32_t*)e->pose_opt.p, e->crow.p, (const double*)e->lm_zref.p
   e->prof_begin(e->ev_landmarks);
   if (st.K) {  // calibration instantiations (LmSize 1): the CAL kernels, same launch shapes
     if (n_small) {
       const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
-      hipLaunchKernelGGL((k_linearize<1, WAVES, false, true, true>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      if (e->calib_tvs) hipLaunchKernelGGL((k_linearize<1, WAVES, false, true, 1>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      else hipLaunchKernelGGL((k_linearize<1, WAVES, false, true, 2>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
     }
     if (st.n_big_chunks) {
       const dim3 grid((st.n_big_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
-      hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, true>), grid, block, 0, e->stream,
-                         BAE_ARGS(n_small, st.n_big_chunks));
+      if (e->calib_tvs)
+        hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, 1>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+      else
+        hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, 2>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
     }
     e->prof_end(e->ev_landmarks);
     BAE_HIP(hipGetLastError());
@@ -653,7 +663,7 @@ __global__ void k_backsub(int L, int D, uint32_t lrow_base, const int32_t* __res
                           const double* __restrict__ frow, const double* __restrict__ lm_vinv,
                           const double* __restrict__ lm_bl, const double* __restrict__ delta_p,
                           double* __restrict__ delta_l, const double* __restrict__ crow_lm,
-                          const double* __restrict__ delta_k) {
+                          const double* __restrict__ delta_k, int K) {
   constexpr int R = LM == 1 ? 6 : 8, WO = LM == 1 ? 4 : 2;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   if (l >= L) return;
@@ -691,8 +701,7 @@ __global__ void k_backsub(int L, int D, uint32_t lrow_base, const int32_t* __res
   if (LM == 1 && crow_lm) {  // calibration: rhs_l -= (J_l^T J_k) delta_k (BundleAdjuster.cpp:729-733)
     const double* er = crow_lm + (size_t)l * kRow;
     double s = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) s += er[r] * delta_k[r];
+    for (int r = 0; r < K; ++r) s += er[r] * delta_k[r];
     rhs[0] -= s;
   }
 #pragma unroll
@@ -712,7 +721,7 @@ int launch_backsub(Engine* e) {
   L, e->pose_dim, e->st.lrow_base, e->lm_opt.p, e->pose_opt.p, e->lm_ptr.p, e->obs_pose.p, e->lm_ref_pose.p, \
       e->frow.p, e->lm_vinv.p, e->lm_bl.p, e->gn_p.p, e->gn_l.p,                                    \
       (const double*)(e->st.K ? e->crow.p + 2 * (size_t)e->st.O * kRow : nullptr),                    \
-      (const double*)(e->gn_p.p + e->st.np)
+      (const double*)(e->gn_p.p + e->st.np), (int)e->st.K
   if (e->lm_dim == 1) hipLaunchKernelGGL(k_backsub<1>, grid, block, 0, e->stream, BAE_ARGS);
   else hipLaunchKernelGGL(k_backsub<3>, grid, block, 0, e->stream, BAE_ARGS);
 #undef BAE_ARGS
@@ -777,6 +786,27 @@ __global__ void k_apply_landmarks(int L, const int32_t* __restrict__ lm_opt,
 #pragma unroll
   for (int i = 0; i < 4; ++i) out[(size_t)l * 4 + i] = x[i];
   rel_out[l] = rel;
+}
+
+// Intrinsics calibration, BundleAdjuster.cpp:57-68: after the camera parameters moved, the sensor-frame
+// ray of EVERY landmark is re-derived from its reference pixel, x_s[0:3] = unit(Unproject(z_ref)) |x_s[0:3]|.
+__global__ void k_reset_rays(int L, const double* __restrict__ cam, const double* __restrict__ zref,
+                             double* __restrict__ x) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= L) return;
+  double* o = x + (size_t)l * 4;
+  const double norm = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+  const double rx = (zref[2 * (size_t)l] - cam[2]) / cam[0], ry = (zref[2 * (size_t)l + 1] - cam[3]) / cam[1];
+  const double s = norm / sqrt(rx * rx + ry * ry + 1.0);
+  o[0] = rx * s; o[1] = ry * s; o[2] = s;
+}
+int launch_reset_rays(Engine* e) {
+  const int L = e->st.L;
+  if (L == 0) return 0;
+  hipLaunchKernelGGL(k_reset_rays, dim3((L + 255) / 256), dim3(256), 0, e->stream, L, (const double*)e->cam.p,
+                     (const double*)e->lm_zref.p, e->lm_x[e->cur].p);
+  BAE_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_apply_step(Engine* e) {

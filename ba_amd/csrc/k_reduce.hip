@@ -367,7 +367,7 @@ k_calib_reduce(uint32_t n_obs_rows, uint32_t L, const double* __restrict__ crow,
 // 6 x 6 block, like the pose blocks), rhs_k (unreduced, tail of rhs_p) and its reduced form (tail of
 // rhs_sc); k_write_border places the S_pk blocks as rows np .. np+5 of the lower storage.
 __global__ void __launch_bounds__(64)
-k_calib_finish(uint32_t nparts, const double* __restrict__ partials, uint32_t np, uint32_t ld,
+k_calib_finish(uint32_t nparts, const double* __restrict__ partials, uint32_t np, uint32_t ld, int K,
                double* __restrict__ A, double* __restrict__ rhs_p, double* __restrict__ rhs_sc) {
   __shared__ double tot[33];
   const int tid = threadIdx.x;
@@ -379,20 +379,22 @@ k_calib_finish(uint32_t nparts, const double* __restrict__ partials, uint32_t np
   __syncthreads();
   if (tid < 36) {
     const int r = tid / 6, c = tid - 6 * r, x = r < c ? r : c, y = r < c ? c : r;
-    A[((size_t)np + r) * ld + np + c] = tot[x * 6 - x * (x - 1) / 2 + (y - x)];
+    if (r < K && c < K) A[((size_t)np + r) * ld + np + c] = tot[x * 6 - x * (x - 1) / 2 + (y - x)];
   } else if (tid < 42) {
     const int k = tid - 36;
-    rhs_p[np + k] = tot[21 + k];
-    rhs_sc[np + k] = tot[21 + k] + tot[27 + k];
+    if (k < K) {
+      rhs_p[np + k] = tot[21 + k];
+      rhs_sc[np + k] = tot[21 + k] + tot[27 + k];
+    }
   }
 }
 __global__ void __launch_bounds__(64)
-k_write_border(const double* __restrict__ border, int D, uint32_t np, uint32_t ld, double* __restrict__ A) {
+k_write_border(const double* __restrict__ border, int D, uint32_t np, uint32_t ld, int K, double* __restrict__ A) {
   const uint32_t i = blockIdx.x;
   const int tid = threadIdx.x;
   if (tid < 36) {
     const int r = tid / 6, c = tid - 6 * r;
-    A[((size_t)np + c) * ld + (size_t)i * D + r] = border[(size_t)i * 36 + tid];
+    if (c < K) A[((size_t)np + c) * ld + (size_t)i * D + r] = border[(size_t)i * 36 + tid];
   }
 }
 
@@ -506,7 +508,7 @@ int launch_gather_S(Engine* e) {
     BAE_HIP(hipGetLastError());
     if (st.K) {
       hipLaunchKernelGGL(k_write_border, dim3(st.Pact), dim3(64), 0, e->stream, (const double*)e->border_blocks.p,
-                         e->pose_dim, st.np, ld, e->A.p);
+                         e->pose_dim, st.np, ld, (int)st.K, e->A.p);
       BAE_HIP(hipGetLastError());
     }
   }
@@ -528,7 +530,7 @@ int launch_calib_border(Engine* e) {
                      e->lm_vinv.p, e->lm_opt.p, part.p, nb);
   BAE_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_calib_finish, dim3(1), dim3(64), 0, e->stream, nb, (const double*)part.p, st.np, st.ld,
-                     e->A.p, e->rhs_p.p, e->rhs_sc.p);
+                     (int)st.K, e->A.p, e->rhs_p.p, e->rhs_sc.p);
   BAE_HIP(hipGetLastError());
   return 0;
 }
@@ -1027,14 +1029,14 @@ int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
 // || J_k rhs_k ||^2 over the observations, which the reference adds to the denominator as a term of
 // its own.
 __global__ void __launch_bounds__(256)
-k_jk_rhs(uint32_t O, const double* __restrict__ crow, const double* __restrict__ rhs_k, double* __restrict__ partials) {
+k_jk_rhs(uint32_t O, int K, const double* __restrict__ crow, const double* __restrict__ rhs_k, double* __restrict__ partials) {
   __shared__ double red[256];
   const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
   double sq = 0.0;
   if (a < O) {
     double u0 = 0, u1 = 0;
     const double* r0 = crow + 2 * a * kRow;
-    for (int c = 0; c < 6; ++c) { u0 += r0[c] * rhs_k[c]; u1 += r0[kRow + c] * rhs_k[c]; }
+    for (int c = 0; c < K; ++c) { u0 += r0[c] * rhs_k[c]; u1 += r0[kRow + c] * rhs_k[c]; }
     sq = u0 * u0 + u1 * u1;
   }
   red[threadIdx.x] = sq;
@@ -1048,14 +1050,14 @@ k_jk_rhs(uint32_t O, const double* __restrict__ crow, const double* __restrict__
 
 int launch_calib_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
   const Structure& st = e->st;
-  double rk[6], gk[6] = {0, 0, 0, 0, 0, 0};
-  BAE_HIP(hipMemcpyAsync(rk, e->rhs_p.p + st.np, sizeof(rk), hipMemcpyDeviceToHost, e->stream));
-  if (gn_available) BAE_HIP(hipMemcpyAsync(gk, e->gn_p.p + st.np, sizeof(gk), hipMemcpyDeviceToHost, e->stream));
+  double rk[6] = {0, 0, 0, 0, 0, 0}, gk[6] = {0, 0, 0, 0, 0, 0};
+  BAE_HIP(hipMemcpyAsync(rk, e->rhs_p.p + st.np, st.K * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (gn_available) BAE_HIP(hipMemcpyAsync(gk, e->gn_p.p + st.np, st.K * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   BAE_HIP(hipStreamSynchronize(e->stream));
   for (int i = 0; i < 6; ++i) { out->rhs_k_sq += rk[i] * rk[i]; out->gn_k_sq += gk[i] * gk[i]; out->rhs_gn_k += rk[i] * gk[i]; }
   const uint32_t nb = (st.O > 0 && st.Pact > 0) ? (st.O + 255) / 256 : 0;  // :881-886: only with active poses
   if (nb) {
-    hipLaunchKernelGGL(k_jk_rhs, dim3(nb), dim3(256), 0, e->stream, st.O, (const double*)e->crow.p,
+    hipLaunchKernelGGL(k_jk_rhs, dim3(nb), dim3(256), 0, e->stream, st.O, (int)st.K, (const double*)e->crow.p,
                        (const double*)(e->rhs_p.p + st.np), e->partials.p);
     BAE_HIP(hipGetLastError());
   }

@@ -58,6 +58,7 @@ struct Problem {  // host copies, reference ids
   std::vector<uint8_t> pose_active;
   std::vector<double> lm_xw;                               // [L][4]
   std::vector<uint32_t> lm_ref_pose, lm_ref_cam;
+  std::vector<double> lm_zref;                             // [L][2] reference pixels (intrinsics calibration only)
   std::vector<uint8_t> lm_active;
   std::vector<double> proj_z, proj_w;                      // [O][2], [O]
   std::vector<uint32_t> proj_pose, proj_lm, proj_cam;

@@ -84,7 +84,7 @@ SYMBOLS = [
     "ba_hip_set_allreduce", "ba_hip_set_collectives", "ba_hip_solve_is_distributed", "ba_hip_dense_solve", "ba_hip_select_kth", "ba_hip_set_profiling",
     "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set", "ba_hip_set_conditioning_residuals",
     "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host", "ba_hip_get_proj_jacobians",
-    "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians", "ba_hip_get_calibration_marginals",
+    "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians", "ba_hip_get_calibration_marginals", "ba_hip_set_landmark_ref_pixels", "ba_hip_get_camera_params",
 ]
 
 
@@ -288,6 +288,15 @@ class Engine:
         c = np.empty((k, k))
         self._chk(self.L.ba_hip_get_calibration_marginals(self.h, _p(c, dp)))
         return c
+
+    def set_landmark_ref_pixels(self, z_ref):
+        z = _d(z_ref).reshape(-1, 2)
+        self._chk(self.L.ba_hip_set_landmark_ref_pixels(self.h, z.shape[0], _p(z, dp)))
+
+    def get_camera_params(self, n):
+        p = np.empty((n, 4))
+        self._chk(self.L.ba_hip_get_camera_params(self.h, _p(p, dp)))
+        return p
 
     def get_cameras(self, n):
         t = np.empty((n, 7))

@@ -11,10 +11,12 @@
 // this class: without a usable MI355X Solve() reports SolverError and prints the
 // engine's message.
 //
-// Supported instantiations: LmSize in {0,1,3}, PoseSize in {6,9,15}, CalibSize == 0; DoTvs (the
-// extrinsics T_vs of camera 0 as six more unknowns, reference :121-134, BundleAdjuster.cpp:72-83,
-// 493-583) with LmSize 1.  CalibSize > 0 (camera intrinsics) needs the camera model's parameter
-// Jacobian and stays out.
+// Supported instantiations: LmSize in {0,1,3}, PoseSize in {6,9,15}; with LmSize 1 the
+// self-calibration instantiations (reference :121-134, BundleAdjuster.cpp:46-83, 493-583): DoTvs —
+// the extrinsics T_vs of camera 0 as six more unknowns — or CalibSize = 4 — the pinhole parameters
+// (fx, fy, u0, v0) of camera 0 (the reference instantiates 5 for Calibu's FOV camera, which is not in
+// its tree; 4 is the camera model of this path).  Not both at once: the reference's own T_vs block
+// wipes the intrinsics columns in that case (BundleAdjuster.cpp:1775-1783).
 #pragma once
 #include <algorithm>
 #include <cassert>
@@ -98,8 +100,9 @@ class BundleAdjuster {
   static_assert(std::is_same<Scalar, double>::value, "the engine computes in FP64 (REAL_TYPE=double)");
   static_assert(LmSize == 0 || LmSize == 1 || LmSize == 3, "LmSize must be 0, 1 or 3");
   static_assert(PoseSize == 6 || PoseSize == 9 || PoseSize == 15, "PoseSize must be 6, 9 or 15");
-  static_assert(CalibSize == 0, "camera-intrinsics calibration columns are not part of this path");
-  static_assert(!DoTvs || LmSize == 1, "T_vs calibration exists for inverse-depth landmarks only (parallel_algos.h:102-131)");
+  static_assert(CalibSize == 0 || CalibSize == 4, "CalibSize: 0 or the 4 pinhole parameters (fx, fy, u0, v0)");
+  static_assert(!(CalibSize > 0 && DoTvs), "CalibSize > 0 with DoTvs: the reference wipes the intrinsics columns (BundleAdjuster.cpp:1775-1783)");
+  static_assert((!DoTvs && CalibSize == 0) || LmSize == 1, "calibration exists for inverse-depth landmarks only (parallel_algos.h:102-131)");
 
  public:
   int debug_level_threshold = 0;
@@ -110,6 +113,7 @@ class BundleAdjuster {
   static constexpr uint32_t kPoseDim = PoseSize;
   static constexpr uint32_t kCalibDim = CalibSize + (DoTvs ? 6 : 0);  // reference :123-124
   static constexpr bool kTvsInCalib = DoTvs;
+  static constexpr bool kCamParamsInCalib = CalibSize > 0;
   static constexpr uint32_t kTvsOffset = CalibSize;
   static constexpr bool kVelInState = (kPoseDim >= 9);
   static constexpr bool kBiasInState = (kPoseDim >= 15);
@@ -488,7 +492,7 @@ class BundleAdjuster {
   bool SolveInternal(const Scalar gn_damping, const bool error_increase_allowed, const bool use_dogleg);
   // reference BundleAdjuster.cpp:771-784 (inside CalculateGn, only with active poses)
   bool FetchCalibrationMarginals() {
-    if (!DoTvs || !options_.calculate_calibration_marginals || num_active_poses_ == 0) return true;
+    if (kCalibDim == 0 || !options_.calculate_calibration_marginals || num_active_poses_ == 0) return true;
     summary_.calibration_marginals = MatX((int)kCalibDim, (int)kCalibDim);
     return Check(ba_hip_get_calibration_marginals(engine_, summary_.calibration_marginals.data()),
                  "ba_hip_get_calibration_marginals");
@@ -566,7 +570,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
       summary_.result = SolverError;
       return false;
     }
-    if (DoTvs && !Check(ba_hip_set_calibration(engine_, CalibSize, 1), "ba_hip_set_calibration")) return false;
+    if (kCalibDim > 0 && !Check(ba_hip_set_calibration(engine_, CalibSize, DoTvs ? 1 : 0), "ba_hip_set_calibration")) return false;
     engine_device_ = options_.device;
     structure_dirty_ = true;
   }
@@ -657,6 +661,11 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
     return false;
   }
   if (!Check(ba_hip_set_landmarks(engine_, L, lx.data(), lrp.data(), lrc.data(), la.data()), "ba_hip_set_landmarks")) return false;
+  if (kCamParamsInCalib) {  // dTransfer_dparams is taken at the landmark's reference pixel (parallel_algos.h:115-118)
+    std::vector<double> zr(2 * (size_t)L);
+    for (uint32_t l = 0; l < L; ++l) { zr[2 * (size_t)l] = landmarks_[l].z_ref[0]; zr[2 * (size_t)l + 1] = landmarks_[l].z_ref[1]; }
+    if (!Check(ba_hip_set_landmark_ref_pixels(engine_, L, zr.data()), "ba_hip_set_landmark_ref_pixels")) return false;
+  }
   if (!Check(ba_hip_set_projection_residuals(engine_, (uint32_t)pr_pose_.size(), pr_z_.data(), pr_pose_.data(),
                                              pr_lm_.data(), pr_cam_.data(), pr_w_.data()),
              "ba_hip_set_projection_residuals")) return false;
@@ -745,18 +754,18 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::WriteReducedCam
   if (fp) std::fclose(fp);
   if (fl) std::fclose(fl);
   if (fr) std::fclose(fr);
-  if (DoTvs) {
+  if (kCalibDim > 0) {  // with CalibSize 4 the last two of the six columns are zero
     std::vector<double> jk(12 * O), jtj(36, 0.0);
     if (!Check(ba_hip_get_calib_jacobians(engine_, jk.data()), "ba_hip_get_calib_jacobians")) return;
     if (FILE* f = std::fopen("j_kpr.txt", "w")) {
-      for (size_t r = 0; r < 2 * O; ++r) put_row(f, &jk[6 * r], 6);
+      for (size_t r = 0; r < 2 * O; ++r) put_row(f, &jk[6 * r], kCalibDim);
       std::fclose(f);
     }
     for (size_t r = 0; r < 2 * O; ++r)
       for (int x = 0; x < 6; ++x)
         for (int y = 0; y < 6; ++y) jtj[6 * x + y] += jk[6 * r + x] * jk[6 * r + y];
     if (FILE* f = std::fopen("jt_kpr_j_kpr.txt", "w")) {
-      for (int x = 0; x < 6; ++x) put_row(f, &jtj[6 * x], 6);
+      for (uint32_t x = 0; x < kCalibDim; ++x) put_row(f, &jtj[6 * x], kCalibDim);
       std::fclose(f);
     }
   }
@@ -1020,6 +1029,11 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     // :72-83 moved the rig's camera 0 on every applied step (host-side copy in the engine: no transfer)
     std::vector<double> tv(7 * (size_t)rig_->NumCams());
     if (Check(ba_hip_get_cameras(engine_, tv.data()), "ba_hip_get_cameras")) rig_->cameras_[0]->SetPose(SE3::from7(tv.data()));
+  }
+  if (kCamParamsInCalib && rig_->NumCams() > 0) {  // :46-53
+    std::vector<double> cp(4 * (size_t)rig_->NumCams());
+    if (Check(ba_hip_get_camera_params(engine_, cp.data()), "ba_hip_get_camera_params"))
+      rig_->cameras_[0]->SetParams(Vector4t({cp[0], cp[1], cp[2], cp[3]}));
   }
   last_step_stale_ = true;
   uploaded_once_ = true;

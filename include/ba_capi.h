@@ -45,8 +45,9 @@ typedef struct { /* ba::SolutionSummary<double> + GetErrors, reference :48-70,59
 
 void ba_default_options(ba_options* o);
 ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim);
-/* ba::BundleAdjuster<double, lm_dim, pose_dim, calib_size, do_tvs>: calib_size must be 0; do_tvs
- * needs lm_dim 1 (the extrinsics of camera 0 become six more unknowns).  NULL otherwise. */
+/* ba::BundleAdjuster<double, lm_dim, pose_dim, calib_size, do_tvs>, lm_dim 1: do_tvs (the extrinsics
+ * of camera 0 become six more unknowns) or calib_size 4 (its pinhole parameters become four more),
+ * not both.  NULL otherwise. */
 ba_adjuster* ba_adjuster_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs);
 void ba_adjuster_destroy(ba_adjuster* a);
 void ba_adjuster_init(ba_adjuster* a, const ba_options* o);
@@ -108,6 +109,8 @@ void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a);
 /* rig()->cameras_[cam_id]->Pose(): with do_tvs camera 0 moves with every applied step */
 void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]);
+/* rig()->cameras_[cam_id]->GetParams(): with calib_size 4 camera 0's move with every applied step */
+void ba_adjuster_get_camera_params(const ba_adjuster* a, uint32_t cam_id, double params[4]);
 /* SolutionSummary::calibration_marginals (6 x 6, row-major) of the last iteration; returns its
  * dimension (0 when the option was off or the adjuster has no calibration unknowns) */
 uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[36]);

@@ -107,9 +107,22 @@ int ba_hip_set_options(ba_hip_engine* e, const ba_hip_options* o);
  * entries (rhs, Gauss-Newton delta, step), ba_hip_get_S returns the bordered (n + 6)^2 matrix, and
  * ba_hip_apply_step moves T_vs by exp_decoupled(T_vs, -delta_k) (:72-83) — read it back with
  * ba_hip_get_cameras.  As in the reference a rolled-back step does NOT restore T_vs (:1060-1068).
- * LmSize 1 only (dz_dtvs, parallel_algos.h:102-131).  calib_size > 0 (camera intrinsics) is refused:
- * not implemented.  Structural: call before ba_hip_finalize. */
+ * calib_size = 4 (with do_tvs = 0): the pinhole parameters (fx, fy, u0, v0) of camera 0 become four
+ * unknowns the same way (kCamParamsInCalib; BundleAdjuster.cpp:46-69, parallel_algos.h:114-118:
+ * dz_dcam_params = -dTransfer_dparams(T_sw_m T_ws_r, z_ref, rho)); needs the reference pixel of every
+ * landmark (ba_hip_set_landmark_ref_pixels).  ba_hip_apply_step moves the parameters by -delta_k and
+ * re-derives every x_s ray from its reference pixel (:57-68); a rollback restores them (:1066, :1147);
+ * read them back with ba_hip_get_camera_params.  The reference instantiates CalibSize = 5 for Calibu's
+ * FOV camera, which is not in its tree: 4 is the size of the camera model this path has.
+ * Both at once is refused (the reference's T_vs block wipes the intrinsics columns it shares a
+ * j_kpr_ entry with, :1775-1783), as is any other size.  LmSize 1 only (parallel_algos.h:102-131).
+ * Structural: call before ba_hip_finalize. */
 int ba_hip_set_calibration(ba_hip_engine* e, int calib_size, int do_tvs);
+/* LandmarkT::z_ref (BundleAdjuster.h:476-483): the pixel of every landmark in its reference
+ * camera, two doubles per landmark id.  Only the intrinsics calibration reads it. */
+int ba_hip_set_landmark_ref_pixels(ba_hip_engine* e, uint32_t n, const double* z_ref2);
+/* [fx, fy, u0, v0] of every camera as the engine currently holds them */
+int ba_hip_get_camera_params(ba_hip_engine* e, double* params4);
 
 /* ---- problem upload (replaces the AoS graph of Types.h:41-321) -------------------- */
 /* calibu::Rig cameras: pinhole params [fx,fy,u0,v0] and T_vs (BundleAdjuster.h:259-263) */

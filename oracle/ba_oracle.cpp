@@ -78,6 +78,7 @@ struct ProjectionResidual {  // Types.h:282-298
   Mat<2, 6> dz_dx_meas, dz_dx_ref;
   Mat<2, 6> dz_dx_meas_raw, dz_dx_ref_raw;  // taps: before column masking
   Mat<2, 6> dz_dtvs;  // Types.h:295, d residual / d T_vs (DoTvs instantiations only)
+  Mat<2, 4> dz_dcam_params;  // Types.h:294 (CalibSize instantiations; pinhole: 4 parameters)
   double mahalanobis_distance = 0, weight = 1, orig_weight = 1;
   bool is_conditioning = false;
 };
@@ -230,11 +231,19 @@ struct orc_ba {
   const int kLmDim, kPoseDim;
   const bool kVelInState, kBiasInState;
   // BundleAdjuster.h:121-134: kCalibDim = CalibSize + (DoTvs ? 6 : 0), kTvsOffset = CalibSize.
-  // Only CalibSize = 0 is restated: the intrinsics columns need the camera model's
-  // dTransfer_dparams, and the reference's one use of them (its 5-parameter FOV camera) wipes them
-  // again when DoTvs is set (BundleAdjuster.cpp:1775 setZero() on the shared block).
+  // CalibSize: 0, or 4 = the parameters (fx, fy, u0, v0) of the pinhole model this restatement has
+  // (the reference instantiates 5 for Calibu's FOV camera, which is not in its tree).  Both at once
+  // is refused: the reference's T_vs block does setZero() on the j_kpr_ entry it shares with the
+  // intrinsics (BundleAdjuster.cpp:1775-1783 after :1759-1766) and so wipes them.
   const bool kTvsInCalib;
+  const int kCamParamsDim;   // CalibSize
+  const bool kCamParamsInCalib;
   const int kCalibDim;
+  // the calibration Jacobian of one residual as the reference lays j_kpr_ out: intrinsics first,
+  // T_vs at kTvsOffset = CalibSize
+  double jk(const ProjectionResidual& res, int r, int c) const {
+    return c < kCamParamsDim ? res.dz_dcam_params(r, c) : res.dz_dtvs(r, c - kCamParamsDim);
+  }
   uint32_t num_total_params() const { return num_active_poses_ * kPoseDim + kCalibDim; }
   static const int kPrPoseDim = 6;
   int imu_res_size() const { return kPoseDim; }  // ImuResidualT<S, kPoseDim, kPoseDim>
@@ -284,9 +293,10 @@ struct orc_ba {
   std::vector<std::vector<WBlock>> w_;
   Delta last_delta_;
 
-  orc_ba(int lm, int pd, bool do_tvs = false)
+  orc_ba(int lm, int pd, bool do_tvs = false, int calib_size = 0)
       : kLmDim(lm), kPoseDim(pd), kVelInState(pd >= 9), kBiasInState(pd >= 15),
-        kTvsInCalib(do_tvs), kCalibDim(do_tvs ? 6 : 0) {
+        kTvsInCalib(do_tvs), kCamParamsDim(calib_size), kCamParamsInCalib(calib_size > 0),
+        kCalibDim(calib_size + (do_tvs ? 6 : 0)) {
     orc_default_options(&options_);
     memset(&summary_, 0, sizeof(summary_));
     memset(&timers_, 0, sizeof(timers_));
@@ -498,6 +508,8 @@ struct orc_ba {
         } else {
           res.dz_dx_ref = Mat<2, 6>::Zero();
         }
+        if (kCamParamsInCalib)  // parallel_algos.h:114-118: at the pixel z_ref, with x_s(3) as it stands
+          res.dz_dcam_params = -cam.dTransfer_dparams(t_sw_m * t_ws_r, lm.z_ref, lm.x_s[3]);
         if (kTvsInCalib) {  // parallel_algos.h:120-131, total derivative of the transfer
           const SE3 t_pm_pr = pose.t_wp.inverse() * ref_pose.t_wp;
           res.dz_dtvs =
@@ -961,9 +973,9 @@ struct orc_ba {
         for (int a = 0; a < K; ++a) {
           for (int b = 0; b < K; ++b)
             s_[(size_t)(n + a) * nt + n + b] +=
-                (res.dz_dtvs(0, a) * res.dz_dtvs(0, b) + res.dz_dtvs(1, a) * res.dz_dtvs(1, b)) * w;
-          rhs_k_[a] += res.dz_dtvs(0, a) * sw * r_pr_[res.residual_offset] +
-                       res.dz_dtvs(1, a) * sw * r_pr_[res.residual_offset + 1];
+                (jk(res, 0, a) * jk(res, 0, b) + jk(res, 1, a) * jk(res, 1, b)) * w;
+          rhs_k_[a] += jk(res, 0, a) * sw * r_pr_[res.residual_offset] +
+                       jk(res, 1, a) * sw * r_pr_[res.residual_offset + 1];
         }
         const bool listed = (res.x_meas_id != res.x_ref_id) || kLmDim != 1;
         if (!listed || num_poses == 0) continue;
@@ -971,7 +983,7 @@ struct orc_ba {
           if (!p.is_active) return;
           for (int r = 0; r < 6; ++r)
             for (int c = 0; c < K; ++c) {
-              const double v = (jp(0, r) * res.dz_dtvs(0, c) + jp(1, r) * res.dz_dtvs(1, c)) * w;
+              const double v = (jp(0, r) * jk(res, 0, c) + jp(1, r) * jk(res, 1, c)) * w;
               s_[(size_t)(p.opt_id * D + r) * nt + n + c] += v;
               if (!options_.use_triangular_matrices) s_[(size_t)(n + c) * nt + p.opt_id * D + r] += v;
             }
@@ -1004,8 +1016,7 @@ struct orc_ba {
             for (int a = 0; a < L; ++a)
               for (int c = 0; c < K; ++c)
                 jt_l_j_kpr_[((size_t)lm.opt_id * L + a) * K + c] +=
-                    (res.dz_dlm(0, a) * res.dz_dtvs(0, c) + res.dz_dlm(1, a) * res.dz_dtvs(1, c)) *
-                    res.weight;
+                    (res.dz_dlm(0, a) * jk(res, 0, c) + res.dz_dlm(1, a) * jk(res, 1, c)) * res.weight;
           }
         // Quirk Q11 (:431-440)
         if (L == 1) {
@@ -1193,9 +1204,22 @@ struct orc_ba {
     // :72-83: the extrinsics of camera 0 take -delta_k; no `coef` here (neither the rollback sign
     // nor the damping reaches T_vs), and the copies SolveInternal restores on a rejected step do
     // not include the rig — a rejected step's T_vs update stays.
+    // :46-69: the intrinsics of camera 0 take -delta_k (no `coef` either); with inverse-depth
+    // landmarks every x_s ray is re-derived from its reference pixel, keeping its length.
+    if (kCamParamsInCalib && !delta.delta_k.empty() && !rig_.empty()) {
+      Pinhole& m = rig_[0].model;
+      m.fx -= delta.delta_k[0]; m.fy -= delta.delta_k[1]; m.u0 -= delta.delta_k[2]; m.v0 -= delta.delta_k[3];
+      if (kLmDim == 1)
+        for (Landmark& lm : landmarks_) {
+          const double norm = std::sqrt(lm.x_s[0] * lm.x_s[0] + lm.x_s[1] * lm.x_s[1] + lm.x_s[2] * lm.x_s[2]);
+          Vec3 ray = m.Unproject(lm.z_ref);
+          const double len = std::sqrt(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+          for (int i = 0; i < 3; ++i) lm.x_s[i] = ray[i] / len * norm;
+        }
+    }
     if (kTvsInCalib && !delta.delta_k.empty() && !rig_.empty()) {
       Vec6 d;
-      for (int i = 0; i < 6; ++i) d[i] = -delta.delta_k[i];
+      for (int i = 0; i < 6; ++i) d[i] = -delta.delta_k[kCamParamsDim + i];
       rig_[0].t_vs = exp_decoupled(rig_[0].t_vs, d);
     }
     for (Pose& pose : poses_) {
@@ -1311,7 +1335,7 @@ struct orc_ba {
       if (kCalibDim && num_active_poses_ > 0) {  // j_kp_rhs_k (:883-886): its own squared norm
         double u[2] = {0, 0};
         for (int r = 0; r < 2; ++r)
-          for (int c = 0; c < kCalibDim; ++c) u[r] += res.dz_dtvs(r, c) * sw * rhs_k_[c];
+          for (int c = 0; c < kCalibDim; ++c) u[r] += jk(res, r, c) * sw * rhs_k_[c];
         denom += u[0] * u[0] + u[1] * u[1];
       }
       if (num_active_poses_ > 0 && listed) {
@@ -1371,6 +1395,7 @@ struct orc_ba {
     std::vector<SE3> t; std::vector<Vec3> v; std::vector<Vec6> b;
     std::vector<Vec4> xs, xw; std::vector<bool> reliable;
     std::vector<std::vector<SE3>> t_sw;
+    Pinhole cam0;  // params_backup (:1025-1028, 1099-1102): the intrinsics ARE restored, T_vs is not
   };
   // The reference deep-copies landmarks_, poses_, imu_ (:1022-1028, :1096-1102);
   // only the fields ApplyUpdate can change need restoring.
@@ -1383,6 +1408,7 @@ struct orc_ba {
     for (const Landmark& l : landmarks_) {
       s.xs.push_back(l.x_s); s.xw.push_back(l.x_w); s.reliable.push_back(l.is_reliable);
     }
+    if (!rig_.empty()) s.cam0 = rig_[0].model;
     return s;
   }
   void Restore(const Snapshot& s) {
@@ -1400,6 +1426,7 @@ struct orc_ba {
       landmarks_[i].x_s = s.xs[i]; landmarks_[i].x_w = s.xw[i];
       landmarks_[i].is_reliable = s.reliable[i];
     }
+    if (!rig_.empty()) rig_[0].model = s.cam0;  // :1066, :1147
   }
 
   // BundleAdjuster.cpp:838-1161
@@ -1606,9 +1633,10 @@ orc_ba* orc_create(int lm_dim, int pose_dim) { return orc_create_calib(lm_dim, p
 orc_ba* orc_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs) {
   if (!(lm_dim == 0 || lm_dim == 1 || lm_dim == 3)) return nullptr;
   if (!(pose_dim == 6 || pose_dim == 9 || pose_dim == 15)) return nullptr;
-  if (calib_size != 0) return nullptr;           // intrinsics columns: not restated (see orc_ba)
-  if (do_tvs && lm_dim != 1) return nullptr;     // dz_dtvs exists for LmSize 1 only (parallel_algos.h:102)
-  return new orc_ba(lm_dim, pose_dim, do_tvs != 0);
+  if (calib_size != 0 && calib_size != 4) return nullptr;  // the pinhole model has four parameters
+  if (calib_size != 0 && do_tvs) return nullptr;           // the reference wipes the intrinsics then (see orc_ba)
+  if ((do_tvs || calib_size) && lm_dim != 1) return nullptr;  // both Jacobians exist for LmSize 1 only (parallel_algos.h:102)
+  return new orc_ba(lm_dim, pose_dim, do_tvs != 0, calib_size);
 }
 void orc_destroy(orc_ba* h) { delete h; }
 void orc_init(orc_ba* h, const orc_options* o) { h->Init(*o); }
@@ -1771,6 +1799,25 @@ int orc_get_calibration_marginals(const orc_ba* h, double* cov) {
     for (uint32_t r = 0; r < K; ++r) cov[(size_t)r * K + i] = x[nt - K + r];
   }
   return (int)K;
+}
+void orc_get_camera_params(const orc_ba* h, uint32_t cam_id, double p[4]) {
+  const Pinhole& m = h->rig_[cam_id].model;
+  p[0] = m.fx; p[1] = m.fy; p[2] = m.u0; p[3] = m.v0;
+}
+void orc_get_proj_calib_jacobians(const orc_ba* h, double* j_k) {  // 2 x kCalibDim per residual id
+  const int K = h->kCalibDim;
+  for (size_t i = 0; i < h->proj_residuals_.size(); ++i)
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < K; ++c) j_k[(i * 2 + r) * K + c] = h->jk(h->proj_residuals_[i], r, c);
+}
+void orc_math_transfer(const double params[4], const double t_ba[7], const double pix[2], double rho, double out[2],
+                       double jac8[8]) {
+  Pinhole m; m.fx = params[0]; m.fy = params[1]; m.u0 = params[2]; m.v0 = params[3];
+  const SE3 t = se3_from7(t_ba);
+  Vec2 px; px[0] = pix[0]; px[1] = pix[1];
+  const Vec2 p = m.Transfer3d(t, m.Unproject(px), rho);
+  out[0] = p[0]; out[1] = p[1];
+  if (jac8) { const Mat<2, 4> J = m.dTransfer_dparams(t, px, rho); memcpy(jac8, J.a, 8 * sizeof(double)); }
 }
 void orc_get_proj_tvs_jacobians(const orc_ba* h, double* j_tvs) {
   for (size_t i = 0; i < h->proj_residuals_.size(); ++i)

@@ -52,9 +52,11 @@ void orc_default_options(orc_options* o);
 
 orc_ba* orc_create(int lm_dim, int pose_dim);
 /* BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs> (BundleAdjuster.h:110-134).  Restated:
-   calib_size = 0 with do_tvs = 0 | 1 (LmSize 1 only); anything else returns NULL.  With do_tvs the
-   reduced system is (n + 6) x (n + 6): the last six unknowns are the decoupled update of the
-   extrinsics T_vs of camera 0 (BundleAdjuster.cpp:72-83, 493-583). */
+   calib_size = 0 with do_tvs = 0 | 1, and calib_size = 4 (the pinhole parameters fx, fy, u0, v0 of
+   camera 0, BundleAdjuster.cpp:46-69) with do_tvs = 0 — LmSize 1 only; anything else returns NULL.
+   The reduced system is (n + kCalibDim)^2: the calibration unknowns follow the pose unknowns
+   (BundleAdjuster.cpp:316-322, 493-583); with do_tvs they are the decoupled update of the
+   extrinsics T_vs of camera 0 (:72-83). */
 orc_ba* orc_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs);
 void orc_destroy(orc_ba* h);
 void orc_init(orc_ba* h, const orc_options* o);
@@ -129,6 +131,12 @@ void orc_get_rhs_k(const orc_ba* h, double* r);          /* rhs_k_ (before Schur
 void orc_get_camera_pose(const orc_ba* h, uint32_t cam_id, double t_vs[7]);
 void orc_get_proj_tvs_jacobians(const orc_ba* h, double* j_tvs); /* dz_dtvs 2x6 per residual id */
 int orc_get_calibration_marginals(const orc_ba* h, double* cov_kxk); /* returns kCalibDim */
+void orc_get_camera_params(const orc_ba* h, uint32_t cam_id, double params[4]);
+void orc_get_proj_calib_jacobians(const orc_ba* h, double* j_k); /* 2 x kCalibDim per residual id, j_kpr_ layout */
+/* Transfer(T_ba, pix, rho) = Project(R Unproject(pix) + rho t) of the pinhole model and its 2x4
+   parameter Jacobian (jac8 may be NULL) — finite-difference pin of dTransfer_dparams */
+void orc_math_transfer(const double params[4], const double t_ba[7], const double pix[2], double rho,
+                       double out[2], double jac8[8]);
 void orc_get_proj_weights(const orc_ba* h, double* w);   /* per residual id */
 void orc_get_proj_residuals(const orc_ba* h, double* r2);/* per residual id, 2 each */
 void orc_get_imu_residuals(const orc_ba* h, double* r15);/* ImuResidualT::residual, 15 each (first PoseSize used) */

@@ -266,6 +266,34 @@ struct Pinhole {
     J(0, 3) = b[0]; J(1, 3) = b[1];
     return J;
   }
+  // Unproject(pix): the ray with z = 1 (LinearCamera); dUnproject_dparams, dProject_dparams over
+  // the parameter vector (fx, fy, u0, v0)
+  Vec3 Unproject(const Vec2& pix) const {
+    Vec3 r;
+    r[0] = (pix[0] - u0) / fx; r[1] = (pix[1] - v0) / fy; r[2] = 1.0;
+    return r;
+  }
+  // dTransfer_dparams(T_ba, pix, rho) = d/dparams Project(R Unproject(pix) + rho t): both the
+  // un-projection and the projection depend on the parameters (2x4).  Call site
+  // parallel_algos.h:115-118; Calibu is absent from the reference tree — reconstructed as the
+  // derivative of the function the call site names, pinned by finite differences of that function.
+  Mat<2, 4> dTransfer_dparams(const SE3& t_ba, const Vec2& pix, double rho) const {
+    const Vec3 ray = Unproject(pix);
+    const Vec3 P = t_ba.so3() * ray + t_ba.translation() * rho;
+    const Mat<2, 3> dp = dProject_dP(P);
+    const Mat3 R = t_ba.so3().matrix();
+    Mat<2, 4> J;
+    const double dx_dfx = -(pix[0] - u0) / (fx * fx), dy_dfy = -(pix[1] - v0) / (fy * fy);
+    for (int r = 0; r < 2; ++r) {
+      double c0 = 0, c1 = 0;  // dp * R column 0 / column 1
+      for (int k = 0; k < 3; ++k) { c0 += dp(r, k) * R(k, 0); c1 += dp(r, k) * R(k, 1); }
+      J(r, 0) = c0 * dx_dfx; J(r, 1) = c1 * dy_dfy;
+      J(r, 2) = c0 * (-1.0 / fx); J(r, 3) = c1 * (-1.0 / fy);
+    }
+    J(0, 0) += P[0] / P[2]; J(1, 1) += P[1] / P[2];
+    J(0, 2) += 1.0; J(1, 3) += 1.0;
+    return J;
+  }
 };
 
 }  // namespace orc

@@ -108,12 +108,12 @@ def default_options():
 class OracleBundleAdjuster:
     """CPU restatement of ba::BundleAdjuster<double, lm_dim, pose_dim, 0, do_tvs>."""
 
-    def __init__(self, lm_dim=1, pose_dim=6, do_tvs=False):
+    def __init__(self, lm_dim=1, pose_dim=6, do_tvs=False, calib_size=0):
         self.L = lib()
-        self.lm_dim, self.pose_dim, self.do_tvs = lm_dim, pose_dim, bool(do_tvs)
-        self.h = C.c_void_p(self.L.orc_create_calib(lm_dim, pose_dim, 0, int(do_tvs)))
+        self.lm_dim, self.pose_dim, self.do_tvs, self.calib_size = lm_dim, pose_dim, bool(do_tvs), int(calib_size)
+        self.h = C.c_void_p(self.L.orc_create_calib(lm_dim, pose_dim, int(calib_size), int(do_tvs)))
         if not self.h:
-            raise ValueError("unsupported (lm_dim, pose_dim, do_tvs)")
+            raise ValueError("unsupported (lm_dim, pose_dim, calib_size, do_tvs)")
 
     def __del__(self):
         try:
@@ -295,6 +295,17 @@ class OracleBundleAdjuster:
         self.L.orc_get_camera_pose(self.h, int(cam_id), _dp(t))
         return t
 
+    def camera_params(self, cam_id=0):
+        p = np.empty(4)
+        self.L.orc_get_camera_params(self.h, int(cam_id), _dp(p))
+        return p
+
+    def proj_calib_jacobians(self):
+        """dz_dk per residual id in the j_kpr_ layout (intrinsics first, then T_vs), unweighted."""
+        j = np.empty((self.GetNumProjResiduals(), 2, self.num_calib_params()))
+        self.L.orc_get_proj_calib_jacobians(self.h, _dp(j))
+        return j
+
     def calibration_marginals(self):
         k = self.num_calib_params()
         c = np.empty((k, k))
@@ -432,3 +443,10 @@ def integrate(pose_t, v, meas, bg, ba, g, r6=None, jac=False):
                              _dp(g), _dp(r), _dp(out_t), _dp(out_v),
                              _dp(db) if jac else None, _dp(c) if jac else None)
     return (out_t, out_v, db, c) if jac else (out_t, out_v)
+
+
+def transfer(params, t_ba, pix, rho, jac=False):
+    """Pinhole Transfer(T_ba, pix, rho) and (jac) its 2x4 Jacobian w.r.t. (fx, fy, u0, v0)."""
+    p, t, x, out, J = _d(params), _d(t_ba), _d(pix), np.empty(2), np.empty((2, 4))
+    lib().orc_math_transfer(_dp(p), _dp(t), _dp(x), C.c_double(rho), _dp(out), _dp(J) if jac else None)
+    return (out, J) if jac else out

@@ -1836,10 +1836,6 @@ def test_calibration_engine_refuses_what_it_does_not_implement():
     with pytest.raises(hipapi.HipError):
         eng.set_calibration(0, True)      # dz_dtvs exists for LmSize 1 only
     eng.close()
-    eng = hipapi.Engine(1, 6)
-    with pytest.raises(hipapi.HipError):
-        eng.set_calibration(5, False)     # camera intrinsics: not implemented
-    eng.close()
     with pytest.raises(ValueError):
         adjuster.BundleAdjuster(3, 6, do_tvs=True)
 
@@ -1864,3 +1860,111 @@ def test_calibration_marginals(oracle_lib, P):
     assert rel_err(cov_h, cov_o) < 1e-7
     assert rel_err(cov_h, np.linalg.inv(o.S())[n:, n:]) < 1e-6
     assert np.all(np.linalg.eigvalsh(0.5 * (cov_h + cov_h.T)) > 0)
+
+
+# ---- camera-intrinsics calibration (CalibSize = 4: fx, fy, u0, v0 of the pinhole model) ---------------
+def _intrinsics_pair(po, sc, pa, wrong, pose_dim=6, **kw):
+    o = po.OracleBundleAdjuster(1, pose_dim, calib_size=4)
+    o.Init(gn_options(po, **kw))
+    h = adjuster.BundleAdjuster(1, pose_dim, calib_size=4)
+    h.Init(hip_options(**kw))
+    for b in (o, h):
+        b.AddCamera(wrong)
+        b.add_poses(sc.poses, is_active=pa)
+        b.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+        b.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    return o, h
+
+
+def _intrinsics_scene(P=40, L=160, K=8, seed=2, **kw):
+    sc = scene.make_scene(P, L, K, lm_dim=1, seed=seed, roll_amp=0.6, **kw)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[::3] = 0
+    sc.poses[::3] = sc.gt_poses[::3]
+    return sc, pa, np.asarray(sc.cam_params) * np.array([1.03, 0.97, 1.02, 0.98])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("triangular", [1, 0])
+def test_intrinsics_calibration_reduced_system_and_step(oracle_lib, triangular):
+    """CalibSize 4: dz_dcam_params per residual, the bordered (n + 4) system, the step and the
+    marginals against the oracle (BundleAdjuster.cpp:493-583, 771-784; parallel_algos.h:114-118)."""
+    po = oracle_lib
+    sc, pa, wrong = _intrinsics_scene(P=30, L=90, K=6, seed=7)
+    o, h = _intrinsics_pair(po, sc, pa, wrong, apply_results=0, use_triangular_matrices=triangular,
+                            calculate_calibration_marginals=1)
+    o.Solve(1)
+    h.Solve(1)
+    n = o.num_pose_params()
+    assert h.num_pose_params() == n and h.engine().num_calib_params() == 4
+    w = np.sqrt(o.proj_weights())[:, None, None]
+    assert rel_err(h.proj_calib_jacobians(), w * o.proj_calib_jacobians()) < 1e-11
+    So, Sh = o.S(), h.S()
+    assert Sh.shape == (n + 4, n + 4)
+    assert rel_err(Sh[:n, :n], So[:n, :n]) < 1e-12
+    assert rel_err(Sh[:n, n:], So[:n, n:]) < 1e-11 and np.abs(So[:n, n:]).max() > 0.1
+    assert rel_err(Sh[n:, n:], So[n:, n:]) < 1e-11
+    assert rel_err(h.rhs(), o.rhs()) < 1e-11
+    assert rel_err(h.delta_p(), o.delta_p()) < 1e-8
+    assert rel_err(h.delta_k(), o.delta_k()) < 1e-8
+    assert rel_err(h.delta_l(), o.delta_l()) < 1e-8
+    if not triangular:
+        assert rel_err(h.calibration_marginals(), o.calibration_marginals()) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_dogleg", [0, 1])
+def test_intrinsics_calibration_iterations_track_oracle_and_recover_the_camera(oracle_lib, use_dogleg):
+    """Six iterations from wrong pinhole parameters: summaries, the rig's parameters, poses and
+    landmarks (whose rays are re-derived from the reference pixels after every step) follow the oracle,
+    and the parameters end close to the ones the scene was rendered with."""
+    po = oracle_lib
+    sc, pa, wrong = _intrinsics_scene(outlier_frac=0.0, pixel_sigma=0.3)
+    o, h = _intrinsics_pair(po, sc, pa, wrong, use_dogleg=use_dogleg)
+    err0 = np.linalg.norm(wrong - sc.cam_params)
+    for it in range(6):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result, it
+        assert abs(so.proj_error - sh.proj_error) < 1e-7 * so.proj_error, it
+        assert abs(so.delta_norm - sh.delta_norm) < 1e-6 * max(so.delta_norm, 1e-12), it
+        assert rel_err(h.camera_params(0), o.camera_params(0)) < 1e-9, it
+    to, _, _ = o.poses()
+    th, _, _ = h.poses()
+    assert rel_err(th, to) < 1e-7
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-7
+    assert np.linalg.norm(h.camera_params(0) - sc.cam_params) < 0.2 * err0
+
+
+@pytest.mark.gpu
+def test_intrinsics_calibration_rejected_step_restores_the_parameters(oracle_lib):
+    """Unlike T_vs the intrinsics ARE restored when a step is rejected (params_backup,
+    BundleAdjuster.cpp:1025-1028, 1066, 1099-1102, 1147)."""
+    po = oracle_lib
+    sc, pa, wrong = _intrinsics_scene(P=30, L=90, K=6, seed=11)
+    o, h = _intrinsics_pair(po, sc, pa, wrong)
+    o.Solve(3)
+    h.Solve(3)
+    assert rel_err(h.camera_params(0), o.camera_params(0)) < 1e-9
+    before = h.camera_params(0).copy()
+    lm_before = h.landmarks().copy()
+    o.Solve(1, 40.0)
+    h.Solve(1, 40.0)
+    assert adjuster.RESULT_NAMES[h.summary().result] == "ErrorIncreased"
+    assert o.summary().result == h.summary().result
+    assert np.array_equal(h.camera_params(0), before)
+    assert rel_err(h.landmarks(), lm_before) < 1e-12
+    assert rel_err(o.camera_params(0), before) < 1e-9
+
+
+@pytest.mark.gpu
+def test_calibration_combinations_that_are_refused():
+    eng = hipapi.Engine(1, 6)
+    with pytest.raises(hipapi.HipError):
+        eng.set_calibration(4, True)      # the reference wipes the intrinsics columns in this combination
+    with pytest.raises(hipapi.HipError):
+        eng.set_calibration(5, False)     # the pinhole model has four parameters
+    eng.close()
+    with pytest.raises(ValueError):
+        adjuster.BundleAdjuster(1, 6, do_tvs=True, calib_size=4)

@@ -121,6 +121,41 @@ def test_extrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc):
     assert worst < 1e-11, worst
 
 
+def test_intrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc):
+    """dz_dcam_params (CalibSize 4): dmath.h proj_intrinsics_rows against the oracle's
+    -dTransfer_dparams(T_sw_m T_ws_r, z_ref, x_s(3)) (parallel_algos.h:115-118)."""
+    po = oracle_lib
+    sc = scene.make_scene(30, 60, 5, lm_dim=1, seed=19)
+    t_vs = np.concatenate([[0.05, -0.02, 0.1], scene.quat_exp(np.array([0.2, -0.3, 0.1]))])
+    o = po.OracleBundleAdjuster(1, 6, calib_size=4)
+    o.Init(gn_options(po, apply_results=0))
+    o.AddCamera(sc.cam_params, t_vs)
+    o.add_poses(sc.poses)
+    o.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    o.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    o.Solve(1)
+    jk_o = o.proj_calib_jacobians()
+    acc = accepted_obs(sc)
+    cam = np.asarray(sc.cam_params, dtype=np.float64)
+    nsel = sc.obs_per_landmark + 1
+    worst = 0.0
+    for rid, (pm, pr, l) in enumerate(acc):
+        xw = np.asarray(sc.landmarks[l], dtype=np.float64)
+        t_sw = po.se3_inv(po.se3_mul(np.asarray(sc.poses[pr], dtype=np.float64), t_vs))
+        p = scene.quat_to_rot(t_sw[3:]) @ xw[:3] + t_sw[:3] * xw[3]
+        rho = xw[3] / np.linalg.norm(p)
+        jk = np.zeros(12)
+        hc.ba_hostcheck_proj_intrinsics_jacobian(
+            _dp(cam), _dp(np.asarray(sc.obs_z[l * nsel], dtype=np.float64)), ctypes.c_double(rho),
+            _dp(np.asarray(sc.poses[pm], dtype=np.float64)), _dp(t_vs),
+            _dp(np.asarray(sc.poses[pr], dtype=np.float64)), _dp(t_vs), _dp(jk))
+        jk = jk.reshape(2, 6)
+        assert np.all(jk[:, 4:] == 0)
+        worst = max(worst, rel_err(jk[:, :4], jk_o[rid]))
+    assert len(acc) > 100 and np.abs(jk_o).max() > 0.1
+    assert worst < 1e-11, worst
+
+
 def test_unary_and_binary_blocks_of_the_kernels_match_the_oracle(oracle_lib, hc):
     po = oracle_lib
     rng = np.random.default_rng(5)

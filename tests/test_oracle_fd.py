@@ -170,6 +170,58 @@ def test_projection_extrinsics_jacobian(oracle_lib):
         assert np.linalg.norm(jk[rid] - fd[rid]) < NORM_THRESHOLD * max(1.0, np.abs(jk[rid]).max()), rid
 
 
+def test_transfer_parameter_jacobian(oracle_lib):
+    """dTransfer_dparams of the pinhole model (the call of parallel_algos.h:115-118; Calibu itself is
+    not in the reference tree): central differences of Transfer(T, pix, rho) over (fx, fy, u0, v0)."""
+    po = oracle_lib
+    rng = np.random.default_rng(0)
+    params = np.array([500.0, 480.0, 320.0, 240.0])
+    for _ in range(40):
+        t = np.concatenate([rng.normal(0, 0.5, 3), po.so3_exp(rng.normal(0, 0.3, 3))])
+        pix = np.array([rng.uniform(50, 600), rng.uniform(50, 430)])
+        rho = rng.uniform(0.05, 0.5)
+        _, J = po.transfer(params, t, pix, rho, jac=True)
+        fd = np.zeros((2, 4))
+        for j in range(4):
+            e = np.zeros(4)
+            e[j] = 1e-4
+            fd[:, j] = (po.transfer(params + e, t, pix, rho) - po.transfer(params - e, t, pix, rho)) / 2e-4
+        assert np.linalg.norm(J - fd) < NORM_THRESHOLD
+    # identity transfer: Project(Unproject(pix)) = pix whatever the parameters
+    _, J = po.transfer(params, np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([100.0, 50.0]), 0.3, jac=True)
+    assert np.abs(J).max() < 1e-12
+
+
+def test_projection_intrinsics_jacobian_in_place(oracle_lib):
+    """dz_dcam_params of the CalibSize instantiations is -dTransfer_dparams(T_sw_m T_ws_r, z_ref,
+    x_s(3)) — evaluated at the reference PIXEL with the inverse depth of the unit-length ray
+    (parallel_algos.h:115-118 as written, not the derivative of the residual itself)."""
+    po = oracle_lib
+    sc = scene.make_scene(24, 12, 4, lm_dim=1, seed=8)
+    ba = po.OracleBundleAdjuster(1, 6, calib_size=4)
+    o = po.default_options()
+    o.use_dogleg = 0
+    o.apply_results = 0
+    ba.Init(o)
+    ba.AddCamera(sc.cam_params)
+    ba.add_poses(sc.poses)
+    ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    ba.Solve(1)
+    jk = ba.proj_calib_jacobians()
+    assert jk.shape[1:] == (2, 4) and np.abs(jk).max() > 0.1
+    acc = accepted_obs(sc)
+    nsel = sc.obs_per_landmark + 1
+    for rid, (m, r, l) in enumerate(acc):
+        z_ref = sc.obs_z[l * nsel]  # the landmark's first observation is the reference one
+        t = po.se3_mul(po.se3_inv(sc.poses[m]), sc.poses[r])
+        t_sw = po.se3_inv(sc.poses[r])
+        xs = scene.quat_to_rot(t_sw[3:]) @ sc.landmarks[l, :3] + t_sw[:3] * sc.landmarks[l, 3]
+        rho = sc.landmarks[l, 3] / np.linalg.norm(xs)
+        _, J = po.transfer(sc.cam_params, t, z_ref, rho, jac=True)
+        assert np.linalg.norm(jk[rid] + J) < 1e-9 * max(1.0, np.abs(J).max())
+
+
 @pytest.mark.parametrize("lm_dim", [1, 3])
 def test_projection_landmark_jacobian(oracle_lib, lm_dim):
     po = oracle_lib
