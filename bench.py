@@ -404,17 +404,21 @@ def main():
         # 128x128 blocks on trailing matrices of >= 128 tiles, the capped 64-tile kernel below
         bulk_kernel = "k_update128<false>" if n >= 128 * 64 else "k_update2<true>"
 
+        def pmc_entry(name):
+            # exact kernel name, else the one instantiation that starts with it (template arguments
+            # added since the pass was recorded)
+            if name in pmc:
+                return pmc[name]
+            hits = [k for k in pmc if k.startswith(name.rstrip(">"))]
+            return pmc[hits[0]] if len(hits) == 1 else None
+
         def pmc_bytes(name):
-            try:
-                return pmc[name]["traffic_bytes_per_launch_corrected"]
-            except KeyError:
-                return None
+            e = pmc_entry(name)
+            return e["traffic_bytes_per_launch_corrected"] if e else None
 
         def pmc_raw(name):
-            try:
-                return (pmc[name].get("FETCH_SIZE_KB_per_launch", 0.0) + pmc[name].get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
-            except KeyError:
-                return None
+            e = pmc_entry(name)
+            return (e.get("FETCH_SIZE_KB_per_launch", 0.0) + e.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0 if e else None
         out = {
             "metric": "Gauss-Newton iterations/sec",
             "value": args.steps / elapsed,

@@ -28,7 +28,7 @@ def demangle(name):
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    d = os.path.join(root, "gpurun_out", "pmc_%s_cfg%d" % (ctr, cfg))
+    d = os.path.join("/tmp", "pmc_%s_cfg%d" % (ctr, cfg))  # raw pass output: large, not worth copying back
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--",
            "python3", os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-api", "--steps", "1", "--warmup", "0",
@@ -52,6 +52,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         short = demangle(name)
         o = out.setdefault(short, {"launches": n})
         o["%s_KB_per_launch" % ctr] = tot / n
+    c.close()
+    shutil.rmtree(d, ignore_errors=True)
 for k, o in out.items():
     f = o.get("FETCH_SIZE_KB_per_launch", 0.0); w = o.get("WRITE_SIZE_KB_per_launch", 0.0)
     o["traffic_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
