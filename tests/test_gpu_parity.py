@@ -1968,3 +1968,56 @@ def test_calibration_combinations_that_are_refused():
     eng.close()
     with pytest.raises(ValueError):
         adjuster.BundleAdjuster(1, 6, do_tvs=True, calib_size=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+def test_calibration_edge_cases_match_oracle(oracle_lib, kind):
+    """Both calibration kinds on a graph with a landmark seen from 150 poses (the two-pass variant of
+    the linearisation kernel), duplicate observations, inactive poses and landmarks, and weights:
+    reduced system, border, step against the oracle."""
+    po = oracle_lib
+    sc = scene.make_scene(60, 200, 7, lm_dim=1, seed=123, roll_amp=0.6)
+    rng = np.random.default_rng(4)
+    nsel = sc.obs_per_landmark + 1
+    z, pose, lm = sc.obs_z.copy(), sc.obs_pose.copy(), sc.obs_lm.copy()
+    dup = rng.choice(len(pose), 40, replace=False)
+    dup = dup[dup % nsel != 0]  # not the reference observations (they define z_ref)
+    big_pose = rng.integers(0, sc.num_poses, 150).astype(pose.dtype)
+    big_pose = big_pose[big_pose != sc.lm_ref_pose[7]]
+    zb = sc.obs_z[1:1 + len(big_pose)] + rng.normal(0, 1.0, (len(big_pose), 2))
+    z = np.concatenate([z, z[dup] + 0.3, zb])
+    pose = np.concatenate([pose, pose[dup], big_pose])
+    lm = np.concatenate([lm, lm[dup], np.full(len(big_pose), 7, dtype=lm.dtype)])
+    w = rng.uniform(0.5, 2.0, len(pose))
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[::3] = 0
+    la = np.ones(sc.num_landmarks, dtype=np.uint8)
+    la[[2, 50, 51]] = 0
+    t_vs = T_VS_MOUNT
+    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=4)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, apply_results=0, use_triangular_matrices=0)),
+                      (adjuster.BundleAdjuster, hip_options(apply_results=0, use_triangular_matrices=0))):
+        b = cls(1, 6, **kw)
+        b.Init(opts)
+        b.AddCamera(sc.cam_params, t_vs)
+        b.add_poses(sc.poses, is_active=pa)
+        b.add_landmarks(sc.landmarks, sc.lm_ref_pose, is_active=la)
+        b.add_projection_residuals(z, pose, lm, weight=w)
+        b.Solve(1)
+        objs.append(b)
+    o, h = objs
+    n, K = o.num_pose_params(), o.num_calib_params()
+    assert h.engine().structure_stats()["linearize_waves"] > 0
+    ws = np.sqrt(o.proj_weights())[:, None, None]
+    assert rel_err(h.proj_calib_jacobians(), ws * o.proj_calib_jacobians()) < 1e-11
+    # the 150 extra observations carry pixels of other landmarks: residuals of hundreds of pixels, points
+    # near the image plane, Jacobians of 1e5 and more — the Schur complement cancels several digits.
+    # Rounding-order tolerances (the per-residual Jacobians above agree to 1e-11); step: north_star's 1e-6
+    assert rel_err(h.S(), o.S()) < 1e-9
+    assert rel_err(h.S()[:n, n:], o.S()[:n, n:]) < 1e-9 and rel_err(h.S()[n:, n:], o.S()[n:, n:]) < 1e-9
+    assert rel_err(h.rhs(), o.rhs()) < 1e-9
+    assert rel_err(h.delta_k(), o.delta_k()) < 1e-6 and rel_err(h.delta_p(), o.delta_p()) < 1e-6
+    assert rel_err(h.delta_l(), o.delta_l()) < 1e-6
+    assert K == (6 if kind == "tvs" else 4)
