@@ -2021,3 +2021,106 @@ def test_calibration_edge_cases_match_oracle(oracle_lib, kind):
     assert rel_err(h.delta_k(), o.delta_k()) < 1e-6 and rel_err(h.delta_p(), o.delta_p()) < 1e-6
     assert rel_err(h.delta_l(), o.delta_l()) < 1e-6
     assert K == (6 if kind == "tvs" else 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+@pytest.mark.parametrize("distributed", [0, 1], ids=["replicated_solve", "distributed_solve"])
+def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
+    """Calibration unknowns with the landmarks sharded over three engines (threads + in-process
+    hooks, as the other shard tests): the border blocks S_pk / S_kk and rhs_k are sums over the shards
+    like the rest of S; with the collectives hook the bordered system goes through the distributed
+    factorisation.  Three iterations against ONE engine and against the oracle: steps, errors, the
+    camera's T_vs / parameters on every rank."""
+    import threading
+
+    from ba_amd import sharding
+    po = oracle_lib
+    nranks = 3
+    P = 150 if distributed else 40
+    sc = scene.make_scene(P, 10 * P, 6, lm_dim=1, seed=67, roll_amp=0.6, outlier_frac=0.0, pixel_sigma=0.3)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[::3] = 0
+    sc.poses[::3] = sc.gt_poses[::3]
+    if kind == "tvs":
+        sc = scene.mount_camera(sc, T_VS_MOUNT)
+        t_vs0 = po.exp_decoupled(T_VS_MOUNT, np.array([0.03, -0.02, 0.02, 0.01, -0.015, 0.01]))
+        sc.landmarks = scene.remount_landmarks(sc, T_VS_MOUNT, t_vs0)
+        cam0 = np.asarray(sc.cam_params, dtype=np.float64)
+    else:
+        t_vs0 = np.array([0, 0, 0, 0, 0, 0, 1.0])
+        cam0 = np.asarray(sc.cam_params) * np.array([1.02, 0.98, 1.01, 0.99])
+    nsel = sc.obs_per_landmark + 1
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    keep[::nsel] = False
+    z_ref = sc.obs_z[::nsel]
+
+    def make(lo, hi):
+        sel = keep & (sc.obs_lm >= lo) & (sc.obs_lm < hi)
+        eng = hipapi.Engine(1, 6)
+        eng.set_calibration(0 if kind == "tvs" else 4, kind == "tvs")
+        eng.set_cameras(cam0, t_vs0)
+        eng.set_poses(sc.poses, is_active=pa)
+        eng.set_landmarks(sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi])
+        if kind == "intrinsics":
+            eng.set_landmark_ref_pixels(z_ref[lo:hi])
+        eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], sc.obs_lm[sel] - lo)
+        eng.finalize()
+        eng.begin_solve()
+        eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+        return eng
+
+    def calib_state(eng):
+        return eng.get_cameras(1)[0] if kind == "tvs" else eng.get_camera_params(1)[0]
+
+    L = sc.num_landmarks
+    single = make(0, L)
+    out = {}
+    _run_engine_steps(single, 3, out, "single")
+    shards = sharding.landmark_shards(np.full(L, sc.obs_per_landmark), nranks)
+    engs = [make(*shards[r]) for r in range(nranks)]
+    ar = sharding.ThreadAllReduce(nranks)
+    for r in range(nranks):
+        engs[r].set_allreduce(ar.hook(r), r, nranks)
+        if distributed:
+            engs[r].set_collectives(ar.collectives(r))
+        assert bool(engs[r].solve_is_distributed()) == bool(distributed)
+    th = [threading.Thread(target=_run_engine_steps, args=(engs[r], 3, out, r)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=180)
+    assert not ar.failed
+    for k in ["single"] + list(range(nranks)):
+        assert not isinstance(out[k], Exception), out[k]
+    n = single.num_pose_params()
+    for it in range(3):
+        a = out["single"][it]
+        for r in range(nranks):
+            b = out[r][it]
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                assert abs(x - y) <= 1e-7 * max(abs(x), 1e-12)
+    for r in range(nranks):
+        assert rel_err(out[(r, "delta_p")], out[("single", "delta_p")]) < 1e-7   # [delta_p ; delta_k] of iteration 0
+        assert rel_err(calib_state(engs[r]), calib_state(single)) < 1e-9
+        assert np.array_equal(calib_state(engs[r]), calib_state(engs[0]))        # every rank moves the camera alike
+    # the oracle on the whole scene
+    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=4)
+    o = po.OracleBundleAdjuster(1, 6, **kw)
+    o.Init(gn_options(po))
+    o.AddCamera(cam0, t_vs0)
+    o.add_poses(sc.poses, is_active=pa)
+    o.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    o.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    for it in range(3):
+        o.Solve(1)
+        if it == 0:
+            assert rel_err(out[(0, "delta_p")][:n], o.delta_p()) < 1e-6
+            assert rel_err(out[(0, "delta_p")][n:], o.delta_k()) < 1e-6
+        if adjuster.RESULT_NAMES[o.summary().result] == "Success":
+            assert abs(out[0][it][3] - o.summary().proj_error) <= 1e-7 * o.summary().proj_error
+    oc = o.camera_pose(0) if kind == "tvs" else o.camera_params(0)
+    assert rel_err(calib_state(engs[0]), oc) < 1e-7
+    for e_ in engs + [single]:
+        e_.end_solve()
