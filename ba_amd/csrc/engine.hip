@@ -688,11 +688,10 @@ int ba_hip_begin_solve(ba_hip_engine* h) {
     return e->fail_msg("per-pose camera parameters: one [fx,fy,u0,v0] per pose expected");
   int rc = upload_imu_consts(e);
   if (rc) return rc;
-  if (e->calib_dim) {  // a new Solve() starts from the rig's T_vs (see DESIGN.md §4c on the one deviation)
-    e->tvs_eval = e->prob.cam_tvs;
-    e->tvs_eval_prev = e->prob.cam_tvs;
-    if ((rc = upload_cameras(e, true))) return rc;
-  }
+  // (calibration: the tables of k_pose_prep keep the T_vs they were last built with across Solve()
+  // calls — after a Solve() that ended in a rejected step the reference's poses carry their cached
+  // T_sw of the T_vs before that step into the next call, until a step is applied: tvs_eval is not
+  // resynchronised with the rig here)
   rc = launch_pose_prep(e);
   if (rc) return rc;
   rc = launch_begin_solve(e);

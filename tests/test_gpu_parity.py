@@ -1801,6 +1801,18 @@ def test_calibration_multi_iteration_solve_and_rejected_step(oracle_lib):
     assert rel_err(po_after, po_before) < 1e-12                        # poses restored
     assert np.linalg.norm(o.camera_pose(0) - before_o) > 1e-6           # the oracle's T_vs moved ...
     assert rel_err(h.camera_pose(0) - before_h, o.camera_pose(0) - before_o) < 1e-5  # ... and so did ours, alike
+    # the world points written back at the end of that Solve() come from the restored caches (the
+    # T_vs BEFORE the rejected step) on both sides
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-10
+    # Known deviation: a LINEARISATION in that state — the next Solve() call — mixes
+    # cached T_sw (old T_vs) and the rig (new T_vs) inside the reference's Jacobian chains; the engine's
+    # closed forms take the rig's T_vs where the chain does and the cached transforms elsewhere, but
+    # they were derived for consistent inputs: the steps agree to first order in the rejected update
+    # only, until the next applied step rebuilds the caches.
+    o.Solve(1)
+    h.Solve(1)
+    assert o.summary().result == h.summary().result
+    assert rel_err(h.camera_pose(0), o.camera_pose(0)) < 0.1
 
 
 @pytest.mark.gpu
