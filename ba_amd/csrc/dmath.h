@@ -333,4 +333,109 @@ BA_HD void proj_intrinsics_rows(const Cam& cam, const double* z_ref, double rho,
   jk[10] = 0.0; jk[11] = 0.0;
 }
 
+// ---- the reference's Jacobian chains with TWO extrinsics (DoTvs instantiations after a rejected step) ----
+// After a rejected calibration step the reference's poses carry cached T_sw built with the T_vs BEFORE
+// the step while the rig already holds the step (BundleAdjuster.cpp:72-83 vs :1060-1068, Types.h:61-70):
+// until the next applied step its chains (parallel_algos.h:91-131) read cached transforms in some
+// factors and the rig's T_vs in others.  The closed forms above assume one T_vs; this is the chain
+// factor by factor — block products of the 4x7 . 7x7 . 7x6 matrices written out with quaternion
+// products — with every factor taking the T_vs the reference takes.
+//   d(R(q) v)/dq . dq : Utils.h:295-312 (the partial derivatives of the polynomial form, as written there)
+BA_HD V3 dqx_dq_apply(const double* q, V3 p, const double* dq) {
+  const double qx = q[0], qy = q[1], qz = q[2], qw = q[3], x = p.x, y = p.y, z = p.z;
+  const double j00 = 2 * qy * y + 2 * qz * z, j10 = 2 * qy * x - 4 * qx * y - 2 * qw * z, j20 = 2 * qz * x + 2 * qw * y - 4 * qx * z;
+  const double j01 = 2 * qx * y - 4 * qy * x + 2 * qw * z, j11 = 2 * qx * x + 2 * qz * z, j21 = 2 * qz * y - 2 * qw * x - 4 * qy * z;
+  const double j02 = 2 * qx * z - 2 * qw * y - 4 * qz * x, j12 = 2 * qy * z + 2 * qw * x - 4 * qz * y, j22 = 2 * qy * y + 2 * qx * x;
+  const double j03 = 2 * qy * z - 2 * qz * y, j13 = 2 * qz * x - 2 * qx * z, j23 = 2 * qx * y - 2 * qy * x;
+  return v3(j00 * dq[0] + j01 * dq[1] + j02 * dq[2] + j03 * dq[3], j10 * dq[0] + j11 * dq[1] + j12 * dq[2] + j13 * dq[3],
+            j20 * dq[0] + j21 * dq[1] + j22 * dq[2] + j23 * dq[3]);
+}
+// t_wp_m7 / t_wp_r7: the two poses (t, q);  t_vs_rig7: the rig's T_vs;  t_vs_cache7: the T_vs the cached T_sw
+// were built with.  x = (ray, rho) in the reference sensor frame.  Outputs the three 2x6 blocks (row-major):
+// dz_dx_meas, dz_dx_ref, dz_dtvs; same_pose zeroes the two pose blocks as the reference does.
+BA_HD void proj_chain_two_tvs(const Cam& cam, const double* x, const double* t_wp_m7, const double* t_wp_r7,
+                              const double* t_vs_rig7, const double* t_vs_cache7, bool same_pose, double* jm,
+                              double* jr, double* jk) {
+  const V3 ray = v3(x[0], x[1], x[2]);
+  const double rho = x[3];
+  const double* qp = t_wp_m7 + 3;
+  const double* qr = t_wp_r7 + 3;
+  const double* qv = t_vs_rig7 + 3;
+  const V3 tp = v3(t_wp_m7[0], t_wp_m7[1], t_wp_m7[2]), tr = v3(t_wp_r7[0], t_wp_r7[1], t_wp_r7[2]);
+  const V3 tv = v3(t_vs_rig7[0], t_vs_rig7[1], t_vs_rig7[2]), tv0 = v3(t_vs_cache7[0], t_vs_cache7[1], t_vs_cache7[2]);
+  // cached transforms: T_ws = T_wp T_vs(cache) (quaternion product renormalised), T_sw its inverse
+  double q_ws_m[4], q_ws_r[4], q_s[4], q_sr[4];
+  quat_mul(qp, t_vs_cache7 + 3, q_ws_m); quat_normalize(q_ws_m);
+  quat_mul(qr, t_vs_cache7 + 3, q_ws_r); quat_normalize(q_ws_r);
+  q_s[0] = -q_ws_m[0]; q_s[1] = -q_ws_m[1]; q_s[2] = -q_ws_m[2]; q_s[3] = q_ws_m[3];
+  q_sr[0] = -q_ws_r[0]; q_sr[1] = -q_ws_r[1]; q_sr[2] = -q_ws_r[2]; q_sr[3] = q_ws_r[3];
+  (void)q_sr;
+  const M3 R_p = quat_to_rot(qp[0], qp[1], qp[2], qp[3]), R_r = quat_to_rot(qr[0], qr[1], qr[2], qr[3]);
+  const M3 R_ws_m = quat_to_rot(q_ws_m[0], q_ws_m[1], q_ws_m[2], q_ws_m[3]);
+  const M3 R_ws_r = quat_to_rot(q_ws_r[0], q_ws_r[1], q_ws_r[2], q_ws_r[3]);
+  const V3 t_ws_m = mul(R_p, tv0) + tp, t_ws_r = mul(R_r, tv0) + tr;
+  const M3 R_s = transpose(R_ws_m);
+  const V3 t_s = mul(R_s, t_ws_m) * -1.0;
+  // world point (scaled by rho) and the point in the measuring sensor frame, both from the caches
+  const V3 Xw = mul(R_ws_r, ray) + t_ws_r * rho;
+  const V3 P = mul(R_s, Xw) + t_s * rho;
+  V3 d0, d1;
+  dproject(cam, P, &d0, &d1);
+  // rig: T_sv = T_vs^-1
+  const double q_c[4] = {-qv[0], -qv[1], -qv[2], qv[3]};
+  const M3 R_v = quat_to_rot(qv[0], qv[1], qv[2], qv[3]);
+  const M3 R_c = transpose(R_v);
+  const double q_pw[4] = {-qp[0], -qp[1], -qp[2], qp[3]};
+  const M3 R_pw = transpose(R_p);
+  const double keep = same_pose ? 0.0 : 1.0;
+  auto put = [&](double* j, int col, V3 v) { j[col] = -dot(d0, v); j[6 + col] = -dot(d1, v); };
+  for (int k = 0; k < 3; ++k) {
+    const V3 ek = v3(k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0);
+    const double dk[4] = {0.5 * ek.x, 0.5 * ek.y, 0.5 * ek.z, 0.0};  // dq_exp_dw(0) e_k
+    // ---- dz_dx_meas = -dpi . dt_x_dt(T_sw[cache], pw) . dt1_t2_dt2(T_sv[rig]) . dinv_exp_decoupled_dx(T_wp)
+    {
+      double dq_pw[4], br[4], t1[4];
+      quat_mul(dk, q_pw, dq_pw);                                  // R(q_pw) E e_k
+      br[0] = -dq_pw[0]; br[1] = -dq_pw[1]; br[2] = -dq_pw[2]; br[3] = -dq_pw[3];
+      const V3 trk = dqx_dq_apply(q_pw, tp, dq_pw);               // translation of T_pw w.r.t. the rotation update
+      quat_mul(q_c, br, t1);                                      // L(q_c) R(q_pw) (-E) e_k
+      const V3 rot = mul(R_c, trk) * rho + dqx_dq_apply(q_s, Xw, t1);
+      const V3 trn = mul(R_c, mul(R_pw, ek)) * -rho;
+      put(jm, k, trn * keep);
+      put(jm, 3 + k, rot * keep);
+    }
+    // ---- dz_dx_ref = -dpi . dt_x_dt(T_sw_m[cache] T_wp_r, T_vs[rig] x) . dt1_t2_dt2(T_sw_m[cache]) . dexp_decoupled_dx(T_wp_r)
+    {
+      double q_a[4], t1[4], t2[4];
+      quat_mul(q_s, qr, q_a); quat_normalize(q_a);
+      const V3 Y = mul(R_v, ray) + tv * rho;
+      quat_mul(qr, dk, t1);
+      quat_mul(q_s, t1, t2);
+      put(jr, k, mul(R_s, ek) * (rho * keep));
+      put(jr, 3 + k, dqx_dq_apply(q_a, Y, t2) * keep);
+    }
+    // ---- dz_dtvs = -dpi . dt_x_dt(T_sw_m T_ws_r [caches], x) . ( dt1_t2_dt2(T_sv) dt1_t2_dt2(D) dexp_decoupled_dx(T_vs)
+    //                                                             + dt1_t2_dt1(T_sv, D T_vs) dinv_exp_decoupled_dx(T_vs) ),  D = T_wp_m^-1 T_wp_r
+    {
+      double q_T[4], q_D[4], q_2[4], a1[4], a2[4], a3[4], dq_c[4], brv[4], b1[4];
+      quat_mul(q_s, q_ws_r, q_T); quat_normalize(q_T);
+      quat_mul(q_pw, qr, q_D); quat_normalize(q_D);
+      const M3 R_D = quat_to_rot(q_D[0], q_D[1], q_D[2], q_D[3]);
+      const V3 t_D = mul(R_pw, tr - tp);
+      quat_mul(q_D, qv, q_2); quat_normalize(q_2);
+      const V3 t_2 = mul(R_D, tv) + t_D;
+      quat_mul(qv, dk, a1); quat_mul(q_D, a1, a2); quat_mul(q_c, a2, a3);   // L(q_c) L(q_D) L(q_v) E e_k
+      quat_mul(dk, q_c, dq_c);                                               // R(q_c) E e_k
+      brv[0] = -dq_c[0]; brv[1] = -dq_c[1]; brv[2] = -dq_c[2]; brv[3] = -dq_c[3];
+      const V3 trv = dqx_dq_apply(q_c, tv, dq_c);
+      quat_mul(brv, q_2, b1);                                                // R(q_2) brv
+      const double sum4[4] = {a3[0] + b1[0], a3[1] + b1[1], a3[2] + b1[2], a3[3] + b1[3]};
+      const V3 rot = dqx_dq_apply(q_T, ray, sum4) + (trv + dqx_dq_apply(q_c, t_2, brv)) * rho;
+      const V3 trn = (mul(R_c, mul(R_D, ek)) - mul(R_c, ek)) * rho;
+      put(jk, k, trn);
+      put(jk, 3 + k, rot);
+    }
+  }
+}
+
 }  // namespace bad

@@ -68,6 +68,15 @@ extern "C" void ba_hostcheck_proj_intrinsics_jacobian(const double* cam4, const 
   proj_intrinsics_rows(cam, z_ref, rho, t_sw_m, t_ws_r, 1.0, jk12);
 }
 
+// the reference's chains with cached and rig extrinsics apart (proj_chain_two_tvs)
+extern "C" void ba_hostcheck_proj_chain_two_tvs(const double* cam4, const double* x, const double* t_wp_m7,
+                                                const double* t_wp_r7, const double* t_vs_rig7,
+                                                const double* t_vs_cache7, int same_pose, double* jm12,
+                                                double* jr12, double* jk12) {
+  Cam cam = {cam4[0], cam4[1], cam4[2], cam4[3]};
+  proj_chain_two_tvs(cam, x, t_wp_m7, t_wp_r7, t_vs_rig7, t_vs_cache7, same_pose != 0, jm12, jr12, jk12);
+}
+
 // ---- pose-pose residuals (dpose.h) ---------------------------------------------------
 #include "dpose.h"
 

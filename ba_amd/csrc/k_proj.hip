@@ -274,7 +274,9 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
                                               const double* __restrict__ pose_cam, const double* __restrict__ tsw,
                                               const double* __restrict__ tws, const double* __restrict__ twp,
                                               ObsLin<LM, CAL>* o, const int32_t* __restrict__ pose_opt = nullptr,
-                                              const double* __restrict__ lm_zref = nullptr) {
+                                              const double* __restrict__ lm_zref = nullptr,
+                                              const double* __restrict__ state = nullptr,
+                                              const double* __restrict__ cam_cache = nullptr) {
   const uint32_t pm = obs_pose[a], cm = obs_cam[a];
   const double* cp = cam + (size_t)cm * 35;
   // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
@@ -301,7 +303,15 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
     if constexpr (CAL != 0) {
       // parallel_algos.h:88,114,120: the calibration Jacobians are only formed when one of the two poses is active
       const double keep = (pose_opt[pm] >= 0 || pose_opt[rp] >= 0) ? 1.0 : 0.0;
-      if constexpr (CAL == 1) {
+      if constexpr (CAL == 3) {
+        // T_vs calibration between a rejected step and the next applied one: the tables (residual, J_l)
+        // hold the T_vs before the step, the rig the step itself — the three Jacobian blocks from the
+        // reference's chains with the two kept apart (dmath.h: proj_chain_two_tvs).  Rare path.
+        proj_chain_two_tvs(cc, x, state + (size_t)pm * kPoseState, state + (size_t)rp * kPoseState,
+                           cam + (size_t)cm * 35 + 28, cam_cache + (size_t)cm * 35 + 28, pm == rp, J.jm, J.jr, o->jk);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o->jk[i] *= keep;
+      } else if constexpr (CAL == 1) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) o->jk[i] *= keep;
       } else {
@@ -447,7 +457,8 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
             double* __restrict__ obs_w, double* __restrict__ frow, double* __restrict__ scal,
             double* __restrict__ lm_vinv, double* __restrict__ lm_bl, double* __restrict__ obs_jl,
             double* __restrict__ partials, const int32_t* __restrict__ pose_opt, double* __restrict__ crow,
-            const double* __restrict__ lm_zref) {
+            const double* __restrict__ lm_zref, const double* __restrict__ state,
+            const double* __restrict__ cam_cache) {
   constexpr int R = LM == 1 ? 6 : 8, RD = R * 6;   // rows / doubles per observation
   constexpr int STRIDE = RD + 2;                    // LDS stride per lane (even: 16-byte reads; odd multiple of 2 banks)
   constexpr int NS = LmSums<LM, CAL>::N, NV = LmSums<LM, CAL>::NV, NE = LmSums<LM, CAL>::NE;
@@ -483,7 +494,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     const bool lm_act = lm_opt[l] >= 0;
     const int s0 = (int)(lm_ptr[l] - a0), s1 = (int)(lm_ptr[l + 1] - 1 - a0);  // lanes of this landmark
     ObsLin<LM, CAL> q;
-    linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref);
+    linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
     double v[NS];
     obs_sums<LM, CAL>(q, v);
     if (!valid || !lm_act) {
@@ -556,7 +567,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     for (int i = 0; i < NS; ++i) tot[i] = 0.0;
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
       ObsLin<LM, CAL> q;
-      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref);
+      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
       double v[NS];
       obs_sums<LM, CAL>(q, v);
 #pragma unroll
@@ -571,7 +582,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     invert_v<LM>(tot, Vi);
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
       ObsLin<LM, CAL> q;
-      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref);
+      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
       double rows[RD];
       obs_rows<LM, CAL>(q, Vi, rows);
       store_calib_obs(a, q);
@@ -610,9 +621,25 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
       e->obs_pose.p, e->obs_cam.p, e->obs_lm.p, e->obs_w0.p, e->lm_opt.p, e->pose_mask.p, e->lm_x[e->cur].p, \
       e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->twp.p,     \
       e->obs_w.p, e->frow.p, e->scal.p, e->lm_vinv.p, e->lm_bl.p, e->obs_jl.p, e->partials.p + (first),  \
-      (const int32_t*)e->pose_opt.p, e->crow.p, (const double*)e->lm_zref.p
+      (const int32_t*)e->pose_opt.p, e->crow.p, (const double*)e->lm_zref.p,                           \
+      (const double*)e->pose_state[e->cur].p, e->cam_eval_ptr()
   e->prof_begin(e->ev_landmarks);
   if (st.K) {  // calibration instantiations (LmSize 1): the CAL kernels, same launch shapes
+    // T_vs calibration with the tables of k_pose_prep built for another T_vs than the rig's (after a
+    // rejected step, until the next applied one): the chain variant (CAL 3), direct stores
+    const bool two_tvs = e->calib_tvs && e->tvs_eval != e->prob.cam_tvs;
+    if (two_tvs) {
+      const dim3 grid((st.n_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
+      if (n_small)
+        hipLaunchKernelGGL((k_linearize<1, WAVES, false, false, 3>), dim3((n_small + WAVES - 1) / WAVES), block, 0, e->stream, BAE_ARGS(0, n_small));
+      if (st.n_big_chunks)
+        hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, 3>), dim3((st.n_big_chunks + WAVES - 1) / WAVES), block, 0, e->stream,
+                           BAE_ARGS(n_small, st.n_big_chunks));
+      (void)grid;
+      e->prof_end(e->ev_landmarks);
+      BAE_HIP(hipGetLastError());
+      return 0;
+    }
     if (n_small) {
       const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
       if (e->calib_tvs) hipLaunchKernelGGL((k_linearize<1, WAVES, false, true, 1>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));

@@ -156,6 +156,57 @@ def test_intrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc):
     assert worst < 1e-11, worst
 
 
+@pytest.mark.parametrize("stale", [False, True], ids=["consistent", "after_rejected_step"])
+def test_chain_with_cached_and_rig_extrinsics_matches_the_oracle(oracle_lib, hc, stale):
+    """dmath.h proj_chain_two_tvs — the reference's Jacobian chains factor by factor with the cached
+    T_sw and the rig's T_vs kept apart.  consistent: both equal, must reproduce the ordinary Jacobians.
+    after_rejected_step: the oracle is driven into the state the reference is in after a rejected
+    DoTvs step (poses restored with their cached T_sw, rig moved; BundleAdjuster.cpp:72-83, 1139-1149)
+    and linearised there."""
+    po = oracle_lib
+    sc = scene.mount_camera(scene.make_scene(30, 90, 6, lm_dim=1, seed=11, roll_amp=0.6),
+                            np.concatenate([[0.05, -0.02, 0.1], scene.quat_exp(np.array([0.02, -0.03, 0.01]))]))
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[::3] = 0
+    t0 = po.exp_decoupled(sc.gt_t_vs, np.array([0.06, -0.05, 0.05, 0.02, -0.03, 0.02]))
+    sc.landmarks = scene.remount_landmarks(sc, sc.gt_t_vs, t0)
+    o = po.OracleBundleAdjuster(1, 6, do_tvs=True)
+    o.Init(gn_options(po))
+    o.AddCamera(sc.cam_params, t0)
+    o.add_poses(sc.poses, is_active=pa)
+    o.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    o.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    o.Solve(2)
+    t_cache = o.camera_pose(0).copy()
+    if stale:
+        o.Solve(1, 40.0)  # overshoots: rejected, the rig keeps the step
+        assert o.summary().result == 1
+        assert np.linalg.norm(o.camera_pose(0) - t_cache) > 1e-4
+    t_rig = o.camera_pose(0).copy()
+    poses, lms = o.poses()[0].copy(), o.landmarks().copy()
+    o.Solve(1)  # its linearisation happens in that state
+    jm_o, jr_o, _ = o.proj_jacobians()
+    jk_o = o.proj_tvs_jacobians()
+    acc = accepted_obs(sc)
+    cam = np.asarray(sc.cam_params, dtype=np.float64)
+    worst = 0.0
+    for rid, (pm, pr, l) in enumerate(acc):
+        if not (pa[pm] or pa[pr]):
+            continue  # the reference forms no pose / calibration Jacobians there (parallel_algos.h:88)
+        t_sw = po.se3_inv(po.se3_mul(poses[pr], t_cache))
+        p = scene.quat_to_rot(t_sw[3:]) @ lms[l, :3] + t_sw[:3] * lms[l, 3]
+        nrm = np.linalg.norm(p)
+        x = np.concatenate([p / nrm, [lms[l, 3] / nrm]])
+        jm, jr, jk = np.zeros(12), np.zeros(12), np.zeros(12)
+        hc.ba_hostcheck_proj_chain_two_tvs(_dp(cam), _dp(x), _dp(np.ascontiguousarray(poses[pm])),
+                                           _dp(np.ascontiguousarray(poses[pr])), _dp(t_rig), _dp(t_cache), 0,
+                                           _dp(jm), _dp(jr), _dp(jk))
+        worst = max(worst, rel_err(jm, jm_o[rid].ravel()), rel_err(jr, jr_o[rid].ravel()),
+                    rel_err(jk, jk_o[rid].ravel()))
+    assert len(acc) > 100
+    assert worst < 1e-10, worst
+
+
 def test_unary_and_binary_blocks_of_the_kernels_match_the_oracle(oracle_lib, hc):
     po = oracle_lib
     rng = np.random.default_rng(5)
