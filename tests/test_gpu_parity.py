@@ -2138,3 +2138,44 @@ def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
     assert rel_err(calib_state(engs[0]), oc) < 1e-7
     for e_ in engs + [single]:
         e_.end_solve()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+def test_calibration_at_config1_scale_matches_oracle(oracle_lib, kind):
+    """The self-calibration instantiations at the size of BASELINE.json configs[1] (1k poses / 100k
+    landmarks / 1M residuals, a tenth of the poses held fixed): the first Gauss-Newton step
+    [delta_p ; delta_k], delta_l and the moved camera against the oracle (north_star: 1e-6)."""
+    po = oracle_lib
+    sc = scene.make_scene(1000, 100000, 10, lm_dim=1, seed=2)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[::10] = 0
+    sc.poses[::10] = sc.gt_poses[::10]
+    ident = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    if kind == "tvs":
+        t0 = po.exp_decoupled(ident, np.array([0.02, -0.02, 0.02, 0.005, -0.01, 0.005]))
+        sc.landmarks = scene.remount_landmarks(sc, ident, t0)
+        cam0, kw = np.asarray(sc.cam_params, dtype=np.float64), dict(do_tvs=True)
+    else:
+        t0, cam0, kw = ident, np.asarray(sc.cam_params) * np.array([1.01, 0.99, 1.005, 0.995]), dict(calib_size=4)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po)), (adjuster.BundleAdjuster, hip_options(write_reduced_camera_matrix=0))):
+        b = cls(1, 6, **kw)
+        b.Init(opts)
+        b.AddCamera(cam0, t0)
+        b.add_poses(sc.poses, is_active=pa)
+        b.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+        b.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+        b.Solve(1)
+        objs.append(b)
+    o, h = objs
+    assert o.summary().result == h.summary().result == 0
+    assert abs(o.summary().proj_error - h.summary().proj_error) <= 1e-9 * o.summary().proj_error
+    assert rel_err(h.delta_p(), o.delta_p()) < 1e-6
+    assert rel_err(h.delta_k(), o.delta_k()) < 1e-6
+    assert rel_err(h.delta_l(), o.delta_l()) < 1e-6
+    co = o.camera_pose(0) if kind == "tvs" else o.camera_params(0)
+    ch = h.camera_pose(0) if kind == "tvs" else h.camera_params(0)
+    assert rel_err(ch, co) < 1e-9
+    print("calibration (%s) at config-1 scale: delta_p %.2e delta_k %.2e delta_l %.2e" %
+          (kind, rel_err(h.delta_p(), o.delta_p()), rel_err(h.delta_k(), o.delta_k()), rel_err(h.delta_l(), o.delta_l())))
