@@ -173,6 +173,26 @@ inline Mat<N, N> inverse(const Mat<N, N>& m) {
   return out;
 }
 
+// 3x3: Eigen's fixed-size inverse is the cofactor form (Eigen/src/LU/InverseImpl.h,
+// compute_inverse<.., 3>: cofactors, determinant from the first column, one reciprocal) — what the
+// reference's `jtj.inverse()` of a landmark's 3x3 V runs (BundleAdjuster.cpp:438-440).  For a nearly
+// singular V (a landmark seen from three poses with a short baseline) the elimination order matters
+// at the 1e-8 level, so the restatement follows the same form.
+template <>
+inline Mat<3, 3> inverse<3>(const Mat<3, 3>& m) {
+  auto cof = [&](int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m(i1, j1) * m(i2, j2) - m(i1, j2) * m(i2, j1);
+  };
+  const double c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+  const double invdet = 1.0 / (c00 * m(0, 0) + c10 * m(1, 0) + c20 * m(2, 0));
+  Mat<3, 3> out;
+  out(0, 0) = c00 * invdet; out(0, 1) = c10 * invdet; out(0, 2) = c20 * invdet;
+  out(1, 0) = cof(0, 1) * invdet; out(1, 1) = cof(1, 1) * invdet; out(1, 2) = cof(2, 1) * invdet;
+  out(2, 0) = cof(0, 2) * invdet; out(2, 1) = cof(1, 2) * invdet; out(2, 2) = cof(2, 2) * invdet;
+  return out;
+}
+
 // Principal square root of a symmetric positive (semi)definite matrix by cyclic
 // Jacobi eigen-decomposition.  The reference calls Eigen's unsupported
 // MatrixFunctions sqrt() (Schur method) on cov_inv matrices

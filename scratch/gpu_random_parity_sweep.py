@@ -77,8 +77,19 @@ for trial in range(N):
     # a numerically singular reduced system (an unobserved direction) has no unique solution:
     # unpivoted LDLT on either side returns an arbitrary one, so only well-posed trials are compared
     tol = max(1e-9, 1e-15 * cond)
+    # ... and so does a nearly singular landmark block V (LmSize 3, few observations over a short
+    # baseline): V^-1 amplifies the rounding of the two summation orders by cond(V)
+    cond_v = 1.0
+    if lm_dim == 3:
+        _, _, jl = o.proj_jacobians(); wts = o.proj_weights()
+        V = np.zeros((L, 3, 3)); k = 0
+        for i in range(len(sc.obs_lm)):
+            V[sc.obs_lm[i]] += wts[i] * jl[i].T @ jl[i]
+        ev = np.linalg.eigvalsh(V[la.astype(bool)])
+        cond_v = float((ev[:, 2] / np.maximum(ev[:, 0], 1e-300)).max())
+        tol = max(tol, 1e-15 * cond_v)
     flag = "" if (ok and d < tol and dl < tol) else ("  (singular S: not comparable)" if cond > 1e14 else "  <-- CHECK")
     if cond <= 1e14:
         worst = max(worst, d, dl)
-    print("trial %2d P=%2d L=%3d K=%d lm=%d D=%2d dogleg=%d result=%d cond %.1e pose %.1e lm %.1e%s" % (trial, P, L, K, lm_dim, pose_dim, dog, so.result, cond, d, dl, flag), flush=True)
+    print("trial %2d P=%2d L=%3d K=%d lm=%d D=%2d dogleg=%d result=%d cond %.1e condV %.1e pose %.1e lm %.1e%s" % (trial, P, L, K, lm_dim, pose_dim, dog, so.result, cond, cond_v, d, dl, flag), flush=True)
 print("worst rel diff %.2e" % worst)
