@@ -3,21 +3,36 @@
 // main.cpp:31,60-230: Init / AddPose / Add*Constraint / AddImuResidual / Solve / GetPose).
 // Builds a small ring of cameras looking at random points, perturbs the state and runs
 // Solve() on the MI355X engine.  Exit code 0 iff the reprojection error went down.
+//
+//   visual_ba_demo                          ba::BundleAdjuster<double, 1, 6, 0>        (VisualBundleAdjuster)
+//   visual_ba_demo --calibrate-intrinsics   ba::BundleAdjuster<double, 1, 6, 4, false> starting from pinhole
+//                                           parameters that are 2-3 % off; a third of the poses held fixed
+//   visual_ba_demo --calibrate-extrinsics   ba::BundleAdjuster<double, 1, 6, 0, true>  starting from a camera
+//                                           mount T_vs that is a few centimetres / half a degree off
 #include <ba/BundleAdjuster.h>
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 
-int main() {
-  typedef ba::BundleAdjuster<double, 1, 6, 0> BA;  // VisualBundleAdjuster<double>
+template <class BA>
+int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics
   BA adjuster;
   ba::Options<double> options;  // reference defaults: dogleg, robust norm, auto regularisation
   options.error_change_threshold = 1e-5;
   const int kPoses = 24, kLandmarks = 300;
   adjuster.Init(options, kPoses, kLandmarks * 6, kLandmarks);
   const double fx = 198.969, fy = 198.1284, u0 = 329.9368, v0 = 240.1017;
-  adjuster.AddCamera(std::make_shared<ba::CameraInterface<double>>(fx, fy, u0, v0));
+  ba::SE3 mount0;  // the true mount is the identity
+  if (calibrate == 2) {
+    const double t[3] = {0.03, -0.02, 0.02}, q[4] = {0.004, -0.005, 0.003, 1.0};
+    mount0 = ba::SE3(t, q);
+  }
+  if (calibrate == 1)
+    adjuster.AddCamera(std::make_shared<ba::CameraInterface<double>>(fx * 1.03, fy * 0.97, u0 * 1.02, v0 * 0.98, mount0));
+  else
+    adjuster.AddCamera(std::make_shared<ba::CameraInterface<double>>(fx, fy, u0, v0, mount0));
 
   std::mt19937 rng(7);
   std::normal_distribution<double> n01(0.0, 1.0);
@@ -27,14 +42,23 @@ int main() {
   for (int i = 0; i < kPoses; ++i) {
     const double a = 2 * M_PI * i / kPoses;
     const double c[3] = {6 * std::cos(a), 6 * std::sin(a), 0.3 * std::sin(3 * a)};
-    // z axis -> origin, y axis ~ world -z
-    double z[3] = {-c[0], -c[1], -c[2]};
+    // z axis -> a target near the origin that wanders with the pose (cameras that all look at ONE
+    // point make a shift of the mount along the optical axis a pure change of scale), y axis ~ world -z
+    const double tgt[3] = {0.8 * std::sin(2 * a), 0.8 * std::cos(3 * a), 0.2 * std::sin(a)};
+    double z[3] = {tgt[0] - c[0], tgt[1] - c[1], tgt[2] - c[2]};
     const double zn = std::sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
     for (double& v : z) v /= zn;
     double x[3] = {z[1], -z[0], 0.0};  // z cross (0,0,1)... any unit vector orthogonal to z
     const double xn = std::sqrt(x[0] * x[0] + x[1] * x[1]);
     for (double& v : x) v /= xn;
-    const double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    {  // roll about the optical axis
+      const double r = 0.5 * std::sin(5 * a), cr = std::cos(r), sr = std::sin(r);
+      for (int k = 0; k < 3; ++k) {
+        const double xk = cr * x[k] + sr * y[k], yk = -sr * x[k] + cr * y[k];
+        x[k] = xk; y[k] = yk;
+      }
+    }
     const double R[9] = {x[0], y[0], z[0], x[1], y[1], z[1], x[2], y[2], z[2]};
     // rotation matrix -> quaternion (trace branch is fine for this geometry after a sign fix)
     double q[4];
@@ -63,8 +87,10 @@ int main() {
   };
   for (int i = 0; i < kPoses; ++i) {
     ba::SE3 init = gt[i];
-    if (i >= 2) for (int k = 0; k < 3; ++k) init.t[k] += 0.03 * n01(rng);
-    adjuster.AddPose(init, /*is_active=*/i >= 2);  // two fixed poses pin the gauge (and the scale)
+    for (int k = 0; k < 3; ++k) init.t[k] += 0.03 * n01(rng);
+    // two fixed poses pin the gauge (and the scale); self-calibration needs more of them
+    const bool fixed = calibrate ? (i % 3 == 0) : (i < 2);
+    adjuster.AddPose(fixed ? gt[i] : init, /*is_active=*/!fixed);
   }
   int n_res = 0;
   for (int l = 0; l < kLandmarks; ++l) {
@@ -74,7 +100,19 @@ int main() {
     for (int i = 0; i < kPoses && ref < 0; ++i)
       if (project(gt[(i + l) % kPoses], X, uv)) ref = (i + l) % kPoses;
     if (ref < 0) continue;
-    const double Xp[4] = {X[0] * (1 + 0.02 * n01(rng)), X[1] * (1 + 0.02 * n01(rng)), X[2], 1.0};
+    double Xp[4] = {X[0] * (1 + 0.02 * n01(rng)), X[1] * (1 + 0.02 * n01(rng)), X[2], 1.0};
+    if (calibrate == 2) {
+      // a front end hands over world points built with ITS mount guess: keep the point's coordinates in
+      // the reference camera and map them back through T_wp T_vs(guess)
+      auto apply = [](const ba::SE3& T, const double* p, double* o) {
+        const ba::Matrix3t R = T.rotationMatrix();
+        for (int r = 0; r < 3; ++r) o[r] = R(r, 0) * p[0] + R(r, 1) * p[1] + R(r, 2) * p[2] + T.t[r];
+      };
+      double xs[3], xw[3];
+      apply(gt[ref].inverse(), Xp, xs);
+      apply(gt[ref] * mount0, xs, xw);
+      for (int k = 0; k < 3; ++k) Xp[k] = xw[k];
+    }
     const uint32_t lm = adjuster.AddLandmark(ba::Vector4t({Xp[0], Xp[1], Xp[2], Xp[3]}), ref, 0, true);
     for (int i = 0; i < kPoses; ++i) {
       if (!project(gt[i], X, uv)) continue;
@@ -97,5 +135,25 @@ int main() {
   }
   std::printf("proj error after 1 iteration %.4f, after 9 %.4f, result %d, worst position error %.4f m\n", e0, e1,
               (int)adjuster.GetSolutionSummary().result, worst);
-  return (e1 <= e0 && worst < 0.15) ? 0 : 1;
+  bool ok = e1 <= e0 && worst < 0.15;
+  if (calibrate == 1) {
+    const ba::Vector4t p = adjuster.rig()->cameras_[0]->GetParams();
+    std::printf("camera parameters %.3f %.3f %.3f %.3f (true %.3f %.3f %.3f %.3f)\n", p[0], p[1], p[2], p[3], fx, fy, u0, v0);
+    ok = ok && std::fabs(p[0] - fx) < 0.01 * fx && std::fabs(p[1] - fy) < 0.01 * fy && std::fabs(p[2] - u0) < 0.01 * u0 &&
+         std::fabs(p[3] - v0) < 0.01 * v0;
+  }
+  if (calibrate == 2) {
+    const ba::SE3 m = adjuster.rig()->cameras_[0]->Pose();
+    std::printf("camera mount t = %.4f %.4f %.4f  q = %.5f %.5f %.5f %.5f (true: identity)\n", m.t[0], m.t[1], m.t[2], m.q[0],
+                m.q[1], m.q[2], m.q[3]);
+    const double before = std::sqrt(0.03 * 0.03 + 0.02 * 0.02 + 0.02 * 0.02);
+    ok = ok && std::sqrt(m.t[0] * m.t[0] + m.t[1] * m.t[1] + m.t[2] * m.t[2]) < before;
+  }
+  return ok ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && std::strcmp(argv[1], "--calibrate-intrinsics") == 0) return run<ba::BundleAdjuster<double, 1, 6, 4, false>>(1);
+  if (argc > 1 && std::strcmp(argv[1], "--calibrate-extrinsics") == 0) return run<ba::BundleAdjuster<double, 1, 6, 0, true>>(2);
+  return run<ba::BundleAdjuster<double, 1, 6, 0>>(0);  // VisualBundleAdjuster<double>
 }

@@ -366,12 +366,15 @@ def test_poses_without_residuals_and_empty_landmarks(oracle_lib):
 
 
 # ---- the C++ host class used directly by a C++ application ---------------------------------
-def test_cpp_application_runs_on_the_engine():
+@pytest.mark.parametrize("mode", [None, "--calibrate-intrinsics", "--calibrate-extrinsics"])
+def test_cpp_application_runs_on_the_engine(mode):
+    """applications/visual_ba_demo: plain C++ against include/ba/BundleAdjuster.h — the visual
+    adjuster and the two self-calibration instantiations <1, 6, 4, false> / <1, 6, 0, true>."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "ba_amd", "lib", "visual_ba_demo")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe] + ([mode] if mode else []), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "proj error" in r.stdout
 
