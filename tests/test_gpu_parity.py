@@ -1309,13 +1309,29 @@ def test_config4_miniature_matches_oracle(oracle_lib, lm_dim):
     assert rel_err(h.landmarks(), o.landmarks()) < 1e-6
 
 
-def _bench_scene_engine(P, L, K, keep_s=False):
-    sc = scene.make_scene(P, L, K, lm_dim=1, seed=2)
+_BENCH_SCENES = {}
+
+
+def _bench_scene(P, L, K):
+    """The bench scene of that size, generated once per test session (30 s at configs[3]); read-only."""
+    if (P, L, K) not in _BENCH_SCENES:
+        _BENCH_SCENES.clear()  # one at a time: the 10M-residual scene holds about a gigabyte
+        _BENCH_SCENES[(P, L, K)] = scene.make_scene(P, L, K, lm_dim=1, seed=2)
+    return _BENCH_SCENES[(P, L, K)]
+
+
+def _bench_scene_engine(P, L, K, keep_s=False, calibrate=None):
+    sc = _bench_scene(P, L, K)
     keep = np.ones(len(sc.obs_pose), dtype=bool)
     keep[::K + 1] = False
     pa = np.ones(sc.num_poses, dtype=np.uint8)
     pa[sc.anchor_poses] = 0
     eng = hipapi.Engine(1, 6)
+    if calibrate:
+        eng.set_calibration(4 if calibrate == "intrinsics" else 0, calibrate == "tvs")
+        pa[::10] = 0  # the calibration unknowns need more than the two anchors to be observable
+        if calibrate == "intrinsics":
+            eng.set_landmark_ref_pixels(sc.obs_z[::K + 1])
     if keep_s:
         o = hipapi.Options()
         o.projection_outlier_threshold = 1.0
@@ -1366,6 +1382,46 @@ def test_config3_full_size_properties():
     # the first step moved the poses towards the ground truth
     t, _, _ = eng.get_poses(sc.num_poses)
     assert np.linalg.norm(t[:, :3] - sc.gt_poses[:, :3]) < np.linalg.norm(sc.poses[:, :3] - sc.gt_poses[:, :3])
+    eng.end_solve()
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+def test_config3_full_size_with_calibration_unknowns(kind):
+    """The configs[3] scene (10k poses / 1M landmarks / 10M residuals) with the self-calibration
+    unknowns switched on: the bordered system of n + 6 (n + 4) unknowns — 9 000 border blocks from
+    k_pose_border, S_kk / rhs_k from one pass over 21M calibration rows, a dense last tile row through
+    the factorisation.  Size-independent gates as for the plain scene: S delta = rhs on the device,
+    a bitwise repeatable step, two accepted steps that reduce the error, a camera that moves."""
+    sc, eng = _bench_scene_engine(10000, 1000000, 10, keep_s=True, calibrate=kind)
+    K = 6 if kind == "tvs" else 4
+    n = eng.num_pose_params()
+    assert n == 9000 * 6 and eng.num_calib_params() == K
+    e0 = eng.linearize()
+    assert eng.solve_gn() == 0
+    res, rhs = eng.check_solve()
+    assert rhs > 0 and res / rhs < 1e-9, (res, rhs)
+    d1, l1 = eng.get_delta_gn()
+    assert d1.shape[0] == n + K and np.all(np.isfinite(d1)) and np.linalg.norm(d1[n:]) > 0
+    eng.linearize()
+    assert eng.solve_gn() == 0
+    d2, l2 = eng.get_delta_gn()
+    assert np.array_equal(d1, d2) and np.array_equal(l1, l2)
+    cam_before = (eng.get_cameras(1) if kind == "tvs" else eng.get_camera_params(1)).copy()
+    errs = [e0.proj_error]
+    for _ in range(2):
+        eng.compose_step(0.0, 1.0)
+        pre = eng.eval_residuals()
+        eng.apply_step()
+        post = eng.eval_residuals()
+        assert post.total() < pre.total()
+        errs.append(post.total())
+        eng.linearize()
+        assert eng.solve_gn() == 0
+    assert errs[2] < errs[1] < errs[0]
+    cam_after = eng.get_cameras(1) if kind == "tvs" else eng.get_camera_params(1)
+    assert np.linalg.norm(cam_after - cam_before) > 0
     eng.end_solve()
     eng.close()
 
