@@ -445,7 +445,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   (void)hipSetDevice(e->device);
   (void)hipStreamSynchronize(e->stream);
 #define REL(b) e->b.release()
-  REL(cam); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
+  REL(cam); REL(cam_eval); REL(lm_zref); REL(crow); REL(border_blocks); REL(calib_partials); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0); REL(obs_cond);
   REL(wave_rng); REL(tile_order); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
   REL(imu_frozen); REL(imu_cov_done); REL(pose_cam);
