@@ -453,6 +453,14 @@ BA_HD void add_ident(DM<10, 10>& m, const DM<4, 4>& dy_dy) {  // Types.h:488-490
   for (int i = 0; i < 3; ++i) { m(i, i) += 1.0; m(7 + i, 7 + i) += 1.0; }
   add_block(m, 3, 3, dy_dy);
 }
+// C <- F C F^T + G R G^T with the Jacobians of one integration step (Types.h:617-640)
+BA_HD void imu_cov_update(const DM<10, 6>& dy_db, const DM<10, 10>& dy_dy0, DM<10, 10>* cov, const double* r6) {
+  DM<10, 6> GR = dy_db;
+  for (int r = 0; r < 10; ++r)
+    for (int c = 0; c < 6; ++c) GR(r, c) *= r6[c];
+  const DM<10, 10> prop = mmT(mm(dy_dy0, *cov), dy_dy0);
+  *cov = madd(prop, mmT(GR, dy_db));
+}
 // Types.h:419-643, Jacobian branch, Euler covariance (C <- F C F^T + G R G^T)
 BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* z1, const double* bg,
                              const double* ba, const double* g, bool jac, DM<10, 6>* dy_db,
@@ -515,13 +523,7 @@ BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* 
   *dy_db = mm(dy_dk, dkt_db);
   *dy_dy0 = mm(dy_dk, dkt_dy);
   add_ident(*dy_dy0, dyy);
-  if (cov) {
-    DM<10, 6> GR = *dy_db;
-    for (int r = 0; r < 10; ++r)
-      for (int c = 0; c < 6; ++c) GR(r, c) *= r6[c];
-    const DM<10, 10> prop = mmT(mm(*dy_dy0, *cov), *dy_dy0);
-    *cov = madd(prop, mmT(GR, *dy_db));
-  }
+  if (cov) imu_cov_update(*dy_db, *dy_dy0, cov, r6);
   return res;
 }
 
@@ -535,9 +537,14 @@ struct ImuOut {
 // 160 doubles = the integration covariance (10x10) and the bias Jacobian of the integration
 // (10x6).  frozen_in: integrate without Jacobians and take both from there; frozen_out: store
 // what this call computed.
+// steps (optional): the Jacobians of every integration step, computed beforehand (imu_step_jacobians:
+// 160 doubles per sample, [dy_db 10x6 | dy_dy0 10x10], sample k holds the step k-1 -> k) — the state is
+// then integrated without Jacobians and only the two accumulations run here, in the same order and
+// with the same arithmetic as the fused form.
 BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, int nmeas,
                         const double* g, const double* r6, const double* rb6, int RS, bool jac,
-                        ImuOut* o, const double* frozen_in = nullptr, double* frozen_out = nullptr) {
+                        ImuOut* o, const double* frozen_in = nullptr, double* frozen_out = nullptr,
+                        const double* steps = nullptr) {
   ImuState s;
   for (int i = 0; i < 3; ++i) { s.t[i] = p1[i]; s.v[i] = p1[7 + i]; }
   for (int i = 0; i < 4; ++i) s.q[i] = p1[3 + i];
@@ -549,7 +556,17 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
   cov.zero();
   const bool ijac = jac && !frozen_in;
   for (int i = 1; i < nmeas; ++i) {
-    s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, ijac, &dy_db, &dy_dy, &cov, r6);
+    if (ijac && steps) {
+      const double* z0 = meas + 7 * (i - 1);
+      const double* z1 = meas + 7 * i;
+      s = integrate_imu(s, z0, z1, bg, ba, g, false, nullptr, nullptr, nullptr, r6);
+      const double* st = steps + (size_t)160 * i;
+      for (int k = 0; k < 60; ++k) dy_db.m[k] = st[k];
+      for (int k = 0; k < 100; ++k) dy_dy.m[k] = st[60 + k];
+      if (z1[6] - z0[6] != 0) imu_cov_update(dy_db, dy_dy, &cov, r6);  // (a zero step leaves the covariance alone)
+    } else {
+      s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, ijac, &dy_db, &dy_dy, &cov, r6);
+    }
     if (ijac) dpose_db = madd(dy_db, mm(dy_dy, dpose_db));  // Types.h:712-714
   }
   if (jac && frozen_in) {
@@ -617,6 +634,25 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
     for (int i = 0; i < 6; ++i) o->dz2(9 + i, 9 + i) = -1.0;
   }
 }
+// The Jacobians of ONE integration step of a residual, sample k-1 -> k (k >= 1): the states up to
+// sample k-1 are re-integrated without Jacobians (cheap), then the step with them.  One lane per
+// (residual, sample): the steps of a residual are independent given the states, so the expensive part
+// of the pre-integration — 80 % of its multiply-adds — runs in parallel over the samples.
+BA_HD void imu_step_jacobians(const double* p1, const double* meas, int k, const double* g, double* out160) {
+  ImuState s;
+  for (int i = 0; i < 3; ++i) { s.t[i] = p1[i]; s.v[i] = p1[7 + i]; }
+  for (int i = 0; i < 4; ++i) s.q[i] = p1[3 + i];
+  const double* bg = p1 + 10;
+  const double* ba = p1 + 13;
+  for (int i = 1; i < k; ++i)
+    s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, false, nullptr, nullptr, nullptr, nullptr);
+  DM<10, 6> dy_db;
+  DM<10, 10> dy_dy;
+  (void)integrate_imu(s, meas + 7 * (k - 1), meas + 7 * k, bg, ba, g, true, &dy_db, &dy_dy, nullptr, nullptr);
+  for (int i = 0; i < 60; ++i) out160[i] = dy_db.m[i];
+  for (int i = 0; i < 100; ++i) out160[60 + i] = dy_dy.m[i];
+}
+
 // blocks J^T S^-1 J, J^T S^-1 r with S^-1 = cov_inv * weight (BundleAdjuster.cpp:1526)
 BA_HD void imu_blocks(const ImuOut& io, double weight, PPBlocks* o) {
   DM<15, 15> info = io.cov_inv;

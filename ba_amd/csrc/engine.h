@@ -140,6 +140,7 @@ struct Engine {
   // bias Jacobian of its first linearisation, and a "done" flag
   bool imu_cov_once = false;
   DBuf<double> imu_frozen;
+  DBuf<double> imu_steps;                // [samples][160] step Jacobians of the pre-integration (k_imu_steps)
   DBuf<uint8_t> imu_cov_done;
   uint32_t imu_cov_count = 0;
   DBuf<double> pp_h, pp_g, pp_dz, pp_info, pp_err;

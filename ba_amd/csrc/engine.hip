@@ -448,7 +448,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(cam); REL(cam_eval); REL(lm_zref); REL(crow); REL(border_blocks); REL(calib_partials); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0); REL(obs_cond);
   REL(wave_rng); REL(tile_order); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
-  REL(imu_frozen); REL(imu_cov_done); REL(pose_cam);
+  REL(imu_frozen); REL(imu_steps); REL(imu_cov_done); REL(pose_cam);
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);

@@ -1,6 +1,7 @@
 // Host build of the device math (dmath.h) so that `-m "not gpu"` tests can compare the
 // kernels' closed-form Jacobians with the oracle without a GPU.  Test hook only: the
 // product never calls this library.
+#include <vector>
 #include "dmath.h"
 using namespace bad;
 
@@ -105,6 +106,19 @@ extern "C" void ba_hostcheck_imu(const double* p1_16, const double* p2_16, const
                                  int RS, double* r15, double* dz1, double* dz2, double* cov_inv) {
   ImuOut o;
   imu_residual(p1_16, p2_16, meas, nmeas, g3, r6, rb6, RS, true, &o);
+  for (int i = 0; i < 15; ++i) r15[i] = o.r[i];
+  for (int i = 0; i < 225; ++i) { dz1[i] = o.dz1.m[i]; dz2[i] = o.dz2.m[i]; cov_inv[i] = o.cov_inv.m[i]; }
+}
+
+// the two-launch form of the device (k_imu_steps + k_imu): step Jacobians per sample first, then the
+// sequential part — must reproduce the fused form bit for bit
+extern "C" void ba_hostcheck_imu_split(const double* p1_16, const double* p2_16, const double* meas,
+                                       int nmeas, const double* g3, const double* r6, const double* rb6,
+                                       int RS, double* r15, double* dz1, double* dz2, double* cov_inv) {
+  std::vector<double> steps((size_t)160 * (nmeas > 0 ? nmeas : 1), 0.0);
+  for (int k = 1; k < nmeas; ++k) imu_step_jacobians(p1_16, meas, k, g3, &steps[(size_t)160 * k]);
+  ImuOut o;
+  imu_residual(p1_16, p2_16, meas, nmeas, g3, r6, rb6, RS, true, &o, nullptr, nullptr, steps.data());
   for (int i = 0; i < 15; ++i) r15[i] = o.r[i];
   for (int i = 0; i < 225; ++i) { dz1[i] = o.dz1.m[i]; dz2[i] = o.dz2.m[i]; cov_inv[i] = o.cov_inv.m[i]; }
 }

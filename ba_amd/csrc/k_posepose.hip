@@ -122,7 +122,29 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
       double* __restrict__ pp_h, double* __restrict__ pp_g, double* __restrict__ pp_dz,
       double* __restrict__ pp_info, uint32_t slot0, double* __restrict__ out_err,
       double* __restrict__ res_out /* mode 2, optional: the residual vectors, 15 per residual */,
-      int cov_once, double* __restrict__ frozen, uint8_t* __restrict__ cov_done) {
+      int cov_once, double* __restrict__ frozen, uint8_t* __restrict__ cov_done,
+      const double* __restrict__ steps /* k_imu_steps, or null: integrate with Jacobians here */) {
+  if (mode == 3) {
+    // Step Jacobians of the pre-integration, one lane per IMU sample (dpose.h: imu_step_jacobians);
+    // n = number of samples, RS = number of residuals; `mptr` is the CSR of the samples over the
+    // residuals (the residual of sample j by binary search).  A mode of this kernel rather than a kernel
+    // of its own: two kernels with different private-memory sizes alternating on one queue make the
+    // runtime re-size the queue's scratch at every launch.
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (uint32_t)n) return;
+    uint32_t lo = 0, hi = (uint32_t)RS;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (mptr[mid] <= j) lo = mid; else hi = mid;
+    }
+    const uint32_t ri = lo, k = j - mptr[ri];
+    if (k == 0 || j >= mptr[ri + 1]) return;          // sample 0 starts the integration: no step ends there
+    if (cov_once && cov_done[ri]) return;             // frozen covariance / bias Jacobian: not needed
+    const double gg[3] = {grav[0], grav[1], grav[2]};
+    imu_step_jacobians(state + (size_t)p1[ri] * kPoseState, meas + (size_t)mptr[ri] * 7, (int)k, gg,
+                       const_cast<double*>(steps) + (size_t)j * 160);
+    return;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double* s1 = state + (size_t)p1[i] * kPoseState;
@@ -149,11 +171,13 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     // calculate_inertial_covariance_once: the first linearisation of a residual freezes its
     // integration covariance and bias Jacobian
     double* fz = frozen + (size_t)i * 160;
+    const double* st = steps ? steps + (size_t)mptr[i] * 160 : nullptr;
     if (cov_done[i]) imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, fz, nullptr);
-    else imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, nullptr, fz);
+    else imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, nullptr, fz, st);
     cov_done[i] = 1;
   } else {
-    imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io);
+    imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, nullptr, nullptr,
+                 steps ? steps + (size_t)mptr[i] * 160 : nullptr);
   }
   double w = 1.0;
   if (use_robust) {
@@ -321,13 +345,27 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
     e->imu_cov_count = ni;
   }
   if (ni) {
+    // two launches: the step Jacobians of every sample in parallel, then one lane per residual for the
+    // sequential part (states, accumulations, the 15x15 algebra).  BA_HIP_IMU_FUSED=1: the single-launch form
+    static const bool fused = getenv("BA_HIP_IMU_FUSED") != nullptr;
+    const uint32_t n_meas = (uint32_t)(pb.imu_meas.size() / 7);
+    const double* steps = nullptr;
     e->prof_begin(e->ev_imu, s2);
+    if (!fused && n_meas) {
+      BAE_HIP(e->imu_steps.alloc((size_t)n_meas * 160));
+      steps = e->imu_steps.p;
+      hipLaunchKernelGGL(k_imu, dim3((n_meas + 63) / 64), dim3(64), 0, s2, (int)n_meas, 3, (int)ni, 0, 0.0, e->imu_p1.p,
+                         e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
+                         e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
+                         e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
+                         e->imu_frozen.p, e->imu_cov_done.p, steps);
+    }
     hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, s2, (int)ni, 1, e->pose_dim,
                        e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
                        e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                        e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
                        e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
-                       e->imu_frozen.p, e->imu_cov_done.p);
+                       e->imu_frozen.p, e->imu_cov_done.p, steps);
     e->prof_end(e->ev_imu, s2);
     BAE_HIP(hipGetLastError());
   }
@@ -422,7 +460,7 @@ int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
                        0.0, e->imu_p1.p, e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p,
                        e->imu_consts.p + 3, e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p,
                        e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, 0,
-                       (double*)nullptr, (uint8_t*)nullptr);
+                       (double*)nullptr, (uint8_t*)nullptr, (const double*)nullptr);
     BAE_HIP(hipGetLastError());
   }
   if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
@@ -455,7 +493,7 @@ int launch_imu_residual_vectors(Engine* e, double* d_r15) {
                      e->imu_p1.p, e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                      e->pose_active.p, (const double*)e->pose_state[e->cur].p, e->imu_cov_inv.p, e->pp_h.p,
                      e->pp_g.p, e->pp_dz.p, e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, d_r15, 0, (double*)nullptr,
-                     (uint8_t*)nullptr);
+                     (uint8_t*)nullptr, (const double*)nullptr);
   BAE_HIP(hipGetLastError());
   return 0;
 }

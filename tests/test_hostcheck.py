@@ -289,6 +289,12 @@ def test_imu_residual_blocks_of_the_kernels_match_the_oracle(oracle_lib, hc, pos
         r15 = np.zeros(15); dz1 = np.zeros(225); dz2 = np.zeros(225); ci = np.zeros(225)
         hc.ba_hostcheck_imu(_dp(p1), _dp(p2), _dp(meas), int(meas.shape[0]), _dp(g), _dp(r6), _dp(rb6),
                             int(pose_dim), _dp(r15), _dp(dz1), _dp(dz2), _dp(ci))
+        # the two-launch form of the device (step Jacobians per sample, then the sequential part)
+        r15s = np.zeros(15); dz1s = np.zeros(225); dz2s = np.zeros(225); cis = np.zeros(225)
+        hc.ba_hostcheck_imu_split(_dp(p1), _dp(p2), _dp(meas), int(meas.shape[0]), _dp(g), _dp(r6), _dp(rb6),
+                                  int(pose_dim), _dp(r15s), _dp(dz1s), _dp(dz2s), _dp(cis))
+        assert np.array_equal(r15s, r15) and np.array_equal(dz1s, dz1) and np.array_equal(dz2s, dz2)
+        assert np.array_equal(cis, ci)
         R = pose_dim
         sl = np.s_[:R, :R]
         assert rel_err(r15[:R], np.asarray(r_o)[:R]) < 1e-10
