@@ -57,6 +57,46 @@ BA_HD DM<R, C> mTm(const DM<K, R>& a, const DM<K, C>& b) {  // a^T * b
     }
   return o;
 }
+// Wave-cooperative products (device only).  When the 64 lanes of ONE wavefront run the same scalar
+// code on the same residual — every lane holds identical copies of the operands — a product is dealt
+// element-wise to the lanes (each element summed over k in the order of mm / mmT / mTm: bitwise the
+// scalar result), exchanged through `lds` (>= R*C doubles, workgroup = that one wavefront) and read
+// back by every lane.  ctx == nullptr (always on the host): the scalar product.
+struct WaveCtx { double* lds; int lane; };
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BAD_WAVE_PRODUCT(EXPR)                                        \
+  if (w) {                                                            \
+    for (int e = w->lane; e < R * C; e += 64) {                       \
+      const int r = e / C, c = e - r * C;                             \
+      double s = 0.0;                                                 \
+      for (int k = 0; k < K; ++k) s += (EXPR);                        \
+      w->lds[e] = s;                                                  \
+    }                                                                 \
+    __syncthreads();                                                  \
+    DM<R, C> o;                                                       \
+    for (int e = 0; e < R * C; ++e) o.m[e] = w->lds[e];               \
+    __syncthreads();                                                  \
+    return o;                                                         \
+  }
+#else
+#define BAD_WAVE_PRODUCT(EXPR) (void)w;
+#endif
+template <int R, int K, int C>
+BA_HD DM<R, C> mm(const DM<R, K>& a, const DM<K, C>& b, const WaveCtx* w) {
+  BAD_WAVE_PRODUCT(a(r, k) * b(k, c))
+  return mm(a, b);
+}
+template <int R, int K, int C>
+BA_HD DM<R, C> mmT(const DM<R, K>& a, const DM<C, K>& b, const WaveCtx* w) {
+  BAD_WAVE_PRODUCT(a(r, k) * b(c, k))
+  return mmT(a, b);
+}
+template <int K, int R, int C>
+BA_HD DM<R, C> mTm(const DM<K, R>& a, const DM<K, C>& b, const WaveCtx* w) {
+  BAD_WAVE_PRODUCT(a(k, r) * b(k, c))
+  return mTm(a, b);
+}
+#undef BAD_WAVE_PRODUCT
 template <int R, int C>
 BA_HD DM<R, C> madd(const DM<R, C>& a, const DM<R, C>& b, double sb = 1.0) {
   DM<R, C> o;
@@ -454,17 +494,18 @@ BA_HD void add_ident(DM<10, 10>& m, const DM<4, 4>& dy_dy) {  // Types.h:488-490
   add_block(m, 3, 3, dy_dy);
 }
 // C <- F C F^T + G R G^T with the Jacobians of one integration step (Types.h:617-640)
-BA_HD void imu_cov_update(const DM<10, 6>& dy_db, const DM<10, 10>& dy_dy0, DM<10, 10>* cov, const double* r6) {
+BA_HD void imu_cov_update(const DM<10, 6>& dy_db, const DM<10, 10>& dy_dy0, DM<10, 10>* cov, const double* r6,
+                          const WaveCtx* w = nullptr) {
   DM<10, 6> GR = dy_db;
   for (int r = 0; r < 10; ++r)
     for (int c = 0; c < 6; ++c) GR(r, c) *= r6[c];
-  const DM<10, 10> prop = mmT(mm(dy_dy0, *cov), dy_dy0);
-  *cov = madd(prop, mmT(GR, dy_db));
+  const DM<10, 10> prop = mmT(mm(dy_dy0, *cov, w), dy_dy0, w);
+  *cov = madd(prop, mmT(GR, dy_db, w));
 }
 // Types.h:419-643, Jacobian branch, Euler covariance (C <- F C F^T + G R G^T)
 BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* z1, const double* bg,
                              const double* ba, const double* g, bool jac, DM<10, 6>* dy_db,
-                             DM<10, 10>* dy_dy0, DM<10, 10>* cov, const double* r6) {
+                             DM<10, 10>* dy_dy0, DM<10, 10>* cov, const double* r6, const WaveCtx* w = nullptr) {
   const double dt = z1[6] - z0[6];
   if (dt == 0) {
     if (jac) { dy_db->zero(); dy_dy0->identity(); }
@@ -490,29 +531,29 @@ BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* 
   const DM<9, 6> dk1_db = dk_db;
   const DM<9, 10> dk1_dy = dk_dy;
   const ImuState y1 = integrate_pose(s, k1, dt * 0.5, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dk1_db);
-  *dy_dy0 = mm(dy_dk, dk1_dy);
+  *dy_db = mm(dy_dk, dk1_db, w);
+  *dy_dy0 = mm(dy_dk, dk1_dy, w);
   add_ident(*dy_dy0, dyy);
 
   pose_derivative(y1, g, z0, z1, bg, ba, dt / 2, k2, &dk_db, &dk_dy);
-  const DM<9, 6> dk2_db = madd(dk_db, mm(dk_dy, *dy_db));
-  const DM<9, 10> dk2_dy = mm(dk_dy, *dy_dy0);
+  const DM<9, 6> dk2_db = madd(dk_db, mm(dk_dy, *dy_db, w));
+  const DM<9, 10> dk2_dy = mm(dk_dy, *dy_dy0, w);
   const ImuState y2 = integrate_pose(s, k2, dt * 0.5, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dk2_db);
-  *dy_dy0 = mm(dy_dk, dk2_dy);
+  *dy_db = mm(dy_dk, dk2_db, w);
+  *dy_dy0 = mm(dy_dk, dk2_dy, w);
   add_ident(*dy_dy0, dyy);
 
   pose_derivative(y2, g, z0, z1, bg, ba, dt / 2, k3, &dk_db, &dk_dy);
-  const DM<9, 6> dk3_db = madd(dk_db, mm(dk_dy, *dy_db));
-  const DM<9, 10> dk3_dy = mm(dk_dy, *dy_dy0);
+  const DM<9, 6> dk3_db = madd(dk_db, mm(dk_dy, *dy_db, w));
+  const DM<9, 10> dk3_dy = mm(dk_dy, *dy_dy0, w);
   const ImuState y3 = integrate_pose(s, k3, dt, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dk3_db);
-  *dy_dy0 = mm(dy_dk, dk3_dy);
+  *dy_db = mm(dy_dk, dk3_db, w);
+  *dy_dy0 = mm(dy_dk, dk3_dy, w);
   add_ident(*dy_dy0, dyy);
 
   pose_derivative(y3, g, z0, z1, bg, ba, dt, k4, &dk_db, &dk_dy);
-  const DM<9, 6> dk4_db = madd(dk_db, mm(dk_dy, *dy_db));
-  const DM<9, 10> dk4_dy = mm(dk_dy, *dy_dy0);
+  const DM<9, 6> dk4_db = madd(dk_db, mm(dk_dy, *dy_db, w));
+  const DM<9, 10> dk4_dy = mm(dk_dy, *dy_dy0, w);
 
   for (int i = 0; i < 9; ++i) k[i] = k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i];
   DM<9, 6> dkt_db;
@@ -520,10 +561,10 @@ BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* 
   for (int i = 0; i < 54; ++i) dkt_db.m[i] = dk1_db.m[i] + 2 * dk2_db.m[i] + 2 * dk3_db.m[i] + dk4_db.m[i];
   for (int i = 0; i < 90; ++i) dkt_dy.m[i] = dk1_dy.m[i] + 2 * dk2_dy.m[i] + 2 * dk3_dy.m[i] + dk4_dy.m[i];
   const ImuState res = integrate_pose(s, k, dt / 6.0, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dkt_db);
-  *dy_dy0 = mm(dy_dk, dkt_dy);
+  *dy_db = mm(dy_dk, dkt_db, w);
+  *dy_dy0 = mm(dy_dk, dkt_dy, w);
   add_ident(*dy_dy0, dyy);
-  if (cov) imu_cov_update(*dy_db, *dy_dy0, cov, r6);
+  if (cov) imu_cov_update(*dy_db, *dy_dy0, cov, r6, w);
   return res;
 }
 
@@ -544,7 +585,7 @@ struct ImuOut {
 BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, int nmeas,
                         const double* g, const double* r6, const double* rb6, int RS, bool jac,
                         ImuOut* o, const double* frozen_in = nullptr, double* frozen_out = nullptr,
-                        const double* steps = nullptr) {
+                        const double* steps = nullptr, const WaveCtx* w = nullptr) {
   ImuState s;
   for (int i = 0; i < 3; ++i) { s.t[i] = p1[i]; s.v[i] = p1[7 + i]; }
   for (int i = 0; i < 4; ++i) s.q[i] = p1[3 + i];
@@ -563,11 +604,11 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
       const double* st = steps + (size_t)160 * i;
       for (int k = 0; k < 60; ++k) dy_db.m[k] = st[k];
       for (int k = 0; k < 100; ++k) dy_dy.m[k] = st[60 + k];
-      if (z1[6] - z0[6] != 0) imu_cov_update(dy_db, dy_dy, &cov, r6);  // (a zero step leaves the covariance alone)
+      if (z1[6] - z0[6] != 0) imu_cov_update(dy_db, dy_dy, &cov, r6, w);  // (a zero step leaves the covariance alone)
     } else {
       s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, ijac, &dy_db, &dy_dy, &cov, r6);
     }
-    if (ijac) dpose_db = madd(dy_db, mm(dy_dy, dpose_db));  // Types.h:712-714
+    if (ijac) dpose_db = madd(dy_db, mm(dy_dy, dpose_db, w));  // Types.h:712-714
   }
   if (jac && frozen_in) {
     for (int k = 0; k < 100; ++k) cov.m[k] = frozen_in[k];
@@ -615,7 +656,7 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
   A.zero();
   set_block(A, 0, 0, dlog1);
   A(6, 7) = A(7, 8) = A(8, 9) = 1.0;
-  const DM<9, 9> c9 = mmT(mm(A, cov), A);
+  const DM<9, 9> c9 = mmT(mm(A, cov, w), A, w);
   o->cov_inv.zero();
   for (int i = 0; i < 15; ++i) o->cov_inv(i, i) = 1.0;
   if (RS >= 15)
@@ -638,7 +679,8 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
 // sample k-1 are re-integrated without Jacobians (cheap), then the step with them.  One lane per
 // (residual, sample): the steps of a residual are independent given the states, so the expensive part
 // of the pre-integration — 80 % of its multiply-adds — runs in parallel over the samples.
-BA_HD void imu_step_jacobians(const double* p1, const double* meas, int k, const double* g, double* out160) {
+BA_HD void imu_step_jacobians(const double* p1, const double* meas, int k, const double* g, double* out160,
+                              const WaveCtx* w = nullptr) {
   ImuState s;
   for (int i = 0; i < 3; ++i) { s.t[i] = p1[i]; s.v[i] = p1[7 + i]; }
   for (int i = 0; i < 4; ++i) s.q[i] = p1[3 + i];
@@ -648,19 +690,20 @@ BA_HD void imu_step_jacobians(const double* p1, const double* meas, int k, const
     s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, false, nullptr, nullptr, nullptr, nullptr);
   DM<10, 6> dy_db;
   DM<10, 10> dy_dy;
-  (void)integrate_imu(s, meas + 7 * (k - 1), meas + 7 * k, bg, ba, g, true, &dy_db, &dy_dy, nullptr, nullptr);
-  for (int i = 0; i < 60; ++i) out160[i] = dy_db.m[i];
-  for (int i = 0; i < 100; ++i) out160[60 + i] = dy_dy.m[i];
+  (void)integrate_imu(s, meas + 7 * (k - 1), meas + 7 * k, bg, ba, g, true, &dy_db, &dy_dy, nullptr, nullptr, w);
+  const int l0 = w ? w->lane : 0, ls = w ? 64 : 1;
+  for (int i = l0; i < 60; i += ls) out160[i] = dy_db.m[i];
+  for (int i = l0; i < 100; i += ls) out160[60 + i] = dy_dy.m[i];
 }
 
 // blocks J^T S^-1 J, J^T S^-1 r with S^-1 = cov_inv * weight (BundleAdjuster.cpp:1526)
-BA_HD void imu_blocks(const ImuOut& io, double weight, PPBlocks* o) {
+BA_HD void imu_blocks(const ImuOut& io, double weight, PPBlocks* o, const WaveCtx* w = nullptr) {
   DM<15, 15> info = io.cov_inv;
   for (int i = 0; i < 225; ++i) info.m[i] *= weight;
-  const DM<15, 15> j1t = mTm(io.dz1, info), j2t = mTm(io.dz2, info);
-  o->h11 = mm(j1t, io.dz1);
-  o->h12 = mm(j1t, io.dz2);
-  o->h22 = mm(j2t, io.dz2);
+  const DM<15, 15> j1t = mTm(io.dz1, info, w), j2t = mTm(io.dz2, info, w);
+  o->h11 = mm(j1t, io.dz1, w);
+  o->h12 = mm(j1t, io.dz2, w);
+  o->h22 = mm(j2t, io.dz2, w);
   double e = 0.0;
   for (int i = 0; i < 15; ++i) {
     double s1 = 0.0, s2 = 0.0, q = 0.0;

@@ -1246,6 +1246,7 @@ int ba_hip_debug_set(ba_hip_engine* h, int key, int value) {
     case 2: e->dbg_tile_order = value; e->tile_order_version = ~0ull; break;
     case 4: e->dbg_linearize_variant = value; break;
     case 5: e->dbg_host_structure = value; e->finalized = false; break;
+    case 6: e->dbg_imu_wave = value; break;
     case 3: e->dbg_all_tiles = value; e->tile_order_version = ~0ull; e->A_cleared = nullptr; break;
     default: return e->fail_msg("ba_hip_debug_set: unknown key");
   }

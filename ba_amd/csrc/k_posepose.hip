@@ -145,7 +145,17 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
                        const_cast<double*>(steps) + (size_t)j * 160);
     return;
   }
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // mode 4 = mode 1 with ONE WAVEFRONT PER RESIDUAL: every lane runs the scalar code of the residual
+  // (uniform loads), the dense 10x10 / 15x15 products are dealt to the lanes through LDS (dpose.h:
+  // WaveCtx; bitwise the scalar results), the outputs are stored lane-strided.  For moderate residual
+  // counts: the private memory of a dispatch grows with its wavefronts.
+  __shared__ double wave_lds[256];
+  const bool wave = mode == 4;
+  const WaveCtx wctx = {wave_lds, (int)threadIdx.x};
+  const WaveCtx* wc = wave ? &wctx : nullptr;
+  if (wave) mode = 1;
+  const int lane0 = wave ? (int)threadIdx.x : 0, lstep = wave ? 64 : 1;
+  const int i = wave ? (int)blockIdx.x : (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i >= n) return;
   const double* s1 = state + (size_t)p1[i] * kPoseState;
   const double* s2 = state + (size_t)p2[i] * kPoseState;
@@ -172,12 +182,14 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     // integration covariance and bias Jacobian
     double* fz = frozen + (size_t)i * 160;
     const double* st = steps ? steps + (size_t)mptr[i] * 160 : nullptr;
-    if (cov_done[i]) imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, fz, nullptr);
-    else imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, nullptr, fz, st);
+    const bool done = cov_done[i] != 0;
+    if (wave) __syncthreads();  // every lane has read the flag before lane 0 sets it
+    if (done) imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, fz, nullptr, nullptr, wc);
+    else imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, nullptr, fz, st, wc);
     cov_done[i] = 1;
   } else {
     imu_residual(s1, s2, m, nm, g, noise, noise + 6, RS, true, &io, nullptr, nullptr,
-                 steps ? steps + (size_t)mptr[i] * 160 : nullptr);
+                 steps ? steps + (size_t)mptr[i] * 160 : nullptr, wc);
   }
   double w = 1.0;
   if (use_robust) {
@@ -192,17 +204,22 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     if (e > c_huber && !is_cond) w = c_huber / e;
   }
   PPBlocks b;
-  imu_blocks(io, w, &b);
-  store_blocks(b, pp_h, pp_g, slot0 + i);
+  imu_blocks(io, w, &b, wc);
+  {
+    double* h = pp_h + (size_t)(slot0 + i) * 3 * kPPH;
+    double* gg = pp_g + (size_t)(slot0 + i) * 30;
+    for (int k = lane0; k < kPPH; k += lstep) { h[k] = b.h11.m[k]; h[kPPH + k] = b.h12.m[k]; h[2 * kPPH + k] = b.h22.m[k]; }
+    for (int k = lane0; k < 15; k += lstep) { gg[k] = b.g1[k]; gg[15 + k] = b.g2[k]; }
+  }
   double* dz = pp_dz + (size_t)(slot0 + i) * 2 * kPPH;
   double* info = pp_info + (size_t)(slot0 + i) * kPPH;
-  for (int k = 0; k < kPPH; ++k) {
+  for (int k = lane0; k < kPPH; k += lstep) {
     dz[k] = io.dz1.m[k];
     dz[kPPH + k] = io.dz2.m[k];
     info[k] = io.cov_inv.m[k] * w;
     cst[k] = io.cov_inv.m[k] * w;  // res.cov_inv = res.cov_inv * weight (:1526)
   }
-  out_err[i] = b.err_build;
+  if (lane0 == 0) out_err[i] = b.err_build;
 }
 
 // ---- scatter into the reduced system --------------------------------------------------------
@@ -347,7 +364,8 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
   if (ni) {
     // two launches: the step Jacobians of every sample in parallel, then one lane per residual for the
     // sequential part (states, accumulations, the 15x15 algebra).  BA_HIP_IMU_FUSED=1: the single-launch form
-    static const bool fused = getenv("BA_HIP_IMU_FUSED") != nullptr;
+    static const bool fused_env = getenv("BA_HIP_IMU_FUSED") != nullptr;
+    const bool fused = fused_env || e->dbg_imu_wave == 2;  // (key 6 = 2: the single-pass form)
     const uint32_t n_meas = (uint32_t)(pb.imu_meas.size() / 7);
     const double* steps = nullptr;
     e->prof_begin(e->ev_imu, s2);
@@ -360,7 +378,10 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
                          e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
                          e->imu_frozen.p, e->imu_cov_done.p, steps);
     }
-    hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, s2, (int)ni, 1, e->pose_dim,
+    // a wavefront per residual (mode 4) up to a few thousand residuals; one lane per residual beyond
+    // (ba_hip_debug_set key 6: 0 = one lane per residual, 1 = a wavefront per residual, -1 = by count)
+    const bool wave = steps && (e->dbg_imu_wave < 0 ? ni <= 2048u : e->dbg_imu_wave != 0);
+    hipLaunchKernelGGL(k_imu, dim3(wave ? ni : (ni + 63) / 64), dim3(64), 0, s2, (int)ni, wave ? 4 : 1, e->pose_dim,
                        e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
                        e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                        e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,

@@ -2238,3 +2238,34 @@ def test_calibration_at_config1_scale_matches_oracle(oracle_lib, kind):
     assert rel_err(ch, co) < 1e-9
     print("calibration (%s) at config-1 scale: delta_p %.2e delta_k %.2e delta_l %.2e" %
           (kind, rel_err(h.delta_p(), o.delta_p()), rel_err(h.delta_k(), o.delta_k()), rel_err(h.delta_l(), o.delta_l())))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pose_dim", [9, 15])
+def test_inertial_linearisation_variants_agree(pose_dim):
+    """k_imu's three forms — single pass (step Jacobians inside), two passes with one lane per residual,
+    two passes with a wavefront per residual (dense products dealt to the lanes through LDS) — run the
+    same operations in the same order (bitwise equal when compiled for the host, tests/test_hostcheck.py;
+    on the device the compiler contracts multiply-adds per code shape): S, rhs and the Gauss-Newton step
+    agree to a few units in the last place."""
+    P = 40
+    sc = scene.make_scene(P, 400, 6, lm_dim=1, seed=9)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    pa = np.ones(P, dtype=np.uint8)
+    pa[0] = 0
+
+    def run(variant):
+        h = adjuster.BundleAdjuster(1, pose_dim)
+        h.Init(hip_options(apply_results=0, use_robust_norm_for_inertial_residuals=1))
+        scene.populate(h, sc, active=pa, imu=True)
+        h.Solve(0)                      # creates the engine and uploads the graph, no iteration
+        h.engine().debug_set(6, variant)
+        h.Solve(1)
+        return h.summary().inertial_error, h.S(), h.rhs(), h.delta_p()
+    ref = run(2)
+    assert np.abs(ref[1]).max() > 0 and ref[0] > 0
+    for variant in (0, 1):
+        got = run(variant)
+        assert abs(got[0] - ref[0]) <= 1e-12 * ref[0]
+        assert rel_err(got[1], ref[1]) < 1e-12 and rel_err(got[2], ref[2]) < 1e-12, variant
+        assert rel_err(got[3], ref[3]) < 1e-9, variant
