@@ -502,6 +502,37 @@ BA_HD void imu_cov_update(const DM<10, 6>& dy_db, const DM<10, 10>& dy_dy0, DM<1
   const DM<10, 10> prop = mmT(mm(dy_dy0, *cov, w), dy_dy0, w);
   *cov = madd(prop, mmT(GR, dy_db, w));
 }
+// Products with the two structured Jacobians of an RK4 stage — same sums in the same order as mm()
+// minus the terms that are exactly zero by construction:
+//   dy_dk (integrate_pose): rows 0-2 dt at (i, i); rows 3-6 the 4x3 block at columns 3-5; rows 7-9 dt at (7+i, 6+i)
+//   dk_dy (pose_derivative): rows 0-2 a 1 at (i, 7+i); rows 3-5 and 6-8 a 3x4 block at columns 3-6
+template <int N>
+BA_HD DM<10, N> mm_dy_dk(const DM<10, 9>& a, const DM<9, N>& x) {
+  DM<10, N> o;
+  for (int c = 0; c < N; ++c) {
+    for (int r = 0; r < 3; ++r) o(r, c) = 0.0 + a(r, r) * x(r, c);
+    for (int r = 3; r < 7; ++r) {
+      double s = 0.0;
+      for (int k = 3; k < 6; ++k) s += a(r, k) * x(k, c);
+      o(r, c) = s;
+    }
+    for (int r = 7; r < 10; ++r) o(r, c) = 0.0 + a(r, r - 1) * x(r - 1, c);
+  }
+  return o;
+}
+template <int N>
+BA_HD DM<9, N> mm_dk_dy(const DM<9, 10>& a, const DM<10, N>& y) {
+  DM<9, N> o;
+  for (int c = 0; c < N; ++c) {
+    for (int r = 0; r < 3; ++r) o(r, c) = 0.0 + a(r, 7 + r) * y(7 + r, c);
+    for (int r = 3; r < 9; ++r) {
+      double s = 0.0;
+      for (int k = 3; k < 7; ++k) s += a(r, k) * y(k, c);
+      o(r, c) = s;
+    }
+  }
+  return o;
+}
 // Types.h:419-643, Jacobian branch, Euler covariance (C <- F C F^T + G R G^T)
 BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* z1, const double* bg,
                              const double* ba, const double* g, bool jac, DM<10, 6>* dy_db,
@@ -531,29 +562,29 @@ BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* 
   const DM<9, 6> dk1_db = dk_db;
   const DM<9, 10> dk1_dy = dk_dy;
   const ImuState y1 = integrate_pose(s, k1, dt * 0.5, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dk1_db, w);
-  *dy_dy0 = mm(dy_dk, dk1_dy, w);
+  *dy_db = mm_dy_dk(dy_dk, dk1_db);
+  *dy_dy0 = mm_dy_dk(dy_dk, dk1_dy);
   add_ident(*dy_dy0, dyy);
 
   pose_derivative(y1, g, z0, z1, bg, ba, dt / 2, k2, &dk_db, &dk_dy);
-  const DM<9, 6> dk2_db = madd(dk_db, mm(dk_dy, *dy_db, w));
-  const DM<9, 10> dk2_dy = mm(dk_dy, *dy_dy0, w);
+  const DM<9, 6> dk2_db = madd(dk_db, mm_dk_dy(dk_dy, *dy_db));
+  const DM<9, 10> dk2_dy = mm_dk_dy(dk_dy, *dy_dy0);
   const ImuState y2 = integrate_pose(s, k2, dt * 0.5, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dk2_db, w);
-  *dy_dy0 = mm(dy_dk, dk2_dy, w);
+  *dy_db = mm_dy_dk(dy_dk, dk2_db);
+  *dy_dy0 = mm_dy_dk(dy_dk, dk2_dy);
   add_ident(*dy_dy0, dyy);
 
   pose_derivative(y2, g, z0, z1, bg, ba, dt / 2, k3, &dk_db, &dk_dy);
-  const DM<9, 6> dk3_db = madd(dk_db, mm(dk_dy, *dy_db, w));
-  const DM<9, 10> dk3_dy = mm(dk_dy, *dy_dy0, w);
+  const DM<9, 6> dk3_db = madd(dk_db, mm_dk_dy(dk_dy, *dy_db));
+  const DM<9, 10> dk3_dy = mm_dk_dy(dk_dy, *dy_dy0);
   const ImuState y3 = integrate_pose(s, k3, dt, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dk3_db, w);
-  *dy_dy0 = mm(dy_dk, dk3_dy, w);
+  *dy_db = mm_dy_dk(dy_dk, dk3_db);
+  *dy_dy0 = mm_dy_dk(dy_dk, dk3_dy);
   add_ident(*dy_dy0, dyy);
 
   pose_derivative(y3, g, z0, z1, bg, ba, dt, k4, &dk_db, &dk_dy);
-  const DM<9, 6> dk4_db = madd(dk_db, mm(dk_dy, *dy_db, w));
-  const DM<9, 10> dk4_dy = mm(dk_dy, *dy_dy0, w);
+  const DM<9, 6> dk4_db = madd(dk_db, mm_dk_dy(dk_dy, *dy_db));
+  const DM<9, 10> dk4_dy = mm_dk_dy(dk_dy, *dy_dy0);
 
   for (int i = 0; i < 9; ++i) k[i] = k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i];
   DM<9, 6> dkt_db;
@@ -561,8 +592,8 @@ BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* 
   for (int i = 0; i < 54; ++i) dkt_db.m[i] = dk1_db.m[i] + 2 * dk2_db.m[i] + 2 * dk3_db.m[i] + dk4_db.m[i];
   for (int i = 0; i < 90; ++i) dkt_dy.m[i] = dk1_dy.m[i] + 2 * dk2_dy.m[i] + 2 * dk3_dy.m[i] + dk4_dy.m[i];
   const ImuState res = integrate_pose(s, k, dt / 6.0, &dy_dk, &dyy);
-  *dy_db = mm(dy_dk, dkt_db, w);
-  *dy_dy0 = mm(dy_dk, dkt_dy, w);
+  *dy_db = mm_dy_dk(dy_dk, dkt_db);
+  *dy_dy0 = mm_dy_dk(dy_dk, dkt_dy);
   add_ident(*dy_dy0, dyy);
   if (cov) imu_cov_update(*dy_db, *dy_dy0, cov, r6, w);
   return res;
