@@ -60,40 +60,49 @@ BA_HD DM<R, C> mTm(const DM<K, R>& a, const DM<K, C>& b) {  // a^T * b
 // Wave-cooperative products (device only).  When the 64 lanes of ONE wavefront run the same scalar
 // code on the same residual — every lane holds identical copies of the operands — a product is dealt
 // element-wise to the lanes (each element summed over k in the order of mm / mmT / mTm: bitwise the
-// scalar result), exchanged through `lds` (>= R*C doubles, workgroup = that one wavefront) and read
+// scalar result), exchanged through `lds` (>= 3 * 225 doubles, workgroup = that one wavefront) and read
 // back by every lane.  ctx == nullptr (always on the host): the scalar product.
 struct WaveCtx { double* lds; int lane; };
 #if defined(__HIP_DEVICE_COMPILE__)
-#define BAD_WAVE_PRODUCT(EXPR)                                        \
+// operands first into LDS (each lane copies its share of the — identical — private copies: a few
+// dynamically indexed private-memory reads instead of 2 K per output element), then the elements
+// from LDS.  NA / NB: element counts of the operands; IA / IB: their index expressions in (r, k, c).
+#define BAD_WAVE_PRODUCT(NA, NB, IA, IB)                              \
   if (w) {                                                            \
+    double* la = w->lds;                                              \
+    double* lb = la + (NA);                                           \
+    double* lo = lb + (NB);                                           \
+    for (int e = w->lane; e < (NA); e += 64) la[e] = a.m[e];          \
+    for (int e = w->lane; e < (NB); e += 64) lb[e] = b.m[e];          \
+    __syncthreads();                                                  \
     for (int e = w->lane; e < R * C; e += 64) {                       \
       const int r = e / C, c = e - r * C;                             \
       double s = 0.0;                                                 \
-      for (int k = 0; k < K; ++k) s += (EXPR);                        \
-      w->lds[e] = s;                                                  \
+      for (int k = 0; k < K; ++k) s += la[IA] * lb[IB];               \
+      lo[e] = s;                                                      \
     }                                                                 \
     __syncthreads();                                                  \
     DM<R, C> o;                                                       \
-    for (int e = 0; e < R * C; ++e) o.m[e] = w->lds[e];               \
+    for (int e = 0; e < R * C; ++e) o.m[e] = lo[e];                   \
     __syncthreads();                                                  \
     return o;                                                         \
   }
 #else
-#define BAD_WAVE_PRODUCT(EXPR) (void)w;
+#define BAD_WAVE_PRODUCT(NA, NB, IA, IB) (void)w;
 #endif
 template <int R, int K, int C>
 BA_HD DM<R, C> mm(const DM<R, K>& a, const DM<K, C>& b, const WaveCtx* w) {
-  BAD_WAVE_PRODUCT(a(r, k) * b(k, c))
+  BAD_WAVE_PRODUCT(R * K, K * C, r * K + k, k * C + c)
   return mm(a, b);
 }
 template <int R, int K, int C>
 BA_HD DM<R, C> mmT(const DM<R, K>& a, const DM<C, K>& b, const WaveCtx* w) {
-  BAD_WAVE_PRODUCT(a(r, k) * b(c, k))
+  BAD_WAVE_PRODUCT(R * K, C * K, r * K + k, c * K + k)
   return mmT(a, b);
 }
 template <int K, int R, int C>
 BA_HD DM<R, C> mTm(const DM<K, R>& a, const DM<K, C>& b, const WaveCtx* w) {
-  BAD_WAVE_PRODUCT(a(k, r) * b(k, c))
+  BAD_WAVE_PRODUCT(K * R, K * C, k * R + r, k * C + c)
   return mTm(a, b);
 }
 #undef BAD_WAVE_PRODUCT
@@ -151,6 +160,69 @@ BA_HD void invert_leading(DM<N, N>& a, int n) {
   }
   for (int r = 0; r < n; ++r)
     for (int c = 0; c < n; ++c) a(r, c) = inv(r, c);
+}
+
+// The same elimination with the 2 n^2 entries of [a | inv] dealt to the lanes of one wavefront and both
+// matrices in LDS (w->lds: 2 * N * N doubles): per column the pivot search (every lane reads the
+// column: same decision everywhere), the row swap, the scaling of the pivot row and the elimination
+// of all other rows, each entry by the expression of invert_leading — bitwise the same inverse.
+template <int N>
+BA_HD void invert_leading(DM<N, N>& a, int n, const WaveCtx* w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (w) {
+    double* A = w->lds;
+    double* I = w->lds + N * N;
+    const int lane = w->lane;
+    for (int e = lane; e < N * N; e += 64) { A[e] = a.m[e]; I[e] = ((e / N) == (e % N)) ? 1.0 : 0.0; }
+    __syncthreads();
+    for (int col = 0; col < n; ++col) {
+      int piv = col;
+      double best = fabs(A[col * N + col]);
+      for (int r = col + 1; r < n; ++r) {
+        const double v = fabs(A[r * N + col]);
+        if (v > best) { best = v; piv = r; }
+      }
+      __syncthreads();
+      if (piv != col && lane < 2 * n) {
+        double* M = lane < n ? A : I;
+        const int c = lane < n ? lane : lane - n;
+        const double t = M[piv * N + c]; M[piv * N + c] = M[col * N + c]; M[col * N + c] = t;
+      }
+      __syncthreads();
+      const double s = 1.0 / A[col * N + col];
+      __syncthreads();
+      if (lane < 2 * n) {
+        double* M = lane < n ? A : I;
+        const int c = lane < n ? lane : lane - n;
+        M[col * N + c] *= s;
+      }
+      __syncthreads();
+      // every other row r: x(r, c) -= f_r * x(col, c) with f_r = a(r, col) read before anything moves
+      double fa[8];
+      int cnt = 0;
+      for (int e = lane; e < 2 * n * n; e += 64, ++cnt) {
+        const int r = (e % (n * n)) / n;
+        fa[cnt] = A[r * N + col];
+      }
+      __syncthreads();
+      cnt = 0;
+      for (int e = lane; e < 2 * n * n; e += 64, ++cnt) {
+        const int m = e / (n * n), rc = e % (n * n), r = rc / n, c = rc % n;
+        if (r == col || fa[cnt] == 0.0) continue;
+        double* M = m ? I : A;
+        M[r * N + c] -= fa[cnt] * M[col * N + c];
+      }
+      __syncthreads();
+    }
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) a(r, c) = I[r * N + c];
+    __syncthreads();
+    return;
+  }
+#else
+  (void)w;
+#endif
+  invert_leading(a, n);
 }
 
 // ---- rigid transform with quaternion (x,y,z,w) --------------------------------------
@@ -533,6 +605,51 @@ BA_HD DM<9, N> mm_dk_dy(const DM<9, 10>& a, const DM<10, N>& y) {
   }
   return o;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// Wave mode of the per-residual pass: the two accumulations of one integration step with everything
+// resident in LDS (no private-memory copies of the 10x10 matrices): layout in w->lds
+//   cov[100] | dpose_db[60] | t1[100] | step dy_db[60] | step dy_dy0[100]
+// Element by element the expressions of imu_cov_update and of `madd(dy_db, mm(dy_dy, dpose_db))`.
+BA_HD void imu_accumulate_wave(const double* __restrict__ st, bool update_cov, const double* r6, const WaveCtx* w) {
+  double* cov = w->lds;
+  double* dp = cov + 100;
+  double* t1 = dp + 60;
+  double* sdb = t1 + 100;
+  double* sdy = sdb + 60;
+  const int lane = w->lane;
+  for (int e = lane; e < 160; e += 64) sdb[e] = st[e];  // (sdy follows sdb)
+  __syncthreads();
+  if (update_cov) {
+    for (int e = lane; e < 100; e += 64) {
+      const int r = e / 10, c = e - 10 * r;
+      double s = 0.0;
+      for (int k = 0; k < 10; ++k) s += sdy[r * 10 + k] * cov[k * 10 + c];
+      t1[e] = s;
+    }
+    __syncthreads();
+    for (int e = lane; e < 100; e += 64) {
+      const int r = e / 10, c = e - 10 * r;
+      double p = 0.0, g = 0.0;
+      for (int k = 0; k < 10; ++k) p += t1[r * 10 + k] * sdy[c * 10 + k];
+      for (int k = 0; k < 6; ++k) {
+        const double gr = sdb[r * 6 + k] * r6[k];
+        g += gr * sdb[c * 6 + k];
+      }
+      cov[e] = p + 1.0 * g;
+    }
+    __syncthreads();
+  }
+  for (int e = lane; e < 60; e += 64) {
+    const int r = e / 6, c = e - 6 * r;
+    double s = 0.0;
+    for (int k = 0; k < 10; ++k) s += sdy[r * 10 + k] * dp[k * 6 + c];
+    t1[e] = sdb[e] + 1.0 * s;
+  }
+  __syncthreads();
+  for (int e = lane; e < 60; e += 64) dp[e] = t1[e];
+  __syncthreads();
+}
+#endif
 // Types.h:419-643, Jacobian branch, Euler covariance (C <- F C F^T + G R G^T)
 BA_HD ImuState integrate_imu(const ImuState& s, const double* z0, const double* z1, const double* bg,
                              const double* ba, const double* g, bool jac, DM<10, 6>* dy_db,
@@ -627,7 +744,25 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
   dpose_db.zero();
   cov.zero();
   const bool ijac = jac && !frozen_in;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool lds_acc = ijac && steps && w;
+  if (lds_acc) {
+    for (int e = w->lane; e < 160; e += 64) w->lds[e] = 0.0;  // cov | dpose_db
+    __syncthreads();
+  }
+#else
+  const bool lds_acc = false;
+#endif
   for (int i = 1; i < nmeas; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lds_acc) {
+      const double* z0 = meas + 7 * (i - 1);
+      const double* z1 = meas + 7 * i;
+      s = integrate_imu(s, z0, z1, bg, ba, g, false, nullptr, nullptr, nullptr, r6);
+      imu_accumulate_wave(steps + (size_t)160 * i, z1[6] - z0[6] != 0, r6, w);
+      continue;
+    }
+#endif
     if (ijac && steps) {
       const double* z0 = meas + 7 * (i - 1);
       const double* z1 = meas + 7 * i;
@@ -641,6 +776,13 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
     }
     if (ijac) dpose_db = madd(dy_db, mm(dy_dy, dpose_db, w));  // Types.h:712-714
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (lds_acc) {
+    for (int k = 0; k < 100; ++k) cov.m[k] = w->lds[k];
+    for (int k = 0; k < 60; ++k) dpose_db.m[k] = w->lds[100 + k];
+    __syncthreads();
+  }
+#endif
   if (jac && frozen_in) {
     for (int k = 0; k < 100; ++k) cov.m[k] = frozen_in[k];
     for (int k = 0; k < 60; ++k) dpose_db.m[k] = frozen_in[100 + k];
@@ -693,7 +835,7 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
   if (RS >= 15)
     for (int i = 0; i < 6; ++i) o->cov_inv(9 + i, 9 + i) = rb6[i] * total_dt;
   set_block(o->cov_inv, 0, 0, c9);
-  invert_leading(o->cov_inv, RS);
+  invert_leading(o->cov_inv, RS, w);
   for (int i = RS; i < 15; ++i)
     for (int c = 0; c < 15; ++c) { o->cov_inv(i, c) = 0.0; o->cov_inv(c, i) = 0.0; }
   if (RS >= 15) {  // :313-337
@@ -728,6 +870,52 @@ BA_HD void imu_step_jacobians(const double* p1, const double* meas, int k, const
 }
 
 // blocks J^T S^-1 J, J^T S^-1 r with S^-1 = cov_inv * weight (BundleAdjuster.cpp:1526)
+#if defined(__HIPCC__)
+// Wave mode of imu_blocks: operands in LDS (info | dz1 | dz2 | j1t | j2t, 5 x 225 doubles), the three
+// Hessian blocks and the two gradients go straight from the lanes to global memory.  Same sums in the
+// same order as the scalar form.  Returns the error term.
+__device__ __forceinline__ double imu_blocks_wave(const ImuOut& io, double weight, const WaveCtx* w, double* __restrict__ h675,
+                             double* __restrict__ g30) {
+  double* info = w->lds;
+  double* z1 = info + 225;
+  double* z2 = z1 + 225;
+  double* j1 = z2 + 225;
+  double* j2 = j1 + 225;
+  const int lane = w->lane;
+  for (int e = lane; e < 225; e += 64) { info[e] = io.cov_inv.m[e] * weight; z1[e] = io.dz1.m[e]; z2[e] = io.dz2.m[e]; }
+  __syncthreads();
+  for (int e = lane; e < 225; e += 64) {
+    const int r = e / 15, c = e - 15 * r;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < 15; ++k) { s1 += z1[k * 15 + r] * info[k * 15 + c]; s2 += z2[k * 15 + r] * info[k * 15 + c]; }
+    j1[e] = s1; j2[e] = s2;
+  }
+  __syncthreads();
+  for (int e = lane; e < 225; e += 64) {
+    const int r = e / 15, c = e - 15 * r;
+    double a = 0.0, b = 0.0, d = 0.0;
+    for (int k = 0; k < 15; ++k) {
+      a += j1[r * 15 + k] * z1[k * 15 + c];
+      b += j1[r * 15 + k] * z2[k * 15 + c];
+      d += j2[r * 15 + k] * z2[k * 15 + c];
+    }
+    h675[e] = a; h675[225 + e] = b; h675[450 + e] = d;
+  }
+  double* q = z1;  // (reused after the barrier below)
+  __syncthreads();
+  if (lane < 15) {
+    double s1 = 0.0, s2 = 0.0, qq = 0.0;
+    for (int k = 0; k < 15; ++k) { s1 += j1[lane * 15 + k] * io.r[k]; s2 += j2[lane * 15 + k] * io.r[k]; qq += info[lane * 15 + k] * io.r[k]; }
+    g30[lane] = s1; g30[15 + lane] = s2;
+    q[lane] = qq;
+  }
+  __syncthreads();
+  double e = 0.0;
+  for (int i = 0; i < 15; ++i) e += io.r[i] * q[i];
+  __syncthreads();
+  return e;
+}
+#endif
 BA_HD void imu_blocks(const ImuOut& io, double weight, PPBlocks* o, const WaveCtx* w = nullptr) {
   DM<15, 15> info = io.cov_inv;
   for (int i = 0; i < 225; ++i) info.m[i] *= weight;

@@ -149,7 +149,7 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
   // (uniform loads), the dense 10x10 / 15x15 products are dealt to the lanes through LDS (dpose.h:
   // WaveCtx; bitwise the scalar results), the outputs are stored lane-strided.  For moderate residual
   // counts: the private memory of a dispatch grows with its wavefronts.
-  __shared__ double wave_lds[256];
+  __shared__ double wave_lds[1280];  // products: both operands + output (<= 3 x 225); the inverse: 2 x 225; accumulation: 420; blocks: 5 x 225
   const bool wave = mode == 4;
   const WaveCtx wctx = {wave_lds, (int)threadIdx.x};
   const WaveCtx* wc = wave ? &wctx : nullptr;
@@ -203,13 +203,19 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     const bool is_cond = !pose_active[p1[i]] && pose_active[p2[i]];
     if (e > c_huber && !is_cond) w = c_huber / e;
   }
-  PPBlocks b;
-  imu_blocks(io, w, &b, wc);
+  double err_build;
   {
     double* h = pp_h + (size_t)(slot0 + i) * 3 * kPPH;
     double* gg = pp_g + (size_t)(slot0 + i) * 30;
-    for (int k = lane0; k < kPPH; k += lstep) { h[k] = b.h11.m[k]; h[kPPH + k] = b.h12.m[k]; h[2 * kPPH + k] = b.h22.m[k]; }
-    for (int k = lane0; k < 15; k += lstep) { gg[k] = b.g1[k]; gg[15 + k] = b.g2[k]; }
+    if (wave) {
+      err_build = imu_blocks_wave(io, w, wc, h, gg);
+    } else {
+      PPBlocks b;
+      imu_blocks(io, w, &b, nullptr);
+      for (int k = 0; k < kPPH; ++k) { h[k] = b.h11.m[k]; h[kPPH + k] = b.h12.m[k]; h[2 * kPPH + k] = b.h22.m[k]; }
+      for (int k = 0; k < 15; ++k) { gg[k] = b.g1[k]; gg[15 + k] = b.g2[k]; }
+      err_build = b.err_build;
+    }
   }
   double* dz = pp_dz + (size_t)(slot0 + i) * 2 * kPPH;
   double* info = pp_info + (size_t)(slot0 + i) * kPPH;
@@ -219,7 +225,7 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     info[k] = io.cov_inv.m[k] * w;
     cst[k] = io.cov_inv.m[k] * w;  // res.cov_inv = res.cov_inv * weight (:1526)
   }
-  if (lane0 == 0) out_err[i] = b.err_build;
+  if (lane0 == 0) out_err[i] = err_build;
 }
 
 // ---- scatter into the reduced system --------------------------------------------------------
