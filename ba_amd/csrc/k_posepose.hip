@@ -384,9 +384,10 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
                          e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
                          e->imu_frozen.p, e->imu_cov_done.p, steps);
     }
-    // a wavefront per residual (mode 4) up to a few thousand residuals; one lane per residual beyond
+    // a wavefront per residual (mode 4) up to 16k residuals; one lane per residual beyond
     // (ba_hip_debug_set key 6: 0 = one lane per residual, 1 = a wavefront per residual, -1 = by count)
-    const bool wave = steps && (e->dbg_imu_wave < 0 ? ni <= 2048u : e->dbg_imu_wave != 0);
+    static const uint32_t wave_max = getenv("BA_HIP_IMU_WAVE_MAX") ? (uint32_t)atoi(getenv("BA_HIP_IMU_WAVE_MAX")) : 16384u;
+    const bool wave = steps && (e->dbg_imu_wave < 0 ? ni <= wave_max : e->dbg_imu_wave != 0);
     hipLaunchKernelGGL(k_imu, dim3(wave ? ni : (ni + 63) / 64), dim3(64), 0, s2, (int)ni, wave ? 4 : 1, e->pose_dim,
                        e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
                        e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
