@@ -327,6 +327,26 @@ def add_inertial(sc, period=60.0, samples_per_interval=10, seed=0, vel_sigma=0.0
     return sc
 
 
+def fov_factor(r, w):
+    """r_d / r_u of the FOV camera model (Devernay & Faugeras): atan(2 r tan(w/2)) / (r w)."""
+    r = np.asarray(r, dtype=np.float64)
+    m = 2.0 * np.tan(0.5 * w)
+    rs = np.where(r * r < 1e-5, 1.0, r)
+    return np.where(r * r < 1e-5, m / w, np.arctan(rs * m) / (rs * w))
+
+
+def to_fov_camera(sc, w):
+    """Turn a pinhole scene into the same scene seen through a FOV camera (fx, fy, u0, v0, w):
+    every measured pixel is moved to where that camera images its ray.  The landmarks are
+    back-projections of the reference pixels, so they stay where they are."""
+    fx, fy, u0, v0 = sc.cam_params[:4]
+    px, py = (sc.obs_z[:, 0] - u0) / fx, (sc.obs_z[:, 1] - v0) / fy
+    f = fov_factor(np.hypot(px, py), w)
+    sc.obs_z = np.stack([fx * f * px + u0, fy * f * py + v0], -1)
+    sc.cam_params = np.array([fx, fy, u0, v0, w])
+    return sc
+
+
 def relative_pose(a, b):
     """T_ab = T_wa^-1 T_wb for poses [t, q(xyzw)]."""
     ra, rb = quat_to_rot(np.asarray(a)[3:7]), quat_to_rot(np.asarray(b)[3:7])

@@ -78,7 +78,7 @@ struct ProjectionResidual {  // Types.h:282-298
   Mat<2, 6> dz_dx_meas, dz_dx_ref;
   Mat<2, 6> dz_dx_meas_raw, dz_dx_ref_raw;  // taps: before column masking
   Mat<2, 6> dz_dtvs;  // Types.h:295, d residual / d T_vs (DoTvs instantiations only)
-  Mat<2, 4> dz_dcam_params;  // Types.h:294 (CalibSize instantiations; pinhole: 4 parameters)
+  Mat<2, 5> dz_dcam_params;  // Types.h:294 (CalibSize instantiations; pinhole: 4 parameters, FOV camera: 5)
   double mahalanobis_distance = 0, weight = 1, orig_weight = 1;
   bool is_conditioning = false;
 };
@@ -1209,6 +1209,7 @@ struct orc_ba {
     if (kCamParamsInCalib && !delta.delta_k.empty() && !rig_.empty()) {
       Pinhole& m = rig_[0].model;
       m.fx -= delta.delta_k[0]; m.fy -= delta.delta_k[1]; m.u0 -= delta.delta_k[2]; m.v0 -= delta.delta_k[3];
+      if (kCamParamsDim == 5) m.w -= delta.delta_k[4];
       if (kLmDim == 1)
         for (Landmark& lm : landmarks_) {
           const double norm = std::sqrt(lm.x_s[0] * lm.x_s[0] + lm.x_s[1] * lm.x_s[1] + lm.x_s[2] * lm.x_s[2]);
@@ -1633,7 +1634,9 @@ orc_ba* orc_create(int lm_dim, int pose_dim) { return orc_create_calib(lm_dim, p
 orc_ba* orc_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs) {
   if (!(lm_dim == 0 || lm_dim == 1 || lm_dim == 3)) return nullptr;
   if (!(pose_dim == 6 || pose_dim == 9 || pose_dim == 15)) return nullptr;
-  if (calib_size != 0 && calib_size != 4) return nullptr;  // the pinhole model has four parameters
+  // the pinhole model has four parameters, the FOV model five (camera 0 must be of that model
+  // when Solve() runs: checked there, as the reference's fixed-size assignment at parallel_algos.h:115 would)
+  if (calib_size != 0 && calib_size != 4 && calib_size != 5) return nullptr;
   if (calib_size != 0 && do_tvs) return nullptr;           // the reference wipes the intrinsics then (see orc_ba)
   if ((do_tvs || calib_size) && lm_dim != 1) return nullptr;  // both Jacobians exist for LmSize 1 only (parallel_algos.h:102)
   return new orc_ba(lm_dim, pose_dim, do_tvs != 0, calib_size);
@@ -1649,6 +1652,11 @@ uint32_t orc_add_camera(orc_ba* h, const double params[4], const double t_vs[7])
   h->rig_.push_back(c);
   return h->rig_.size();  // BundleAdjuster.h:259-263 returns NumCams()
 }
+void orc_set_camera_fov(orc_ba* h, uint32_t cam_id, double w) {
+  h->rig_[cam_id].model.model = 1;
+  h->rig_[cam_id].model.w = w;
+}
+double orc_get_camera_fov(const orc_ba* h, uint32_t cam_id) { return h->rig_[cam_id].model.w; }
 uint32_t orc_add_pose(orc_ba* h, const double t_wp[7], const double v_w[3], const double b[6],
                       int is_active, double time) {
   Vec3 v; Vec6 bb;
@@ -1817,7 +1825,28 @@ void orc_math_transfer(const double params[4], const double t_ba[7], const doubl
   Vec2 px; px[0] = pix[0]; px[1] = pix[1];
   const Vec2 p = m.Transfer3d(t, m.Unproject(px), rho);
   out[0] = p[0]; out[1] = p[1];
-  if (jac8) { const Mat<2, 4> J = m.dTransfer_dparams(t, px, rho); memcpy(jac8, J.a, 8 * sizeof(double)); }
+  if (jac8) {
+    const Mat<2, 5> J = m.dTransfer_dparams(t, px, rho);
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 4; ++c) jac8[4 * r + c] = J(r, c);
+  }
+}
+void orc_math_transfer_fov(const double params[5], const double t_ba[7], const double pix[2], double rho,
+                           double out[2], double jac10[10]) {
+  Pinhole m; m.fx = params[0]; m.fy = params[1]; m.u0 = params[2]; m.v0 = params[3]; m.w = params[4]; m.model = 1;
+  const SE3 t = se3_from7(t_ba);
+  Vec2 px; px[0] = pix[0]; px[1] = pix[1];
+  const Vec2 p = m.Transfer3d(t, m.Unproject(px), rho);
+  out[0] = p[0]; out[1] = p[1];
+  if (jac10) { const Mat<2, 5> J = m.dTransfer_dparams(t, px, rho); memcpy(jac10, J.a, 10 * sizeof(double)); }
+}
+void orc_math_fov_project(const double params[5], const double P[3], double pix[2], double dpix_dP[6], double ray[3]) {
+  Pinhole m; m.fx = params[0]; m.fy = params[1]; m.u0 = params[2]; m.v0 = params[3]; m.w = params[4]; m.model = 1;
+  Vec3 X; X[0] = P[0]; X[1] = P[1]; X[2] = P[2];
+  const Vec2 p = m.Project(X);
+  pix[0] = p[0]; pix[1] = p[1];
+  if (dpix_dP) { const Mat<2, 3> d = m.dProject_dP(X); memcpy(dpix_dP, d.a, 6 * sizeof(double)); }
+  if (ray) { const Vec3 r = m.Unproject(p); ray[0] = r[0]; ray[1] = r[1]; ray[2] = r[2]; }
 }
 void orc_get_proj_tvs_jacobians(const orc_ba* h, double* j_tvs) {
   for (size_t i = 0; i < h->proj_residuals_.size(); ++i)

@@ -53,7 +53,9 @@ void orc_default_options(orc_options* o);
 orc_ba* orc_create(int lm_dim, int pose_dim);
 /* BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs> (BundleAdjuster.h:110-134).  Restated:
    calib_size = 0 with do_tvs = 0 | 1, and calib_size = 4 (the pinhole parameters fx, fy, u0, v0 of
-   camera 0, BundleAdjuster.cpp:46-69) with do_tvs = 0 — LmSize 1 only; anything else returns NULL.
+   camera 0, BundleAdjuster.cpp:46-69) or 5 (fx, fy, u0, v0, w of a FOV camera 0 — the reference's
+   SelfCalBundleAdjuster, BundleAdjuster.h:758-759) with do_tvs = 0 — LmSize 1 only; anything else
+   returns NULL.
    The reduced system is (n + kCalibDim)^2: the calibration unknowns follow the pose unknowns
    (BundleAdjuster.cpp:316-322, 493-583); with do_tvs they are the decoupled update of the
    extrinsics T_vs of camera 0 (:72-83). */
@@ -137,6 +139,14 @@ void orc_get_proj_calib_jacobians(const orc_ba* h, double* j_k); /* 2 x kCalibDi
    parameter Jacobian (jac8 may be NULL) — finite-difference pin of dTransfer_dparams */
 void orc_math_transfer(const double params[4], const double t_ba[7], const double pix[2], double rho,
                        double out[2], double jac8[8]);
+/* the same for the FOV camera (fx, fy, u0, v0, w): 2x5 Jacobian; and Project / dProject_dP /
+   Unproject(Project(P)) of that model */
+void orc_math_transfer_fov(const double params[5], const double t_ba[7], const double pix[2], double rho,
+                           double out[2], double jac10[10]);
+void orc_math_fov_project(const double params[5], const double P[3], double pix[2], double dpix_dP[6], double ray[3]);
+/* camera cam_id becomes a calibu::FovCamera with distortion parameter w (default: LinearCamera) */
+void orc_set_camera_fov(orc_ba* h, uint32_t cam_id, double w);
+double orc_get_camera_fov(const orc_ba* h, uint32_t cam_id);
 void orc_get_proj_weights(const orc_ba* h, double* w);   /* per residual id */
 void orc_get_proj_residuals(const orc_ba* h, double* r2);/* per residual id, 2 each */
 void orc_get_imu_residuals(const orc_ba* h, double* r15);/* ImuResidualT::residual, 15 each (first PoseSize used) */

@@ -234,21 +234,76 @@ inline Mat<7, 7> dt1_t2_dt2(const SE3& t1) {
 }
 
 // ---------------------------------------------------------------------------
-// Calibu pinhole ("LinearCamera", params fx,fy,u0,v0) as the hot path uses it.
-// Calibu 0.1 is not in the reference tree; semantics reconstructed from the call
-// sites parallel_algos.h:59-62,73-78: PARITY UNPINNED.
+// Calibu camera models as the hot path uses them: "LinearCamera" (pinhole, params fx,fy,u0,v0)
+// and "FovCamera" (params fx,fy,u0,v0,w — the five parameters of the reference's CalibSize = 5
+// instantiations, BundleAdjuster.cpp:1816-1826, BundleAdjuster.h:758-759).
+// Calibu 0.1 is not in the reference tree; the pinhole semantics are reconstructed from the call
+// sites parallel_algos.h:59-62,73-78, the FOV model is the published one
+// (Devernay & Faugeras 2001, "Straight lines have to be straight": r_d = atan(2 r_u tan(w/2)) / w)
+// in the multiplicative form calibu applies it — pix = K (factor(r_u) p), p = P.xy / P.z — with the
+// limit values taken for a vanishing radius or a vanishing w.  PARITY UNPINNED for both; every
+// derivative below is pinned by finite differences of the function it differentiates.
 struct Pinhole {
-  double fx, fy, u0, v0;
+  double fx = 1, fy = 1, u0 = 0, v0 = 0;
+  double w = 0;   // FOV distortion parameter (model 1)
+  int model = 0;  // 0 LinearCamera, 1 FovCamera
+  static constexpr double kSmall = 1e-5;  // squared radius / squared w below which the limits are used
+  int NumParams() const { return model == 1 ? 5 : 4; }
+  // distortion factor r_d / r_u and its derivatives over the radius and over w
+  void Factor(double r, double* f, double* df_dr, double* df_dw) const {
+    *f = 1.0; *df_dr = 0.0; *df_dw = 0.0;
+    if (model != 1 || w * w <= kSmall) return;
+    const double th = std::tan(0.5 * w), m = 2.0 * th, dm = 1.0 + th * th;
+    if (r * r < kSmall) {
+      *f = m / w;
+      *df_dw = dm / w - m / (w * w);
+      return;
+    }
+    const double at = std::atan(r * m), den = 1.0 + r * r * m * m;
+    *f = at / (r * w);
+    *df_dr = m / (den * r * w) - at / (r * r * w);
+    *df_dw = dm / (den * w) - at / (r * w * w);
+  }
+  // inverse factor r_u / r_d over the distorted radius
+  void FactorInv(double rd, double* g, double* dg_dr, double* dg_dw) const {
+    *g = 1.0; *dg_dr = 0.0; *dg_dw = 0.0;
+    if (model != 1 || w * w <= kSmall) return;
+    const double th = std::tan(0.5 * w), m = 2.0 * th, dm = 1.0 + th * th;
+    if (rd * rd < kSmall) {
+      *g = w / m;
+      *dg_dw = 1.0 / m - w * dm / (m * m);
+      return;
+    }
+    const double tn = std::tan(rd * w), sec2 = 1.0 + tn * tn;
+    *g = tn / (rd * m);
+    *dg_dr = w * sec2 / (rd * m) - tn / (rd * rd * m);
+    *dg_dw = sec2 / m - tn * dm / (rd * m * m);
+  }
   Vec2 Project(const Vec3& P) const {
+    const double px = P[0] / P[2], py = P[1] / P[2];
+    double f, dr, dw;
+    Factor(std::sqrt(px * px + py * py), &f, &dr, &dw);
     Vec2 p;
-    p[0] = fx * P[0] / P[2] + u0;
-    p[1] = fy * P[1] / P[2] + v0;
+    if (model == 1) { p[0] = fx * (f * px) + u0; p[1] = fy * (f * py) + v0; }
+    else { p[0] = fx * P[0] / P[2] + u0; p[1] = fy * P[1] / P[2] + v0; }
     return p;
   }
   Mat<2, 3> dProject_dP(const Vec3& P) const {
     Mat<2, 3> d;
-    d(0, 0) = fx / P[2]; d(0, 2) = -fx * P[0] / (P[2] * P[2]);
-    d(1, 1) = fy / P[2]; d(1, 2) = -fy * P[1] / (P[2] * P[2]);
+    if (model != 1) {
+      d(0, 0) = fx / P[2]; d(0, 2) = -fx * P[0] / (P[2] * P[2]);
+      d(1, 1) = fy / P[2]; d(1, 2) = -fy * P[1] / (P[2] * P[2]);
+      return d;
+    }
+    const double iz = 1.0 / P[2], px = P[0] * iz, py = P[1] * iz, r = std::sqrt(px * px + py * py);
+    double f, dr, dw;
+    Factor(r, &f, &dr, &dw);
+    // d (f p) / d p = f I + (df/dr) p p^T / r
+    const double k = r > 0.0 ? dr / r : 0.0;
+    const double a00 = f + k * px * px, a01 = k * px * py, a11 = f + k * py * py;
+    // d p / d P = [[iz, 0, -px iz], [0, iz, -py iz]]
+    d(0, 0) = fx * a00 * iz; d(0, 1) = fx * a01 * iz; d(0, 2) = -fx * (a00 * px + a01 * py) * iz;
+    d(1, 0) = fy * a01 * iz; d(1, 1) = fy * a11 * iz; d(1, 2) = -fy * (a01 * px + a11 * py) * iz;
     return d;
   }
   // Transfer3d(T_ba, ray, rho) = Project(R ray + rho t)
@@ -266,32 +321,73 @@ struct Pinhole {
     J(0, 3) = b[0]; J(1, 3) = b[1];
     return J;
   }
-  // Unproject(pix): the ray with z = 1 (LinearCamera); dUnproject_dparams, dProject_dparams over
-  // the parameter vector (fx, fy, u0, v0)
+  // Unproject(pix): the ray with z = 1
   Vec3 Unproject(const Vec2& pix) const {
     Vec3 r;
     r[0] = (pix[0] - u0) / fx; r[1] = (pix[1] - v0) / fy; r[2] = 1.0;
+    if (model == 1) {
+      double g, dr, dw;
+      FactorInv(std::sqrt(r[0] * r[0] + r[1] * r[1]), &g, &dr, &dw);
+      r[0] *= g; r[1] *= g;
+    }
     return r;
   }
+  // d Unproject(pix).xy / d params (2 x 5; column 4 is zero for the pinhole)
+  Mat<2, 5> dUnproject_dparams(const Vec2& pix) const {
+    const double dx = (pix[0] - u0) / fx, dy = (pix[1] - v0) / fy;
+    double g = 1.0, dg_dr = 0.0, dg_dw = 0.0;
+    const double rd = std::sqrt(dx * dx + dy * dy);
+    if (model == 1) FactorInv(rd, &g, &dg_dr, &dg_dw);
+    // d ray.xy / d d = g I + (dg/dr) d d^T / rd
+    const double k = rd > 0.0 ? dg_dr / rd : 0.0;
+    const double a00 = g + k * dx * dx, a01 = k * dx * dy, a11 = g + k * dy * dy;
+    Mat<2, 5> J;
+    J(0, 0) = a00 * (-dx / fx); J(1, 0) = a01 * (-dx / fx);
+    J(0, 1) = a01 * (-dy / fy); J(1, 1) = a11 * (-dy / fy);
+    J(0, 2) = a00 * (-1.0 / fx); J(1, 2) = a01 * (-1.0 / fx);
+    J(0, 3) = a01 * (-1.0 / fy); J(1, 3) = a11 * (-1.0 / fy);
+    J(0, 4) = dx * dg_dw; J(1, 4) = dy * dg_dw;
+    return J;
+  }
+  // d Project(P) / d params at a fixed point (2 x 5)
+  Mat<2, 5> dProject_dparams(const Vec3& P) const {
+    const double px = P[0] / P[2], py = P[1] / P[2];
+    double f, dr, dw;
+    Factor(std::sqrt(px * px + py * py), &f, &dr, &dw);
+    Mat<2, 5> J;
+    J(0, 0) = f * px; J(1, 1) = f * py;
+    J(0, 2) = 1.0; J(1, 3) = 1.0;
+    J(0, 4) = fx * px * dw; J(1, 4) = fy * py * dw;
+    return J;
+  }
   // dTransfer_dparams(T_ba, pix, rho) = d/dparams Project(R Unproject(pix) + rho t): both the
-  // un-projection and the projection depend on the parameters (2x4).  Call site
-  // parallel_algos.h:115-118; Calibu is absent from the reference tree — reconstructed as the
+  // un-projection and the projection depend on the parameters (2 x NumParams, held as 2 x 5).  Call
+  // site parallel_algos.h:115-118; Calibu is absent from the reference tree — reconstructed as the
   // derivative of the function the call site names, pinned by finite differences of that function.
-  Mat<2, 4> dTransfer_dparams(const SE3& t_ba, const Vec2& pix, double rho) const {
+  Mat<2, 5> dTransfer_dparams(const SE3& t_ba, const Vec2& pix, double rho) const {
     const Vec3 ray = Unproject(pix);
     const Vec3 P = t_ba.so3() * ray + t_ba.translation() * rho;
     const Mat<2, 3> dp = dProject_dP(P);
     const Mat3 R = t_ba.so3().matrix();
-    Mat<2, 4> J;
-    const double dx_dfx = -(pix[0] - u0) / (fx * fx), dy_dfy = -(pix[1] - v0) / (fy * fy);
-    for (int r = 0; r < 2; ++r) {
-      double c0 = 0, c1 = 0;  // dp * R column 0 / column 1
-      for (int k = 0; k < 3; ++k) { c0 += dp(r, k) * R(k, 0); c1 += dp(r, k) * R(k, 1); }
-      J(r, 0) = c0 * dx_dfx; J(r, 1) = c1 * dy_dfy;
-      J(r, 2) = c0 * (-1.0 / fx); J(r, 3) = c1 * (-1.0 / fy);
+    Mat<2, 5> J;
+    if (model != 1) {  // the pinhole expressions of the earlier rounds, operation for operation
+      const double dx_dfx = -(pix[0] - u0) / (fx * fx), dy_dfy = -(pix[1] - v0) / (fy * fy);
+      for (int r = 0; r < 2; ++r) {
+        double c0 = 0, c1 = 0;  // dp * R column 0 / column 1
+        for (int k = 0; k < 3; ++k) { c0 += dp(r, k) * R(k, 0); c1 += dp(r, k) * R(k, 1); }
+        J(r, 0) = c0 * dx_dfx; J(r, 1) = c1 * dy_dfy;
+        J(r, 2) = c0 * (-1.0 / fx); J(r, 3) = c1 * (-1.0 / fy);
+      }
+      J(0, 0) += P[0] / P[2]; J(1, 1) += P[1] / P[2];
+      J(0, 2) += 1.0; J(1, 3) += 1.0;
+      return J;
     }
-    J(0, 0) += P[0] / P[2]; J(1, 1) += P[1] / P[2];
-    J(0, 2) += 1.0; J(1, 3) += 1.0;
+    const Mat<2, 5> du = dUnproject_dparams(pix), dq = dProject_dparams(P);
+    for (int r = 0; r < 2; ++r) {
+      double c0 = 0, c1 = 0;
+      for (int k = 0; k < 3; ++k) { c0 += dp(r, k) * R(k, 0); c1 += dp(r, k) * R(k, 1); }
+      for (int c = 0; c < 5; ++c) J(r, c) = dq(r, c) + (c0 * du(0, c) + c1 * du(1, c));
+    }
     return J;
   }
 };

@@ -88,6 +88,7 @@ def lib():
                      "orc_num_lm_params", "orc_num_calib_params"):
             getattr(L, name).restype = C.c_uint32
         L.orc_landmark_outlier_ratio.restype = C.c_double
+        L.orc_get_camera_fov.restype = C.c_double
     return _lib
 
 
@@ -133,8 +134,13 @@ class OracleBundleAdjuster:
         self.L.orc_set_gravity(self.h, _dp(g))
 
     def AddCamera(self, params, t_vs=(0, 0, 0, 0, 0, 0, 1)):
+        """params (fx, fy, u0, v0): calibu::LinearCamera; (fx, fy, u0, v0, w): calibu::FovCamera."""
         p, t = _d(params), _d(t_vs)
-        return self.L.orc_add_camera(self.h, _dp(p), _dp(t))
+        n = self.L.orc_add_camera(self.h, _dp(p[:4].copy()), _dp(t))
+        if p.size == 5:
+            self.L.orc_set_camera_fov(self.h, n - 1, C.c_double(p[4]))
+        self._cam_fov = getattr(self, "_cam_fov", []) + [p.size == 5]
+        return n
 
     def AddPose(self, t_wp, is_active=True, time=-1.0, v_w=(0, 0, 0), b=(0,) * 6):
         t, v, bb = _d(t_wp), _d(v_w), _d(b)
@@ -234,7 +240,14 @@ class OracleBundleAdjuster:
         return ids
 
     # -- solve + results ---------------------------------------------------
+    def _check_calib_camera(self):
+        # parallel_algos.h:115-118 assigns dTransfer_dparams (2 x NumParams) to a 2 x CalibSize block
+        if self.calib_size and (not getattr(self, "_cam_fov", [])
+                                or (5 if self._cam_fov[0] else 4) != self.calib_size):
+            raise ValueError("CalibSize %d needs camera 0 with that many parameters" % self.calib_size)
+
     def Solve(self, max_iter, gn_damping=1.0, error_increase_allowed=False):
+        self._check_calib_camera()
         self.L.orc_solve(self.h, int(max_iter), C.c_double(gn_damping),
                          int(error_increase_allowed))
 
@@ -298,6 +311,8 @@ class OracleBundleAdjuster:
     def camera_params(self, cam_id=0):
         p = np.empty(4)
         self.L.orc_get_camera_params(self.h, int(cam_id), _dp(p))
+        if getattr(self, "_cam_fov", [])[cam_id:cam_id + 1] == [True]:
+            p = np.append(p, self.L.orc_get_camera_fov(self.h, int(cam_id)))
         return p
 
     def proj_calib_jacobians(self):
@@ -446,7 +461,17 @@ def integrate(pose_t, v, meas, bg, ba, g, r6=None, jac=False):
 
 
 def transfer(params, t_ba, pix, rho, jac=False):
-    """Pinhole Transfer(T_ba, pix, rho) and (jac) its 2x4 Jacobian w.r.t. (fx, fy, u0, v0)."""
-    p, t, x, out, J = _d(params), _d(t_ba), _d(pix), np.empty(2), np.empty((2, 4))
-    lib().orc_math_transfer(_dp(p), _dp(t), _dp(x), C.c_double(rho), _dp(out), _dp(J) if jac else None)
+    """Transfer(T_ba, pix, rho) and (jac) its Jacobian w.r.t. the camera parameters: 2x4 for the
+    pinhole (fx, fy, u0, v0), 2x5 for the FOV camera (fx, fy, u0, v0, w)."""
+    p, t, x, out = _d(params), _d(t_ba), _d(pix), np.empty(2)
+    J = np.empty((2, p.size))
+    fn = lib().orc_math_transfer_fov if p.size == 5 else lib().orc_math_transfer
+    fn(_dp(p), _dp(t), _dp(x), C.c_double(rho), _dp(out), _dp(J) if jac else None)
     return (out, J) if jac else out
+
+
+def fov_project(params5, P):
+    """FOV camera: Project(P), its 2x3 derivative over P, and Unproject(Project(P)) (the z = 1 ray)."""
+    p, X, pix, d, ray = _d(params5), _d(P), np.empty(2), np.empty((2, 3)), np.empty(3)
+    lib().orc_math_fov_project(_dp(p), _dp(X), _dp(pix), _dp(d), _dp(ray))
+    return pix, d, ray

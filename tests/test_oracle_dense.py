@@ -153,17 +153,20 @@ def _calib_oracle(po, sc, t_vs, pose_active, do_tvs=True, calib_size=0, **opts):
     return ba
 
 
-@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics", "fov"])
 @pytest.mark.parametrize("triangular", [1, 0])
 def test_calibration_border_matches_dense_algebra(oracle_lib, triangular, kind):
     """DoTvs / CalibSize: the (n + K)^2 system of BundleAdjuster.cpp:493-583 equals the Schur complement
     of the dense normal equations over [poses | calibration | landmarks] built from the same Jacobians."""
     po = oracle_lib
     sc = scene.mount_camera(scene.make_scene(30, 60, 5, lm_dim=1, seed=7), T_VS_MOUNT)
+    if kind == "fov":
+        scene.to_fov_camera(sc, 0.93)
     P = sc.num_poses
     pose_active = np.ones(P, dtype=bool)
     pose_active[[0, 3, 4, 15, 17]] = False
-    ba = _calib_oracle(po, sc, T_VS_MOUNT, pose_active, do_tvs=kind == "tvs", calib_size=0 if kind == "tvs" else 4,
+    ba = _calib_oracle(po, sc, T_VS_MOUNT, pose_active, do_tvs=kind == "tvs",
+                       calib_size={"tvs": 0, "intrinsics": 4, "fov": 5}[kind],
                        apply_results=0, use_triangular_matrices=triangular)
     ba.Solve(1)
     jm, jr, jl = ba.proj_jacobians()
@@ -204,10 +207,10 @@ def test_calibration_border_matches_dense_algebra(oracle_lib, triangular, kind):
     assert np.abs(So[:n, n:]).max() > 0.1 and np.abs(So[n:, n:]).max() > 0.1
     assert rel_err(ba.rhs(), rhs) < 1e-10
     assert rel_err(ba.rhs_k(), g[n:m]) < 1e-11
-    assert np.linalg.cond(S) < 1e12
+    assert np.linalg.cond(S) < (1e15 if kind == "fov" else 1e12)   # w is in radians, the rest in pixels
     d = np.linalg.solve(S, rhs)
-    assert rel_err(ba.delta_p(), d[:n]) < 1e-7
-    assert rel_err(ba.delta_k(), d[n:]) < 1e-7
+    assert rel_err(ba.delta_p(), d[:n]) < (1e-5 if kind == "fov" else 1e-7)
+    assert rel_err(ba.delta_k(), d[n:]) < (1e-5 if kind == "fov" else 1e-7)
     dl = Vi @ (g[m:] - H[m:, :m] @ d)
     assert rel_err(ba.delta_l(), dl) < 1e-7
 
@@ -237,17 +240,21 @@ def test_extrinsics_are_recovered(oracle_lib, dogleg):
     assert errs[-1] < 0.5 * errs[0]
 
 
+@pytest.mark.parametrize("fov", [False, True])
 @pytest.mark.parametrize("dogleg", [0, 1])
-def test_intrinsics_are_recovered(oracle_lib, dogleg):
-    """CalibSize = 4: wrong pinhole parameters converge to the ones the scene was rendered with
-    (ApplyUpdate, BundleAdjuster.cpp:46-69: params -= delta_k, every x_s ray re-derived from z_ref)."""
+def test_intrinsics_are_recovered(oracle_lib, dogleg, fov):
+    """CalibSize = 4 / 5: wrong pinhole / FOV-camera parameters converge to the ones the scene was
+    rendered with (ApplyUpdate, BundleAdjuster.cpp:46-69: params -= delta_k, every x_s ray re-derived
+    from z_ref)."""
     po = oracle_lib
     sc = scene.make_scene(40, 160, 8, lm_dim=1, seed=2, outlier_frac=0.0, pixel_sigma=0.3, roll_amp=0.6)
     pose_active = np.ones(sc.num_poses, dtype=bool)
     pose_active[::3] = False
     sc.poses[::3] = sc.gt_poses[::3]
-    wrong = np.asarray(sc.cam_params) * np.array([1.03, 0.97, 1.02, 0.98])
-    ba = po.OracleBundleAdjuster(1, 6, calib_size=4)
+    if fov:
+        scene.to_fov_camera(sc, 0.93)
+    wrong = np.asarray(sc.cam_params) * np.array([1.03, 0.97, 1.02, 0.98, 1.04][:len(sc.cam_params)])
+    ba = po.OracleBundleAdjuster(1, 6, calib_size=len(sc.cam_params))
     ba.Init(gn_options(po, use_dogleg=dogleg))
     ba.AddCamera(wrong)
     ba.add_poses(sc.poses, is_active=pose_active.astype(np.uint8))

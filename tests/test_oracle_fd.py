@@ -192,13 +192,64 @@ def test_transfer_parameter_jacobian(oracle_lib):
     assert np.abs(J).max() < 1e-12
 
 
-def test_projection_intrinsics_jacobian_in_place(oracle_lib):
+def test_fov_camera_model(oracle_lib):
+    """The FOV camera of the CalibSize = 5 instantiations (calibu::FovCamera; BundleAdjuster.h:758-759)
+    as the published model states it: r_d = atan(2 r_u tan(w/2)) / w.  Project against that formula,
+    Unproject as its inverse, dProject_dP and the 2x5 dTransfer_dparams against central differences —
+    including the small-radius and small-w limits."""
+    po = oracle_lib
+    rng = np.random.default_rng(1)
+    for w in (0.93, 0.4, 1.3, 1e-4):
+        params = np.array([198.969, 198.1284, 329.9368, 240.1017, w])
+        for it in range(30):
+            P = np.array([rng.normal(0, 1.0), rng.normal(0, 0.8), rng.uniform(0.5, 6.0)])
+            if it == 0:
+                P[:2] = 1e-4 * P[2]  # inside the small-radius branch
+            pix, d, ray = po.fov_project(params, P)
+            p = P[:2] / P[2]
+            ru = np.linalg.norm(p)
+            if w * w > 1e-5 and ru * ru >= 1e-5:
+                rd = np.arctan(2 * ru * np.tan(w / 2)) / w
+                assert np.allclose(pix, params[:2] * (rd / ru) * p + params[2:4], rtol=1e-13, atol=1e-10)
+            elif w * w <= 1e-5:
+                assert np.allclose(pix, params[:2] * p + params[2:4], rtol=1e-13)
+            assert np.allclose(ray, [p[0], p[1], 1.0], rtol=1e-9, atol=1e-9 if ru * ru >= 1e-5 else 1e-7)
+            fd = np.zeros((2, 3))
+            for j in range(3):
+                e = np.zeros(3)
+                e[j] = 1e-6
+                fd[:, j] = (po.fov_project(params, P + e)[0] - po.fov_project(params, P - e)[0]) / 2e-6
+            assert np.linalg.norm(d - fd) < 1e-5 * max(1.0, np.abs(d).max()), (w, P)
+    params = np.array([500.0, 480.0, 320.0, 240.0, 0.9])
+    for it in range(40):
+        t = np.concatenate([rng.normal(0, 0.5, 3), po.so3_exp(rng.normal(0, 0.3, 3))])
+        pix = np.array([rng.uniform(120, 520), rng.uniform(80, 400)])
+        if it == 0:
+            pix = params[2:4] + 0.1  # distorted radius inside the small-radius branch
+        rho = rng.uniform(0.05, 0.5)
+        _, J = po.transfer(params, t, pix, rho, jac=True)
+        assert J.shape == (2, 5)
+        fd = np.zeros((2, 5))
+        for j in range(5):
+            e = np.zeros(5)
+            e[j] = 1e-4 if j < 4 else 1e-6
+            fd[:, j] = (po.transfer(params + e, t, pix, rho) - po.transfer(params - e, t, pix, rho)) / (2 * e[j])
+        assert np.linalg.norm(J - fd) < NORM_THRESHOLD * max(1.0, np.abs(J).max()), (it, J, fd)
+    _, J = po.transfer(params, np.array([0, 0, 0, 0, 0, 0, 1.0]), np.array([100.0, 50.0]), 0.3, jac=True)
+    assert np.abs(J).max() < 1e-10
+
+
+@pytest.mark.parametrize("fov", [False, True])
+def test_projection_intrinsics_jacobian_in_place(oracle_lib, fov):
     """dz_dcam_params of the CalibSize instantiations is -dTransfer_dparams(T_sw_m T_ws_r, z_ref,
     x_s(3)) — evaluated at the reference PIXEL with the inverse depth of the unit-length ray
     (parallel_algos.h:115-118 as written, not the derivative of the residual itself)."""
     po = oracle_lib
     sc = scene.make_scene(24, 12, 4, lm_dim=1, seed=8)
-    ba = po.OracleBundleAdjuster(1, 6, calib_size=4)
+    if fov:
+        scene.to_fov_camera(sc, 0.93)
+    K = 5 if fov else 4
+    ba = po.OracleBundleAdjuster(1, 6, calib_size=K)
     o = po.default_options()
     o.use_dogleg = 0
     o.apply_results = 0
@@ -209,7 +260,7 @@ def test_projection_intrinsics_jacobian_in_place(oracle_lib):
     ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
     ba.Solve(1)
     jk = ba.proj_calib_jacobians()
-    assert jk.shape[1:] == (2, 4) and np.abs(jk).max() > 0.1
+    assert jk.shape[1:] == (2, K) and np.abs(jk).max() > 0.1
     acc = accepted_obs(sc)
     nsel = sc.obs_per_landmark + 1
     for rid, (m, r, l) in enumerate(acc):
