@@ -9,6 +9,9 @@
 //                                           parameters that are 2-3 % off; a third of the poses held fixed
 //   visual_ba_demo --calibrate-extrinsics   ba::BundleAdjuster<double, 1, 6, 0, true>  starting from a camera
 //                                           mount T_vs that is a few centimetres / half a degree off
+//   visual_ba_demo --calibrate-fov          ba::SelfCalBundleAdjuster<double> = <double, 1, 6, 5> (reference
+//                                           BundleAdjuster.h:758-759) on a ba::FovCamera whose five parameters
+//                                           (fx, fy, u0, v0, w) start 2-4 % off
 #include <ba/BundleAdjuster.h>
 
 #include <cmath>
@@ -17,19 +20,22 @@
 #include <random>
 
 template <class BA>
-int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics
+int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics, 3 the five parameters of a FOV camera
   BA adjuster;
   ba::Options<double> options;  // reference defaults: dogleg, robust norm, auto regularisation
   options.error_change_threshold = 1e-5;
   const int kPoses = 24, kLandmarks = 300;
   adjuster.Init(options, kPoses, kLandmarks * 6, kLandmarks);
-  const double fx = 198.969, fy = 198.1284, u0 = 329.9368, v0 = 240.1017;
+  const double fx = 198.969, fy = 198.1284, u0 = 329.9368, v0 = 240.1017, fov_w = 0.93;
   ba::SE3 mount0;  // the true mount is the identity
   if (calibrate == 2) {
     const double t[3] = {0.03, -0.02, 0.02}, q[4] = {0.004, -0.005, 0.003, 1.0};
     mount0 = ba::SE3(t, q);
   }
-  if (calibrate == 1)
+  const ba::FovCamera<double> true_fov(fx, fy, u0, v0, fov_w);
+  if (calibrate == 3)
+    adjuster.AddCamera(std::make_shared<ba::FovCamera<double>>(fx * 1.03, fy * 0.97, u0 * 1.02, v0 * 0.98, fov_w * 1.04, mount0));
+  else if (calibrate == 1)
     adjuster.AddCamera(std::make_shared<ba::CameraInterface<double>>(fx * 1.03, fy * 0.97, u0 * 1.02, v0 * 0.98, mount0));
   else
     adjuster.AddCamera(std::make_shared<ba::CameraInterface<double>>(fx, fy, u0, v0, mount0));
@@ -83,6 +89,10 @@ int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics
     double d[3] = {X[0] - T.t[0], X[1] - T.t[1], X[2] - T.t[2]}, p[3];
     for (int r = 0; r < 3; ++r) p[r] = R(0, r) * d[0] + R(1, r) * d[1] + R(2, r) * d[2];  // R^T d
     uv[0] = fx * p[0] / p[2] + u0; uv[1] = fy * p[1] / p[2] + v0;
+    if (calibrate == 3) {  // the scene is seen through the FOV camera
+      const ba::Vector2t d = true_fov.Project(ba::Vector3t({p[0], p[1], p[2]}));
+      uv[0] = d[0]; uv[1] = d[1];
+    }
     return p[2] > 0.5 && uv[0] > 0 && uv[0] < 640 && uv[1] > 0 && uv[1] < 480;
   };
   for (int i = 0; i < kPoses; ++i) {
@@ -142,6 +152,13 @@ int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics
     ok = ok && std::fabs(p[0] - fx) < 0.01 * fx && std::fabs(p[1] - fy) < 0.01 * fy && std::fabs(p[2] - u0) < 0.01 * u0 &&
          std::fabs(p[3] - v0) < 0.01 * v0;
   }
+  if (calibrate == 3) {
+    const std::vector<double> p = adjuster.rig()->cameras_[0]->ParamsVector();
+    std::printf("camera parameters %.3f %.3f %.3f %.3f %.4f (true %.3f %.3f %.3f %.3f %.4f)\n", p[0], p[1], p[2], p[3], p[4],
+                fx, fy, u0, v0, fov_w);
+    ok = ok && p.size() == 5 && std::fabs(p[0] - fx) < 0.01 * fx && std::fabs(p[1] - fy) < 0.01 * fy &&
+         std::fabs(p[2] - u0) < 0.01 * u0 && std::fabs(p[3] - v0) < 0.01 * v0 && std::fabs(p[4] - fov_w) < 0.01 * fov_w;
+  }
   if (calibrate == 2) {
     const ba::SE3 m = adjuster.rig()->cameras_[0]->Pose();
     std::printf("camera mount t = %.4f %.4f %.4f  q = %.5f %.5f %.5f %.5f (true: identity)\n", m.t[0], m.t[1], m.t[2], m.q[0],
@@ -155,5 +172,6 @@ int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics
 int main(int argc, char** argv) {
   if (argc > 1 && std::strcmp(argv[1], "--calibrate-intrinsics") == 0) return run<ba::BundleAdjuster<double, 1, 6, 4, false>>(1);
   if (argc > 1 && std::strcmp(argv[1], "--calibrate-extrinsics") == 0) return run<ba::BundleAdjuster<double, 1, 6, 0, true>>(2);
+  if (argc > 1 && std::strcmp(argv[1], "--calibrate-fov") == 0) return run<ba::SelfCalBundleAdjuster<double>>(3);
   return run<ba::BundleAdjuster<double, 1, 6, 0>>(0);  // VisualBundleAdjuster<double>
 }

@@ -67,6 +67,7 @@ SYMBOLS = [
     "ba_adjuster_get_summary", "ba_adjuster_get_cond_errors", "ba_adjuster_get_timers", "ba_adjuster_engine",
     "ba_adjuster_set_allreduce", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
     "ba_adjuster_get_last_calib_step", "ba_adjuster_get_calibration_marginals", "ba_adjuster_get_camera_params",
+    "ba_adjuster_add_camera_fov", "ba_adjuster_get_camera_fov",
 ]
 
 _lib = None
@@ -84,6 +85,7 @@ def lib():
         L.ba_adjuster_create_calib.restype = C.c_void_p
         L.ba_adjuster_engine.restype = C.c_void_p
         L.ba_adjuster_landmark_outlier_ratio.restype = C.c_double
+        L.ba_adjuster_get_camera_fov.restype = C.c_double
         for n in ("ba_adjuster_add_camera", "ba_adjuster_add_pose", "ba_adjuster_add_landmark",
                   "ba_adjuster_add_projection_residual", "ba_adjuster_add_unary_constraint",
                   "ba_adjuster_add_binary_constraint", "ba_adjuster_add_imu_residual",
@@ -149,7 +151,11 @@ class BundleAdjuster:
         self.L.ba_adjuster_set_gravity(self.h, _p(g, dp))
 
     def AddCamera(self, params, t_vs=(0, 0, 0, 0, 0, 0, 1)):
+        """params (fx, fy, u0, v0): calibu::LinearCamera; (fx, fy, u0, v0, w): calibu::FovCamera."""
         p, t = _d(params), _d(t_vs)
+        self._cam_fov = getattr(self, "_cam_fov", []) + [p.size == 5]
+        if p.size == 5:
+            return self.L.ba_adjuster_add_camera_fov(self.h, _p(p, dp), _p(t, dp))
         return self.L.ba_adjuster_add_camera(self.h, _p(p, dp), _p(t, dp))
 
     def AddPose(self, t_wp, is_active=True, time=-1.0, v_w=(0, 0, 0), b=(0,) * 6):
@@ -357,6 +363,8 @@ class BundleAdjuster:
         """rig()->cameras_[cam_id]->GetParams()"""
         p = np.empty(4)
         self.L.ba_adjuster_get_camera_params(self.h, int(cam_id), p.ctypes.data_as(C.POINTER(C.c_double)))
+        if getattr(self, "_cam_fov", [])[cam_id:cam_id + 1] == [True]:
+            p = np.append(p, self.L.ba_adjuster_get_camera_fov(self.h, int(cam_id)))
         return p
 
     def proj_calib_jacobians(self):

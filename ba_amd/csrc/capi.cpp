@@ -12,6 +12,8 @@ struct Iface {
   virtual void init(const ba_options* o) = 0;
   virtual void set_gravity(const double* g) = 0;
   virtual uint32_t add_camera(const double* p, const double* t) = 0;
+  virtual uint32_t add_camera_fov(const double* p5, const double* t) = 0;
+  virtual double camera_fov(uint32_t cam) const = 0;
   virtual uint32_t add_pose(const double* t, const double* v, const double* b, int act, double time) = 0;
   virtual int set_pose_cam_params(uint32_t n, const double* params4) = 0;
   virtual void set_cov_once(int on) = 0;
@@ -75,6 +77,10 @@ struct Impl : Iface {
   uint32_t add_camera(const double* p, const double* t) override {
     return ba.AddCamera(std::make_shared<ba::CameraInterface<double>>(p[0], p[1], p[2], p[3], ba::SE3::from7(t)));
   }
+  uint32_t add_camera_fov(const double* p, const double* t) override {
+    return ba.AddCamera(std::make_shared<ba::FovCamera<double>>(p[0], p[1], p[2], p[3], p[4], ba::SE3::from7(t)));
+  }
+  double camera_fov(uint32_t cam) const override { return ba.rig()->cameras_[cam]->Param(4); }
   void set_imu_noise(const double* r6, const double* rb6) override {
     auto calib = ba.GetImuCalibration();
     for (int i = 0; i < 6; ++i) { calib.r[i] = r6[i]; calib.r_b[i] = rb6[i]; }
@@ -199,6 +205,11 @@ Iface* make(int lm, int pd, int do_tvs, int calib_size) {
     if (pd == 9) return new Impl<1, 9, false, 4>();
     if (pd == 15) return new Impl<1, 15, false, 4>();
   }
+  // CalibSize 5 = the parameters of a FovCamera 0 (reference BundleAdjuster.cpp:1816, 1822: <1,6,5>, <1,15,5>)
+  if (calib_size == 5 && !do_tvs && lm == 1) {
+    if (pd == 6) return new Impl<1, 6, false, 5>();
+    if (pd == 15) return new Impl<1, 15, false, 5>();
+  }
   if (calib_size != 0) return nullptr;
 #define CASE(L, P) if (lm == L && pd == P && !do_tvs) return new Impl<L, P>()
   CASE(0, 6); CASE(0, 9); CASE(0, 15); CASE(1, 6); CASE(1, 9); CASE(1, 15);
@@ -250,6 +261,8 @@ void ba_adjuster_destroy(ba_adjuster* a) { if (a) { delete a->p; delete a; } }
 void ba_adjuster_init(ba_adjuster* a, const ba_options* o) { a->p->init(o); }
 void ba_adjuster_set_gravity(ba_adjuster* a, const double g[3]) { a->p->set_gravity(g); }
 uint32_t ba_adjuster_add_camera(ba_adjuster* a, const double params[4], const double t_vs[7]) { return a->p->add_camera(params, t_vs); }
+uint32_t ba_adjuster_add_camera_fov(ba_adjuster* a, const double params[5], const double t_vs[7]) { return a->p->add_camera_fov(params, t_vs); }
+double ba_adjuster_get_camera_fov(const ba_adjuster* a, uint32_t cam_id) { return a->p->camera_fov(cam_id); }
 uint32_t ba_adjuster_add_pose(ba_adjuster* a, const double t_wp[7], const double v_w[3], const double b[6], int is_active, double time) {
   return a->p->add_pose(t_wp, v_w, b, is_active, time);
 }

@@ -131,18 +131,83 @@ BA_HD Rt inverse(const Rt& a) {
   return c;
 }
 
-struct Cam { double fx, fy, u0, v0; };
+// Camera model: calibu::LinearCamera (model 0: fx, fy, u0, v0) or calibu::FovCamera (model 1: + w, the
+// five parameters of the reference's CalibSize = 5 instantiations, BundleAdjuster.cpp:1816-1826).  Calibu
+// is not in the reference tree: the FOV model is the published one (Devernay & Faugeras 2001,
+// r_d = atan(2 r_u tan(w/2)) / w) applied as a factor on the normalised point, with its limits for a
+// vanishing radius / vanishing w — the same restatement as oracle/outils.h, operation for operation.
+// Kernels built for pinhole-only rigs construct Cam with model = 0 as a literal: the FOV branches fold away.
+struct Cam { double fx, fy, u0, v0, w; int model; };
+constexpr double kFovSmall = 1e-5;
+
+// distortion factor f = r_d / r_u with df/dr, df/dw;  inverse factor g = r_u / r_d with dg/dr, dg/dw
+BA_HD void fov_factor(double w, double r, double* f, double* df_dr, double* df_dw) {
+  *f = 1.0; *df_dr = 0.0; *df_dw = 0.0;
+  if (w * w <= kFovSmall) return;
+  const double th = tan(0.5 * w), m = 2.0 * th, dm = 1.0 + th * th;
+  if (r * r < kFovSmall) {
+    *f = m / w;
+    *df_dw = dm / w - m / (w * w);
+    return;
+  }
+  const double at = atan(r * m), den = 1.0 + r * r * m * m;
+  *f = at / (r * w);
+  *df_dr = m / (den * r * w) - at / (r * r * w);
+  *df_dw = dm / (den * w) - at / (r * w * w);
+}
+BA_HD void fov_factor_inv(double w, double rd, double* g, double* dg_dr, double* dg_dw) {
+  *g = 1.0; *dg_dr = 0.0; *dg_dw = 0.0;
+  if (w * w <= kFovSmall) return;
+  const double th = tan(0.5 * w), m = 2.0 * th, dm = 1.0 + th * th;
+  if (rd * rd < kFovSmall) {
+    *g = w / m;
+    *dg_dw = 1.0 / m - w * dm / (m * m);
+    return;
+  }
+  const double tn = tan(rd * w), sec2 = 1.0 + tn * tn;
+  *g = tn / (rd * m);
+  *dg_dr = w * sec2 / (rd * m) - tn / (rd * rd * m);
+  *dg_dw = sec2 / m - tn * dm / (rd * m * m);
+}
 
 // pi(P) and its 2x3 derivative rows (d0 = d u/dP, d1 = d v/dP)
 BA_HD void project(const Cam& c, V3 P, double* u, double* v) {
   const double iz = 1.0 / P.z;
+  if (c.model == 1) {
+    const double px = P.x / P.z, py = P.y / P.z;
+    double f, dr, dw;
+    fov_factor(c.w, sqrt(px * px + py * py), &f, &dr, &dw);
+    *u = c.fx * (f * px) + c.u0;
+    *v = c.fy * (f * py) + c.v0;
+    return;
+  }
   *u = c.fx * P.x * iz + c.u0;
   *v = c.fy * P.y * iz + c.v0;
 }
 BA_HD void dproject(const Cam& c, V3 P, V3* d0, V3* d1) {
   const double iz = 1.0 / P.z;
+  if (c.model == 1) {
+    const double px = P.x * iz, py = P.y * iz, r = sqrt(px * px + py * py);
+    double f, dr, dw;
+    fov_factor(c.w, r, &f, &dr, &dw);
+    const double k = r > 0.0 ? dr / r : 0.0;  // d (f p) / d p = f I + (df/dr) p p^T / r
+    const double a00 = f + k * px * px, a01 = k * px * py, a11 = f + k * py * py;
+    *d0 = v3(c.fx * a00 * iz, c.fx * a01 * iz, -c.fx * (a00 * px + a01 * py) * iz);
+    *d1 = v3(c.fy * a01 * iz, c.fy * a11 * iz, -c.fy * (a01 * px + a11 * py) * iz);
+    return;
+  }
   *d0 = v3(c.fx * iz, 0.0, -c.fx * P.x * iz * iz);
   *d1 = v3(0.0, c.fy * iz, -c.fy * P.y * iz * iz);
+}
+// Unproject(pix): the ray with z = 1
+BA_HD V3 unproject(const Cam& c, double u, double v) {
+  double x = (u - c.u0) / c.fx, y = (v - c.v0) / c.fy;
+  if (c.model == 1) {
+    double g, dr, dw;
+    fov_factor_inv(c.w, sqrt(x * x + y * y), &g, &dr, &dw);
+    x *= g; y *= g;
+  }
+  return v3(x, y, 1.0);
 }
 
 // One projection residual with its Jacobians.
@@ -309,22 +374,45 @@ BA_HD void proj_linearize(const Cam& cam, const double* z, const double* x, cons
 
 // dz_dcam_params (CalibSize instantiations, LM == 1; parallel_algos.h:114-118):
 //   -dTransfer_dparams(T_sw_m T_ws_r, z_ref, rho),  Transfer(T, pix, rho) = Project(R Unproject(pix) + rho t),
-// over the pinhole parameters (fx, fy, u0, v0) — both the un-projection of the reference pixel and the
-// projection depend on them.  The ray is Unproject(z_ref) (z = 1), NOT the landmark's x_s ray, paired
+// over the camera parameters (pinhole: fx, fy, u0, v0; FOV camera: + w) — both the un-projection of the
+// reference pixel and the projection depend on them.  The ray is Unproject(z_ref) (z = 1), NOT the landmark's x_s ray, paired
 // with the landmark's rho as it stands: the reference's call, kept as written.
-// jk: two rows of six (columns 4, 5 zero).
+// jk: two rows of six (pinhole: columns 4, 5 zero; FOV camera: column 5 zero).
 BA_HD void proj_intrinsics_rows(const Cam& cam, const double* z_ref, double rho, const Rt& t_sw_m, const Rt& t_ws_r,
                                 double keep, double* jk) {
-  const V3 ray = v3((z_ref[0] - cam.u0) / cam.fx, (z_ref[1] - cam.v0) / cam.fy, 1.0);
+  const V3 ray = unproject(cam, z_ref[0], z_ref[1]);
   const V3 P = mul(t_sw_m.R, mul(t_ws_r.R, ray) + t_ws_r.t * rho) + t_sw_m.t * rho;
   V3 d0, d1;
   dproject(cam, P, &d0, &d1);
   // columns 0 and 1 of R_T = R_sw_m R_ws_r
   const V3 c0 = mul(t_sw_m.R, v3(t_ws_r.R.m[0], t_ws_r.R.m[3], t_ws_r.R.m[6]));
   const V3 c1 = mul(t_sw_m.R, v3(t_ws_r.R.m[1], t_ws_r.R.m[4], t_ws_r.R.m[7]));
-  const double dx_dfx = -ray.x / cam.fx, dy_dfy = -ray.y / cam.fy;  // d ray / d fx = -(u - u0) / fx^2
   const double a00 = dot(d0, c0), a01 = dot(d0, c1), a10 = dot(d1, c0), a11 = dot(d1, c1);
   const double iz = 1.0 / P.z;
+  if (cam.model == 1) {
+    // FOV camera, five columns: dProject_dparams(P) + [dProject_dP R](:, 0:2) dUnproject_dparams(z_ref)
+    const double dx = (z_ref[0] - cam.u0) / cam.fx, dy = (z_ref[1] - cam.v0) / cam.fy;
+    const double rd = sqrt(dx * dx + dy * dy);
+    double g, dg_dr, dg_dw;
+    fov_factor_inv(cam.w, rd, &g, &dg_dr, &dg_dw);
+    const double k = rd > 0.0 ? dg_dr / rd : 0.0;
+    const double b00 = g + k * dx * dx, b01 = k * dx * dy, b11 = g + k * dy * dy;  // d ray.xy / d (dx, dy)
+    const double du0[5] = {b00 * (-dx / cam.fx), b01 * (-dy / cam.fy), b00 * (-1.0 / cam.fx), b01 * (-1.0 / cam.fy), dx * dg_dw};
+    const double du1[5] = {b01 * (-dx / cam.fx), b11 * (-dy / cam.fy), b01 * (-1.0 / cam.fx), b11 * (-1.0 / cam.fy), dy * dg_dw};
+    const double px = P.x / P.z, py = P.y / P.z;
+    double f, df_dr, df_dw;
+    fov_factor(cam.w, sqrt(px * px + py * py), &f, &df_dr, &df_dw);
+    const double dq0[5] = {f * px, 0.0, 1.0, 0.0, cam.fx * px * df_dw};
+    const double dq1[5] = {0.0, f * py, 0.0, 1.0, cam.fy * py * df_dw};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      jk[c] = -keep * (dq0[c] + (a00 * du0[c] + a01 * du1[c]));
+      jk[6 + c] = -keep * (dq1[c] + (a10 * du0[c] + a11 * du1[c]));
+    }
+    jk[5] = 0.0; jk[11] = 0.0;
+    return;
+  }
+  const double dx_dfx = -ray.x / cam.fx, dy_dfy = -ray.y / cam.fy;  // d ray / d fx = -(u - u0) / fx^2
   jk[0] = -keep * (a00 * dx_dfx + P.x * iz); jk[1] = -keep * (a01 * dy_dfy);
   jk[2] = -keep * (1.0 - a00 / cam.fx);      jk[3] = -keep * (-a01 / cam.fy);
   jk[4] = 0.0; jk[5] = 0.0;

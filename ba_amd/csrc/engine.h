@@ -33,6 +33,7 @@ struct DBuf {
 
 // Rigid transform in matrix form as stored on the device: R row-major (9) then t (3).
 static const int kRt = 12;
+static const int kCamRec = 37;  // camera record: params(4) | T_vs Rt(12) | T_sv Rt(12) | T_vs as t,q (7) | w | model
 // Pose state row: t(3) q(4) v(3) b(6)
 static const int kPoseState = 16;
 // one factor row: 6 doubles (see DESIGN.md "factor rows")
@@ -52,6 +53,8 @@ struct Engine {
   // (fx, fy, u0, v0) of camera 0 (CalibSize = 4; BundleAdjuster.cpp:46-69, parallel_algos.h:114-118)
   bool calib_tvs = false;
   std::vector<double> cam_params_prev;   // params_backup of SolveInternal (:1025-1028): restored by a rollback
+  std::vector<double> cam_w_prev;        // ... its fifth entry for a FOV camera
+  bool has_fov = false;                  // some camera of the rig is a FovCamera: the FOV kernel instantiations run
   DBuf<double> lm_zref;                  // [L][2] reference pixel of every landmark (LandmarkT::z_ref)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // bulk trailing updates of the factorisation (look-ahead)

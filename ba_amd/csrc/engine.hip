@@ -271,11 +271,16 @@ static int build_structure(Engine* e) {
   BAE_HIP(e->scal.alloc(std::max<size_t>(st.n_scalars, 2 * O1 + L1 * LM1 + 1)));  // last: the zero scalar
   BAE_HIP(hipMemsetAsync(e->scal.p, 0, e->scal.bytes(), e->stream));
   if (st.K && !e->calib_tvs) {
+    // parallel_algos.h:115-118 assigns dTransfer_dparams (2 x NumParams) to a 2 x CalibSize block
+    const int nparams = (!pb.cam_model.empty() && pb.cam_model[0] == 1) ? 5 : 4;
+    if ((int)st.K != nparams)
+      return e->fail_msg("CalibSize must equal the parameter count of camera 0 (LinearCamera 4, FovCamera 5)");
     if (pb.lm_zref.size() != 2 * (size_t)st.L)
       return e->fail_msg("intrinsics calibration needs the reference pixel of every landmark (ba_hip_set_landmark_ref_pixels)");
     if ((rc = upload(e, e->lm_zref, pb.lm_zref))) return rc;
   }
   e->cam_params_prev = pb.cam_params;
+  e->cam_w_prev = pb.cam_w;
   if (st.K) {
     BAE_HIP(e->crow.alloc((size_t)std::max<size_t>(st.n_scalars, 1) * kRow));
     BAE_HIP(hipMemsetAsync(e->crow.p, 0, e->crow.bytes(), e->stream));
@@ -347,15 +352,15 @@ int build_tile_order(Engine* e) {
   return 0;
 }
 
-// cameras: params(4) | T_vs Rt(12) | T_sv Rt(12) | T_vs as t,q (7); `cam` from the rig (prob.cam_tvs),
-// cam_eval (calibration only) from tvs_eval
+// cameras: params(4) | T_vs Rt(12) | T_sv Rt(12) | T_vs as t,q (7) | w | model (kCamRec doubles); `cam` from
+// the rig (prob.cam_tvs), cam_eval (calibration only) from tvs_eval
 int upload_cameras(Engine* e, bool eval_only) {
   const Problem& pb = e->prob;
   const uint32_t C = pb.num_cams;
   auto table = [&](const std::vector<double>& tvs) {
-    std::vector<double> cam((size_t)C * 35, 0.0);
+    std::vector<double> cam((size_t)C * kCamRec, 0.0);
     for (uint32_t c = 0; c < C; ++c) {
-      double* o = &cam[(size_t)c * 35];
+      double* o = &cam[(size_t)c * kCamRec];
       const double* t = &tvs[(size_t)c * 7];
       for (int i = 0; i < 4; ++i) o[i] = pb.cam_params[(size_t)c * 4 + i];
       bad::Rt vs;
@@ -366,9 +371,14 @@ int upload_cameras(Engine* e, bool eval_only) {
       o[13] = vs.t.x; o[14] = vs.t.y; o[15] = vs.t.z;
       o[25] = sv.t.x; o[26] = sv.t.y; o[27] = sv.t.z;
       for (int i = 0; i < 7; ++i) o[28 + i] = t[i];
+      const bool fov = c < pb.cam_model.size() && pb.cam_model[c] == 1;
+      o[35] = fov ? pb.cam_w[c] : 0.0;
+      o[36] = fov ? 1.0 : 0.0;
     }
     return cam;
   };
+  e->has_fov = false;
+  for (uint32_t c = 0; c < C && c < pb.cam_model.size(); ++c) e->has_fov |= pb.cam_model[c] == 1;
   int rc;
   if (!eval_only && (rc = upload(e, e->cam, table(pb.cam_tvs)))) return rc;
   if (e->calib_dim && (rc = upload(e, e->cam_eval, table(e->tvs_eval)))) return rc;
@@ -486,7 +496,28 @@ int ba_hip_set_cameras(ba_hip_engine* h, uint32_t n, const double* params4, cons
   e->prob.num_cams = n;
   e->prob.cam_params.assign(params4, params4 + 4 * (size_t)n);
   e->prob.cam_tvs.assign(t_vs7, t_vs7 + 7 * (size_t)n);
+  e->prob.cam_model.assign(n, 0);
+  e->prob.cam_w.assign(n, 0.0);
   e->finalized = false;
+  return 0;
+}
+
+int ba_hip_set_camera_models(ba_hip_engine* h, uint32_t n, const int32_t* model, const double* w) {
+  ENG(h);
+  if (n != e->prob.num_cams) return e->fail_msg("ba_hip_set_camera_models: one entry per camera of ba_hip_set_cameras expected");
+  for (uint32_t c = 0; c < n; ++c) {
+    if (model[c] != 0 && model[c] != 1) return e->fail_msg("camera model: 0 (LinearCamera) or 1 (FovCamera)");
+    if (model[c] == 1 && !(w && std::isfinite(w[c]))) return e->fail_msg("FovCamera: a finite distortion parameter w is needed");
+  }
+  e->prob.cam_model.assign(model, model + n);
+  e->prob.cam_w.assign(n, 0.0);
+  for (uint32_t c = 0; c < n; ++c) if (model[c] == 1) e->prob.cam_w[c] = w[c];
+  e->finalized = false;
+  return 0;
+}
+int ba_hip_get_camera_fov(ba_hip_engine* h, double* w) {
+  ENG(h);
+  for (size_t c = 0; c < e->prob.cam_w.size(); ++c) w[c] = e->prob.cam_w[c];
   return 0;
 }
 
@@ -686,6 +717,8 @@ int ba_hip_begin_solve(ba_hip_engine* h) {
   BAE_HIP(hipSetDevice(e->device));
   if (!e->prob.pose_cam_params.empty() && e->prob.pose_cam_params.size() != 4 * (size_t)e->prob.num_poses)
     return e->fail_msg("per-pose camera parameters: one [fx,fy,u0,v0] per pose expected");
+  if (!e->prob.pose_cam_params.empty() && e->has_fov)
+    return e->fail_msg("per-pose camera parameters are offered for LinearCamera rigs only");
   int rc = upload_imu_consts(e);
   if (rc) return rc;
   // (calibration: the tables of k_pose_prep keep the T_vs they were last built with across Solve()
@@ -851,11 +884,13 @@ int ba_hip_apply_step(ba_hip_engine* h) {
   if (e->calib_dim && !e->calib_tvs && e->st.C > 0) {
     // BundleAdjuster.cpp:46-69: params of camera 0 -= delta_k, then every x_s ray is re-derived from
     // the landmark's reference pixel with the new parameters, keeping its length
-    double dk[4];
-    BAE_HIP(hipMemcpyAsync(dk, e->step_p.p + e->st.np, sizeof(dk), hipMemcpyDeviceToHost, e->stream));
+    double dk[5] = {0, 0, 0, 0, 0};
+    BAE_HIP(hipMemcpyAsync(dk, e->step_p.p + e->st.np, e->st.K * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     BAE_HIP(hipStreamSynchronize(e->stream));
     e->cam_params_prev = e->prob.cam_params;
+    e->cam_w_prev = e->prob.cam_w;
     for (int i = 0; i < 4; ++i) e->prob.cam_params[i] -= dk[i];
+    if (e->st.K == 5) e->prob.cam_w[0] -= dk[4];
     if ((rc = upload_cameras(e, false))) return rc;
     if ((rc = launch_reset_rays(e))) return rc;
   }
@@ -898,6 +933,7 @@ int ba_hip_rollback(ba_hip_engine* h) {
   } else if (e->calib_dim) {
     // the intrinsics ARE restored (params_backup, :1066, :1147); the rays come back with the landmark buffer
     e->prob.cam_params = e->cam_params_prev;
+    e->prob.cam_w = e->cam_w_prev;
     if ((rc = upload_cameras(e, false))) return rc;
   }
   rc = launch_pose_prep(e);
@@ -978,8 +1014,8 @@ uint32_t ba_hip_num_calib_params(const ba_hip_engine* h) {
 }
 int ba_hip_set_calibration(ba_hip_engine* h, int calib_size, int do_tvs) {
   ENG(h);
-  if (calib_size != 0 && calib_size != 4)
-    return e->fail_msg("CalibSize must be 0 or 4: the camera model of this path is the 4-parameter pinhole (fx, fy, u0, v0)");
+  if (calib_size != 0 && calib_size != 4 && calib_size != 5)
+    return e->fail_msg("CalibSize must be 0, 4 (LinearCamera: fx, fy, u0, v0) or 5 (FovCamera: fx, fy, u0, v0, w)");
   if (calib_size && do_tvs)
     return e->fail_msg("CalibSize > 0 together with DoTvs is not offered: the reference's T_vs block wipes the intrinsics "
                        "columns it shares an entry with (BundleAdjuster.cpp:1775-1783)");

@@ -12,6 +12,14 @@ static Rt rt_from7(const double* p) {
   return t;
 }
 
+// camera model of the calls below: w != 0 makes cam4 the first four parameters of a FOV camera
+static double g_hostcheck_fov_w = 0.0;
+extern "C" void ba_hostcheck_set_fov(double w) { g_hostcheck_fov_w = w; }
+static Cam cam_from4(const double* cam4) {
+  Cam c = {cam4[0], cam4[1], cam4[2], cam4[3], g_hostcheck_fov_w, g_hostcheck_fov_w != 0.0 ? 1 : 0};
+  return c;
+}
+
 static int g_hostcheck_variant = 1;  // 1 = proj_linearize (what k_linearize calls), 0 = proj_jacobians
 extern "C" void ba_hostcheck_set_variant(int v) { g_hostcheck_variant = v; }
 
@@ -20,7 +28,7 @@ extern "C" void ba_hostcheck_proj_jacobians(int lm_dim, const double* cam4, cons
                                             const double* t_vs_m7, const double* t_wp_r7,
                                             const double* t_vs_r7, int same_pose, double* r2,
                                             double* jm12, double* jr12, double* jl) {
-  Cam cam = {cam4[0], cam4[1], cam4[2], cam4[3]};
+  Cam cam = cam_from4(cam4);
   const Rt t_wp_m = rt_from7(t_wp_m7), t_vs_m = rt_from7(t_vs_m7);
   const Rt t_wp_r = rt_from7(t_wp_r7), t_vs_r = rt_from7(t_vs_r7);
   const Rt t_sw_m = inverse(compose(t_wp_m, t_vs_m));
@@ -49,7 +57,7 @@ extern "C" void ba_hostcheck_proj_jacobians(int lm_dim, const double* cam4, cons
 extern "C" void ba_hostcheck_proj_tvs_jacobian(const double* cam4, const double* z, const double* x,
                                                const double* t_wp_m7, const double* t_vs_m7, const double* t_wp_r7,
                                                const double* t_vs_r7, int same_pose, double* jk12) {
-  Cam cam = {cam4[0], cam4[1], cam4[2], cam4[3]};
+  Cam cam = cam_from4(cam4);
   const Rt t_wp_m = rt_from7(t_wp_m7), t_vs_m = rt_from7(t_vs_m7);
   const Rt t_wp_r = rt_from7(t_wp_r7), t_vs_r = rt_from7(t_vs_r7);
   const Rt t_sw_m = inverse(compose(t_wp_m, t_vs_m));
@@ -63,7 +71,7 @@ extern "C" void ba_hostcheck_proj_tvs_jacobian(const double* cam4, const double*
 extern "C" void ba_hostcheck_proj_intrinsics_jacobian(const double* cam4, const double* z_ref, double rho,
                                                       const double* t_wp_m7, const double* t_vs_m7,
                                                       const double* t_wp_r7, const double* t_vs_r7, double* jk12) {
-  Cam cam = {cam4[0], cam4[1], cam4[2], cam4[3]};
+  Cam cam = cam_from4(cam4);
   const Rt t_sw_m = inverse(compose(rt_from7(t_wp_m7), rt_from7(t_vs_m7)));
   const Rt t_ws_r = compose(rt_from7(t_wp_r7), rt_from7(t_vs_r7));
   proj_intrinsics_rows(cam, z_ref, rho, t_sw_m, t_ws_r, 1.0, jk12);
@@ -74,7 +82,7 @@ extern "C" void ba_hostcheck_proj_chain_two_tvs(const double* cam4, const double
                                                 const double* t_wp_r7, const double* t_vs_rig7,
                                                 const double* t_vs_cache7, int same_pose, double* jm12,
                                                 double* jr12, double* jk12) {
-  Cam cam = {cam4[0], cam4[1], cam4[2], cam4[3]};
+  Cam cam = cam_from4(cam4);
   proj_chain_two_tvs(cam, x, t_wp_m7, t_wp_r7, t_vs_rig7, t_vs_cache7, same_pose != 0, jm12, jr12, jk12);
 }
 

@@ -45,7 +45,7 @@ __global__ void k_pose_prep(int P, int C, const double* __restrict__ state,
   wp.R = quat_to_rot(s[3], s[4], s[5], s[6]);
   wp.t = v3(s[0], s[1], s[2]);
   if (c == 0) store_rt(twp + (size_t)p * kRt, wp);
-  const double* cm = cam + (size_t)c * 35;
+  const double* cm = cam + (size_t)c * kCamRec;
   // T_vs as quaternion is kept at cm[28..34] (t, q) to reproduce the normalised product
   double qv[4] = {cm[31], cm[32], cm[33], cm[34]};
   double qp[4] = {s[3], s[4], s[5], s[6]};
@@ -123,7 +123,16 @@ int launch_end_solve(Engine* e) {
 // (SolutionSummary::cond_proj_error, BundleAdjuster.cpp:692-703).  mode 1: EvaluateResiduals — sum |r|^2 * weight
 // and per-landmark outlier counts (BundleAdjuster.cpp:155-187); block partial sums go
 // to `partials` and are added in a fixed order by sum_partials (deterministic).
-template <int LM>
+// camera of one observation: intrinsics `ip` (the rig camera's or the measurement pose's) with the
+// model of the rig camera `cp`.  FOV == false (no FovCamera in the rig): the pinhole as a literal model.
+template <bool FOV>
+__device__ __forceinline__ Cam load_cam(const double* __restrict__ ip, const double* __restrict__ cp) {
+  Cam c = {ip[0], ip[1], ip[2], ip[3], 0.0, 0};
+  if constexpr (FOV) { c.w = cp[35]; c.model = cp[36] != 0.0 ? 1 : 0; }
+  return c;
+}
+
+template <int LM, bool FOV>
 __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
                             const double* __restrict__ obs_z,
                             const uint32_t* __restrict__ obs_pose,
@@ -147,10 +156,10 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
     Rt t_ws_r = t_sw_m;
     if (LM == 1) t_ws_r = load_rt(tws + ((size_t)lm_ref_pose[l] * C + lm_ref_cam[l]) * kRt);
     const V3 P = proj_point<LM>(t_sw_m, t_ws_r, x);
-    const double* cp = cam + (size_t)cm * 35;
+    const double* cp = cam + (size_t)cm * kCamRec;
     // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
     const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
-    Cam cc = {ip[0], ip[1], ip[2], ip[3]};
+    const Cam cc = load_cam<FOV>(ip, cp);
     double u, v;
     project(cc, P, &u, &v);
     const double r0 = obs_z[2 * (size_t)a] - u, r1 = obs_z[2 * (size_t)a + 1] - v;
@@ -178,7 +187,7 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
 // Debug / read-back tap: the residual vector z - pi of every observation at the CURRENT state
 // (what ProjectionResidual::residual holds after the last EvaluateResiduals of a Solve(),
 // BundleAdjuster.cpp:155-181).
-template <int LM>
+template <int LM, bool FOV>
 __global__ void k_residual_vectors(int O, int C, const double* __restrict__ obs_z,
                                    const uint32_t* __restrict__ obs_pose, const uint32_t* __restrict__ obs_cam,
                                    const uint32_t* __restrict__ obs_lm, const double* __restrict__ lm_x,
@@ -195,10 +204,10 @@ __global__ void k_residual_vectors(int O, int C, const double* __restrict__ obs_
   Rt t_ws_r = t_sw_m;
   if (LM == 1) t_ws_r = load_rt(tws + ((size_t)lm_ref_pose[l] * C + lm_ref_cam[l]) * kRt);
   const V3 P = proj_point<LM>(t_sw_m, t_ws_r, x);
-  const double* cp = cam + (size_t)cm * 35;
+  const double* cp = cam + (size_t)cm * kCamRec;
   // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
     const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
-    Cam cc = {ip[0], ip[1], ip[2], ip[3]};
+    const Cam cc = load_cam<FOV>(ip, cp);
   double u, v;
   project(cc, P, &u, &v);
   r2[2 * (size_t)a] = obs_z[2 * (size_t)a] - u;
@@ -214,8 +223,13 @@ int launch_residual_vectors(Engine* e, double* d_r2) {
 #define BAE_ARGS                                                                              \
   O, (int)e->st.C, e->obs_z.p, e->obs_pose.p, e->obs_cam.p, e->obs_lm.p, e->lm_x[e->cur].p,   \
       e->lm_ref_pose.p, e->lm_ref_cam.p, e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, d_r2
-  if (e->lm_dim == 1) hipLaunchKernelGGL(k_residual_vectors<1>, grid, block, 0, e->stream, BAE_ARGS);
-  else hipLaunchKernelGGL(k_residual_vectors<3>, grid, block, 0, e->stream, BAE_ARGS);
+  if (e->has_fov) {
+    if (e->lm_dim == 1) hipLaunchKernelGGL((k_residual_vectors<1, true>), grid, block, 0, e->stream, BAE_ARGS);
+    else hipLaunchKernelGGL((k_residual_vectors<3, true>), grid, block, 0, e->stream, BAE_ARGS);
+  } else {
+    if (e->lm_dim == 1) hipLaunchKernelGGL((k_residual_vectors<1, false>), grid, block, 0, e->stream, BAE_ARGS);
+    else hipLaunchKernelGGL((k_residual_vectors<3, false>), grid, block, 0, e->stream, BAE_ARGS);
+  }
 #undef BAE_ARGS
   BAE_HIP(hipGetLastError());
   return 0;
@@ -232,8 +246,13 @@ int launch_residuals(Engine* e, int mode) {
       e->obs_cam.p, e->obs_lm.p, w, e->lm_x[e->cur].p, e->lm_ref_pose.p, e->lm_ref_cam.p, \
       e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->obs_e.p, e->lm_outliers.p, e->partials.p,     \
       (const uint8_t*)e->obs_cond.p
-  if (e->lm_dim == 1) hipLaunchKernelGGL(k_residuals<1>, grid, block, 0, e->stream, BAE_ARGS);
-  else hipLaunchKernelGGL(k_residuals<3>, grid, block, 0, e->stream, BAE_ARGS);
+  if (e->has_fov) {
+    if (e->lm_dim == 1) hipLaunchKernelGGL((k_residuals<1, true>), grid, block, 0, e->stream, BAE_ARGS);
+    else hipLaunchKernelGGL((k_residuals<3, true>), grid, block, 0, e->stream, BAE_ARGS);
+  } else {
+    if (e->lm_dim == 1) hipLaunchKernelGGL((k_residuals<1, false>), grid, block, 0, e->stream, BAE_ARGS);
+    else hipLaunchKernelGGL((k_residuals<3, false>), grid, block, 0, e->stream, BAE_ARGS);
+  }
 #undef BAE_ARGS
   BAE_HIP(hipGetLastError());
   return 0;
@@ -264,7 +283,7 @@ struct ObsLin {
 
 // Everything one observation contributes, at the current state: residual, Jacobians with the
 // columns of regularised parameters zeroed (BundleAdjuster.cpp:1622-1629), Huber weight.
-template <int LM, int CAL = 0>
+template <int LM, int CAL = 0, bool FOV = false>
 __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, double c_huber, int use_robust,
                                               const double* __restrict__ obs_z, const uint32_t* __restrict__ obs_pose,
                                               const uint32_t* __restrict__ obs_cam, const double* __restrict__ obs_w0,
@@ -278,10 +297,10 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
                                               const double* __restrict__ state = nullptr,
                                               const double* __restrict__ cam_cache = nullptr) {
   const uint32_t pm = obs_pose[a], cm = obs_cam[a];
-  const double* cp = cam + (size_t)cm * 35;
+  const double* cp = cam + (size_t)cm * kCamRec;
   // Options::use_per_pose_cam_params (parallel_algos.h:54-57): intrinsics of the measurement pose
   const double* ip = pose_cam ? pose_cam + (size_t)pm * 4 : cp;
-  const Cam cc = {ip[0], ip[1], ip[2], ip[3]};
+  const Cam cc = load_cam<FOV>(ip, cp);
   double x[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) x[i] = lm_x[(size_t)l * 4 + i];
@@ -308,7 +327,7 @@ __device__ __forceinline__ void linearize_obs(uint32_t a, uint32_t l, int C, dou
         // hold the T_vs before the step, the rig the step itself — the three Jacobian blocks from the
         // reference's chains with the two kept apart (dmath.h: proj_chain_two_tvs).  Rare path.
         proj_chain_two_tvs(cc, x, state + (size_t)pm * kPoseState, state + (size_t)rp * kPoseState,
-                           cam + (size_t)cm * 35 + 28, cam_cache + (size_t)cm * 35 + 28, pm == rp, J.jm, J.jr, o->jk);
+                           cam + (size_t)cm * kCamRec + 28, cam_cache + (size_t)cm * kCamRec + 28, pm == rp, J.jm, J.jr, o->jk);
 #pragma unroll
         for (int i = 0; i < 12; ++i) o->jk[i] *= keep;
       } else if constexpr (CAL == 1) {
@@ -443,7 +462,7 @@ __device__ __forceinline__ void store_landmark(uint32_t l, uint32_t O, uint32_t 
 // CAL (calibration instantiations, LM == 1): additionally the calibration rows `crow` (engine.h) —
 // sqrt(w) dz_dtvs of the observation at 2a, 2a+1 and the landmark's E_l = sum w J_l^T J_k at 2O + l
 // (six more components of the segmented sums).
-template <int LM, int WAVES, bool BIG, bool STAGE, int CAL = 0>
+template <int LM, int WAVES, bool BIG, bool STAGE, int CAL = 0, bool FOV = false>
 __global__ void __launch_bounds__(64 * WAVES)
 k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_huber, int use_robust,
             const uint2* __restrict__ wave_rng, const uint32_t* __restrict__ lm_ptr,
@@ -494,7 +513,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     const bool lm_act = lm_opt[l] >= 0;
     const int s0 = (int)(lm_ptr[l] - a0), s1 = (int)(lm_ptr[l + 1] - 1 - a0);  // lanes of this landmark
     ObsLin<LM, CAL> q;
-    linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
+    linearize_obs<LM, CAL, FOV>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
     double v[NS];
     obs_sums<LM, CAL>(q, v);
     if (!valid || !lm_act) {
@@ -567,7 +586,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     for (int i = 0; i < NS; ++i) tot[i] = 0.0;
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
       ObsLin<LM, CAL> q;
-      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
+      linearize_obs<LM, CAL, FOV>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
       double v[NS];
       obs_sums<LM, CAL>(q, v);
 #pragma unroll
@@ -582,7 +601,7 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
     invert_v<LM>(tot, Vi);
     for (uint32_t a = a0 + lane; a < a1; a += 64) {
       ObsLin<LM, CAL> q;
-      linearize_obs<LM, CAL>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
+      linearize_obs<LM, CAL, FOV>(a, l, BAE_LIN_ARGS, &q, pose_opt, lm_zref, state, cam_cache);
       double rows[RD];
       obs_rows<LM, CAL>(q, Vi, rows);
       store_calib_obs(a, q);
@@ -609,6 +628,13 @@ k_linearize(uint32_t n_chunks, int C, uint32_t O, uint32_t lrow_base, double c_h
   (void)NV; (void)NE;
 }
 
+// one launch of k_linearize: the FOV instantiation when the rig holds a FovCamera
+#define BAE_LIN_LAUNCH(LMv, WAVESv, BIGv, STAGEv, CALv, grid_, block_, shm_, stream_, ...)                        \
+  do {                                                                                                          \
+    if (e->has_fov) hipLaunchKernelGGL((k_linearize<LMv, WAVESv, BIGv, STAGEv, CALv, true>), grid_, block_, shm_, stream_, __VA_ARGS__); \
+    else hipLaunchKernelGGL((k_linearize<LMv, WAVESv, BIGv, STAGEv, CALv, false>), grid_, block_, shm_, stream_, __VA_ARGS__);           \
+  } while (0)
+
 int launch_landmarks(Engine* e, double c_huber, int use_robust) {
   const Structure& st = e->st;
   if (st.n_chunks == 0 || st.O == 0) return 0;
@@ -631,9 +657,9 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
     if (two_tvs) {
       const dim3 grid((st.n_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
       if (n_small)
-        hipLaunchKernelGGL((k_linearize<1, WAVES, false, false, 3>), dim3((n_small + WAVES - 1) / WAVES), block, 0, e->stream, BAE_ARGS(0, n_small));
+        BAE_LIN_LAUNCH(1, WAVES, false, false, 3, dim3((n_small + WAVES - 1) / WAVES), block, 0, e->stream, BAE_ARGS(0, n_small));
       if (st.n_big_chunks)
-        hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, 3>), dim3((st.n_big_chunks + WAVES - 1) / WAVES), block, 0, e->stream,
+        BAE_LIN_LAUNCH(1, WAVES, true, false, 3, dim3((st.n_big_chunks + WAVES - 1) / WAVES), block, 0, e->stream,
                            BAE_ARGS(n_small, st.n_big_chunks));
       (void)grid;
       e->prof_end(e->ev_landmarks);
@@ -642,15 +668,15 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
     }
     if (n_small) {
       const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
-      if (e->calib_tvs) hipLaunchKernelGGL((k_linearize<1, WAVES, false, true, 1>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
-      else hipLaunchKernelGGL((k_linearize<1, WAVES, false, true, 2>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      if (e->calib_tvs) BAE_LIN_LAUNCH(1, WAVES, false, true, 1, grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      else BAE_LIN_LAUNCH(1, WAVES, false, true, 2, grid, block, 0, e->stream, BAE_ARGS(0, n_small));
     }
     if (st.n_big_chunks) {
       const dim3 grid((st.n_big_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
       if (e->calib_tvs)
-        hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, 1>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+        BAE_LIN_LAUNCH(1, WAVES, true, false, 1, grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
       else
-        hipLaunchKernelGGL((k_linearize<1, WAVES, true, false, 2>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+        BAE_LIN_LAUNCH(1, WAVES, true, false, 2, grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
     }
     e->prof_end(e->ev_landmarks);
     BAE_HIP(hipGetLastError());
@@ -659,18 +685,18 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
   if (n_small) {
     if (e->dbg_linearize_variant == 0) {
       const dim3 grid((n_small + WAVES - 1) / WAVES), block(64 * WAVES);
-      if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, false, true>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
-      else hipLaunchKernelGGL((k_linearize<3, WAVES, false, true>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      if (e->lm_dim == 1) BAE_LIN_LAUNCH(1, WAVES, false, true, 0, grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      else BAE_LIN_LAUNCH(3, WAVES, false, true, 0, grid, block, 0, e->stream, BAE_ARGS(0, n_small));
     } else {
       const dim3 grid((n_small + 3) / 4), block(256);
-      if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, 4, false, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
-      else hipLaunchKernelGGL((k_linearize<3, 4, false, false>), grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      if (e->lm_dim == 1) BAE_LIN_LAUNCH(1, 4, false, false, 0, grid, block, 0, e->stream, BAE_ARGS(0, n_small));
+      else BAE_LIN_LAUNCH(3, 4, false, false, 0, grid, block, 0, e->stream, BAE_ARGS(0, n_small));
     }
   }
   if (st.n_big_chunks) {
     const dim3 grid((st.n_big_chunks + WAVES - 1) / WAVES), block(64 * WAVES);
-    if (e->lm_dim == 1) hipLaunchKernelGGL((k_linearize<1, WAVES, true, false>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
-    else hipLaunchKernelGGL((k_linearize<3, WAVES, true, false>), grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+    if (e->lm_dim == 1) BAE_LIN_LAUNCH(1, WAVES, true, false, 0, grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
+    else BAE_LIN_LAUNCH(3, WAVES, true, false, 0, grid, block, 0, e->stream, BAE_ARGS(n_small, st.n_big_chunks));
   }
   e->prof_end(e->ev_landmarks);
 #undef BAE_ARGS
@@ -823,7 +849,12 @@ __global__ void k_reset_rays(int L, const double* __restrict__ cam, const double
   if (l >= L) return;
   double* o = x + (size_t)l * 4;
   const double norm = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
-  const double rx = (zref[2 * (size_t)l] - cam[2]) / cam[0], ry = (zref[2 * (size_t)l + 1] - cam[3]) / cam[1];
+  double rx = (zref[2 * (size_t)l] - cam[2]) / cam[0], ry = (zref[2 * (size_t)l + 1] - cam[3]) / cam[1];
+  if (cam[36] != 0.0) {  // FovCamera: the un-distorted ray
+    double g, dg_dr, dg_dw;
+    fov_factor_inv(cam[35], sqrt(rx * rx + ry * ry), &g, &dg_dr, &dg_dw);
+    rx *= g; ry *= g;
+  }
   const double s = norm / sqrt(rx * rx + ry * ry + 1.0);
   o[0] = rx * s; o[1] = ry * s; o[2] = s;
 }

@@ -52,6 +52,8 @@ struct Problem {  // host copies, reference ids
   uint32_t num_cams = 0, num_poses = 0, num_lms = 0, num_proj = 0;
   uint32_t num_unary = 0, num_binary = 0, num_imu = 0;
   std::vector<double> cam_params, cam_tvs;                 // [C][4], [C][7]
+  std::vector<int32_t> cam_model;                          // [C] 0 LinearCamera, 1 FovCamera (empty: all 0)
+  std::vector<double> cam_w;                               // [C] FOV distortion parameter w (model 1)
   std::vector<double> pose_cam_params;                     // [P][4] or empty (use_per_pose_cam_params)
   std::vector<double> imu_noise;                           // r(6) | r_b(6) or empty (from the option sigmas)
   std::vector<double> pose_state;                          // [P][16]

@@ -85,6 +85,7 @@ SYMBOLS = [
     "ba_hip_get_kernel_stats", "ba_hip_check_solve", "ba_hip_get_structure_stats", "ba_hip_debug_set", "ba_hip_set_conditioning_residuals",
     "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host", "ba_hip_get_proj_jacobians",
     "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians", "ba_hip_get_calibration_marginals", "ba_hip_set_landmark_ref_pixels", "ba_hip_get_camera_params",
+    "ba_hip_set_camera_models", "ba_hip_get_camera_fov",
 ]
 
 
@@ -173,8 +174,24 @@ class Engine:
         self._chk(self.L.ba_hip_set_options(self.h, C.byref(opt)))
 
     def set_cameras(self, params, t_vs):
-        p, t = _d(params).reshape(-1, 4), _d(t_vs).reshape(-1, 7)
-        self._chk(self.L.ba_hip_set_cameras(self.h, p.shape[0], _p(p, dp), _p(t, dp)))
+        """params: C x 4 (calibu::LinearCamera) or C x 5 (calibu::FovCamera: fx, fy, u0, v0, w)."""
+        p = np.atleast_2d(_d(params))
+        if p.shape[1] not in (4, 5):
+            p = p.reshape(-1, 4)
+        t = _d(t_vs).reshape(-1, 7)
+        p4 = np.ascontiguousarray(p[:, :4])
+        self._chk(self.L.ba_hip_set_cameras(self.h, p4.shape[0], _p(p4, dp), _p(t, dp)))
+        if p.shape[1] == 5:
+            self.set_camera_models(np.ones(p.shape[0], dtype=np.int32), p[:, 4])
+
+    def set_camera_models(self, model, w):
+        m, ww = np.ascontiguousarray(model, dtype=np.int32), _d(w)
+        self._chk(self.L.ba_hip_set_camera_models(self.h, m.shape[0], m.ctypes.data_as(C.POINTER(C.c_int32)), _p(ww, dp)))
+
+    def get_camera_fov(self, n):
+        w = np.empty(n)
+        self._chk(self.L.ba_hip_get_camera_fov(self.h, _p(w, dp)))
+        return w
 
     def set_pose_cam_params(self, params):
         """P x 4 pinhole intrinsics per pose (use_per_pose_cam_params), None = rig camera."""

@@ -13,10 +13,11 @@
 //
 // Supported instantiations: LmSize in {0,1,3}, PoseSize in {6,9,15}; with LmSize 1 the
 // self-calibration instantiations (reference :121-134, BundleAdjuster.cpp:46-83, 493-583): DoTvs —
-// the extrinsics T_vs of camera 0 as six more unknowns — or CalibSize = 4 — the pinhole parameters
-// (fx, fy, u0, v0) of camera 0 (the reference instantiates 5 for Calibu's FOV camera, which is not in
-// its tree; 4 is the camera model of this path).  Not both at once: the reference's own T_vs block
-// wipes the intrinsics columns in that case (BundleAdjuster.cpp:1775-1783).
+// the extrinsics T_vs of camera 0 as six more unknowns — or CalibSize = 4 / 5 — the parameters of camera 0:
+// (fx, fy, u0, v0) of a LinearCamera, (fx, fy, u0, v0, w) of a FovCamera (the reference's
+// SelfCalBundleAdjuster; CalibSize must equal the camera's parameter count, as the fixed-size assignment
+// at parallel_algos.h:115-118 demands).  Not both at once: the reference's own T_vs block wipes the
+// intrinsics columns in that case (BundleAdjuster.cpp:1775-1783).
 #pragma once
 #include <algorithm>
 #include <cassert>
@@ -100,7 +101,8 @@ class BundleAdjuster {
   static_assert(std::is_same<Scalar, double>::value, "the engine computes in FP64 (REAL_TYPE=double)");
   static_assert(LmSize == 0 || LmSize == 1 || LmSize == 3, "LmSize must be 0, 1 or 3");
   static_assert(PoseSize == 6 || PoseSize == 9 || PoseSize == 15, "PoseSize must be 6, 9 or 15");
-  static_assert(CalibSize == 0 || CalibSize == 4, "CalibSize: 0 or the 4 pinhole parameters (fx, fy, u0, v0)");
+  static_assert(CalibSize == 0 || CalibSize == 4 || CalibSize == 5,
+                "CalibSize: 0, the 4 pinhole parameters (fx, fy, u0, v0) or the 5 of a FovCamera (fx, fy, u0, v0, w)");
   static_assert(!(CalibSize > 0 && DoTvs), "CalibSize > 0 with DoTvs: the reference wipes the intrinsics columns (BundleAdjuster.cpp:1775-1783)");
   static_assert((!DoTvs && CalibSize == 0) || LmSize == 1, "calibration exists for inverse-depth landmarks only (parallel_algos.h:102-131)");
 
@@ -548,6 +550,8 @@ class BundleAdjuster {
 };
 
 template <typename Scalar>
+using SelfCalBundleAdjuster = BundleAdjuster<Scalar, 1, 6, 5>;          // reference :758-759 (camera 0: a FovCamera)
+template <typename Scalar>
 using VisualBundleAdjuster = BundleAdjuster<Scalar, 1, 6, 0>;           // reference :760-761
 template <typename Scalar>
 using VisualInertialBundleAdjuster = BundleAdjuster<Scalar, 1, 15, 0>;  // reference :762-763
@@ -643,6 +647,12 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::UploadProblem()
     la[l] = landmarks_[l].is_active ? 1 : 0;
   }
   if (!Check(ba_hip_set_cameras(engine_, C, cam_p.data(), cam_t.data()), "ba_hip_set_cameras")) return false;
+  {
+    std::vector<int32_t> cam_m(C);
+    std::vector<double> cam_w(C);
+    for (uint32_t c = 0; c < C; ++c) { cam_m[c] = rig_->cameras_[c]->Type(); cam_w[c] = rig_->cameras_[c]->Param(4); }
+    if (C && !Check(ba_hip_set_camera_models(engine_, C, cam_m.data(), cam_w.data()), "ba_hip_set_camera_models")) return false;
+  }
   if (!Check(ba_hip_set_poses(engine_, P, pt.data(), pv.data(), pb.data(), pa.data()), "ba_hip_set_poses")) return false;
   if (options_.use_per_pose_cam_params) {
     // reference parallel_algos.h:54-57: cam->SetParams(pose.cam_params) per residual
@@ -1031,9 +1041,10 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
     if (Check(ba_hip_get_cameras(engine_, tv.data()), "ba_hip_get_cameras")) rig_->cameras_[0]->SetPose(SE3::from7(tv.data()));
   }
   if (kCamParamsInCalib && rig_->NumCams() > 0) {  // :46-53
-    std::vector<double> cp(4 * (size_t)rig_->NumCams());
-    if (Check(ba_hip_get_camera_params(engine_, cp.data()), "ba_hip_get_camera_params"))
-      rig_->cameras_[0]->SetParams(Vector4t({cp[0], cp[1], cp[2], cp[3]}));
+    std::vector<double> cp(4 * (size_t)rig_->NumCams()), cw(rig_->NumCams());
+    if (Check(ba_hip_get_camera_params(engine_, cp.data()), "ba_hip_get_camera_params") &&
+        Check(ba_hip_get_camera_fov(engine_, cw.data()), "ba_hip_get_camera_fov"))
+      rig_->cameras_[0]->SetParams(std::vector<double>({cp[0], cp[1], cp[2], cp[3], cw[0]}));
   }
   last_step_stale_ = true;
   uploaded_once_ = true;

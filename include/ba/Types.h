@@ -128,26 +128,44 @@ struct SE3 {
   }
 };
 
-// What the hot path needs of calibu::CameraInterface: pinhole parameters and the
-// vehicle-to-sensor pose (reference call sites parallel_algos.h:44-62).
+// What the hot path needs of calibu::CameraInterface: the camera parameters and the
+// vehicle-to-sensor pose (reference call sites parallel_algos.h:44-62).  Two models: the pinhole
+// (calibu::LinearCamera: fx, fy, u0, v0) and the FOV camera (calibu::FovCamera: fx, fy, u0, v0, w — the
+// five parameters of SelfCalBundleAdjuster = BundleAdjuster<Scalar, 1, 6, 5>, reference BundleAdjuster.h:758-759).
+// Calibu is not in the reference tree; the FOV model is the published one (Devernay & Faugeras 2001,
+// r_d = atan(2 r_u tan(w/2)) / w, applied as a factor on the normalised point), as in ba_amd/csrc/dmath.h.
 template <typename Scalar = double>
 class CameraInterface {
  public:
-  CameraInterface() { p_[0] = p_[1] = 1; p_[2] = p_[3] = 0; }
+  enum Model { kLinear = 0, kFov = 1 };
+  CameraInterface() { p_[0] = p_[1] = 1; p_[2] = p_[3] = 0; p_[4] = 0; }
   CameraInterface(double fx, double fy, double u0, double v0, const SE3& t_vs = SE3()) : t_vs_(t_vs) {
-    p_[0] = fx; p_[1] = fy; p_[2] = u0; p_[3] = v0;
+    p_[0] = fx; p_[1] = fy; p_[2] = u0; p_[3] = v0; p_[4] = 0;
   }
+  int Type() const { return model_; }
+  uint32_t NumParams() const { return model_ == kFov ? 5u : 4u; }
+  // the first four parameters (all of them for the pinhole); Param(i) / ParamsVector() reach every one
   Vector4t GetParams() const { Vector4t v; for (int i = 0; i < 4; ++i) v[i] = p_[i]; return v; }
+  double Param(uint32_t i) const { return p_[i]; }
+  std::vector<double> ParamsVector() const { return std::vector<double>(p_, p_ + NumParams()); }
+  // takes min(NumParams(), what the vector holds) entries — a Vector4t leaves w of a FOV camera alone
   template <typename V> void SetParams(const V& v) { for (int i = 0; i < 4; ++i) p_[i] = v[i]; }
+  void SetParams(const std::vector<double>& v) { for (size_t i = 0; i < v.size() && i < NumParams(); ++i) p_[i] = v[i]; }
   const SE3& Pose() const { return t_vs_; }
   void SetPose(const SE3& t) { t_vs_ = t; }
-  // the pinhole (calibu::LinearCamera) model itself, for callers that synthesise or check
-  // measurements on the host (semantics of the calibu calls at parallel_algos.h:59-62,73-74)
+  // the camera model itself, for callers that synthesise or check measurements on the host
+  // (semantics of the calibu calls at parallel_algos.h:59-62,73-74)
   Vector2t Project(const Vector3t& P) const {
+    if (model_ == kFov) {
+      const double px = P[0] / P[2], py = P[1] / P[2], f = Factor(std::sqrt(px * px + py * py));
+      return Vector2t({p_[0] * (f * px) + p_[2], p_[1] * (f * py) + p_[3]});
+    }
     return Vector2t({p_[0] * P[0] / P[2] + p_[2], p_[1] * P[1] / P[2] + p_[3]});
   }
   Vector3t Unproject(const Vector2t& pix) const {  // the ray with z = 1
-    return Vector3t({(pix[0] - p_[2]) / p_[0], (pix[1] - p_[3]) / p_[1], 1.0});
+    double x = (pix[0] - p_[2]) / p_[0], y = (pix[1] - p_[3]) / p_[1];
+    if (model_ == kFov) { const double g = FactorInv(std::sqrt(x * x + y * y)); x *= g; y *= g; }
+    return Vector3t({x, y, 1.0});
   }
   // Transfer3d(T_ba, ray, rho) = Project(R ray + rho t)
   Vector2t Transfer3d(const SE3& t_ba, const Vector3t& ray, const Scalar rho) const {
@@ -161,8 +179,16 @@ class CameraInterface {
     const Matrix3t R = t_ba.rotationMatrix();
     Vector3t P;
     for (int r = 0; r < 3; ++r) P[r] = R(r, 0) * ray[0] + R(r, 1) * ray[1] + R(r, 2) * ray[2] + rho * t_ba.t[r];
-    const double d[2][3] = {{p_[0] / P[2], 0.0, -p_[0] * P[0] / (P[2] * P[2])},
-                            {0.0, p_[1] / P[2], -p_[1] * P[1] / (P[2] * P[2])}};
+    double d[2][3] = {{p_[0] / P[2], 0.0, -p_[0] * P[0] / (P[2] * P[2])},
+                      {0.0, p_[1] / P[2], -p_[1] * P[1] / (P[2] * P[2])}};
+    if (model_ == kFov) {
+      const double iz = 1.0 / P[2], px = P[0] * iz, py = P[1] * iz, r = std::sqrt(px * px + py * py);
+      double df_dr;
+      const double f = Factor(r, &df_dr), k = r > 0.0 ? df_dr / r : 0.0;
+      const double a00 = f + k * px * px, a01 = k * px * py, a11 = f + k * py * py;
+      d[0][0] = p_[0] * a00 * iz; d[0][1] = p_[0] * a01 * iz; d[0][2] = -p_[0] * (a00 * px + a01 * py) * iz;
+      d[1][0] = p_[1] * a01 * iz; d[1][1] = p_[1] * a11 * iz; d[1][2] = -p_[1] * (a01 * px + a11 * py) * iz;
+    }
     Mat<2, 4> J;
     for (int r = 0; r < 2; ++r) {
       for (int c = 0; c < 3; ++c) J(r, c) = d[r][0] * R(0, c) + d[r][1] * R(1, c) + d[r][2] * R(2, c);
@@ -170,12 +196,41 @@ class CameraInterface {
     }
     return J;
   }
- private:
-  double p_[4];
+ protected:
+  // r_d / r_u and r_u / r_d of the FOV model, with their limits for a vanishing radius / vanishing w
+  double Factor(double r, double* df_dr = nullptr) const {
+    const double w = p_[4];
+    if (df_dr) *df_dr = 0.0;
+    if (w * w <= 1e-5) return 1.0;
+    const double m = 2.0 * std::tan(0.5 * w);
+    if (r * r < 1e-5) return m / w;
+    const double at = std::atan(r * m);
+    if (df_dr) *df_dr = m / ((1.0 + r * r * m * m) * r * w) - at / (r * r * w);
+    return at / (r * w);
+  }
+  double FactorInv(double rd) const {
+    const double w = p_[4];
+    if (w * w <= 1e-5) return 1.0;
+    const double m = 2.0 * std::tan(0.5 * w);
+    if (rd * rd < 1e-5) return w / m;
+    return std::tan(rd * w) / (rd * m);
+  }
+  double p_[5];
+  int model_ = kLinear;
   SE3 t_vs_;
 };
 template <typename Scalar = double>
 using LinearCamera = CameraInterface<Scalar>;
+// calibu::FovCamera stand-in: parameters fx, fy, u0, v0, w
+template <typename Scalar = double>
+class FovCamera : public CameraInterface<Scalar> {
+ public:
+  FovCamera(double fx, double fy, double u0, double v0, double w, const SE3& t_vs = SE3())
+      : CameraInterface<Scalar>(fx, fy, u0, v0, t_vs) {
+    this->p_[4] = w;
+    this->model_ = CameraInterface<Scalar>::kFov;
+  }
+};
 
 // calibu::Rig stand-in
 template <typename Scalar = double>

@@ -46,13 +46,15 @@ typedef struct { /* ba::SolutionSummary<double> + GetErrors, reference :48-70,59
 void ba_default_options(ba_options* o);
 ba_adjuster* ba_adjuster_create(int lm_dim, int pose_dim);
 /* ba::BundleAdjuster<double, lm_dim, pose_dim, calib_size, do_tvs>, lm_dim 1: do_tvs (the extrinsics
- * of camera 0 become six more unknowns) or calib_size 4 (its pinhole parameters become four more),
- * not both.  NULL otherwise. */
+ * of camera 0 become six more unknowns) or calib_size 4 / 5 (the parameters of camera 0 — a LinearCamera
+ * / a FovCamera — become four / five more), not both.  NULL otherwise. */
 ba_adjuster* ba_adjuster_create_calib(int lm_dim, int pose_dim, int calib_size, int do_tvs);
 void ba_adjuster_destroy(ba_adjuster* a);
 void ba_adjuster_init(ba_adjuster* a, const ba_options* o);
 void ba_adjuster_set_gravity(ba_adjuster* a, const double g[3]);
 uint32_t ba_adjuster_add_camera(ba_adjuster* a, const double params[4], const double t_vs[7]);
+/* a calibu::FovCamera: params (fx, fy, u0, v0, w) */
+uint32_t ba_adjuster_add_camera_fov(ba_adjuster* a, const double params[5], const double t_vs[7]);
 uint32_t ba_adjuster_add_pose(ba_adjuster* a, const double t_wp[7], const double v_w[3],
                               const double b[6], int is_active, double time);
 uint32_t ba_adjuster_add_landmark(ba_adjuster* a, const double x_w[4], uint32_t ref_pose_id,
@@ -111,6 +113,8 @@ ba_hip_engine* ba_adjuster_engine(ba_adjuster* a);
 void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]);
 /* rig()->cameras_[cam_id]->GetParams(): with calib_size 4 camera 0's move with every applied step */
 void ba_adjuster_get_camera_params(const ba_adjuster* a, uint32_t cam_id, double params[4]);
+/* the fifth parameter w of a FovCamera (0 for a LinearCamera) */
+double ba_adjuster_get_camera_fov(const ba_adjuster* a, uint32_t cam_id);
 /* SolutionSummary::calibration_marginals (6 x 6, row-major) of the last iteration; returns its
  * dimension (0 when the option was off or the adjuster has no calibration unknowns) */
 uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[36]);

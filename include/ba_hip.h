@@ -112,8 +112,10 @@ int ba_hip_set_options(ba_hip_engine* e, const ba_hip_options* o);
  * dz_dcam_params = -dTransfer_dparams(T_sw_m T_ws_r, z_ref, rho)); needs the reference pixel of every
  * landmark (ba_hip_set_landmark_ref_pixels).  ba_hip_apply_step moves the parameters by -delta_k and
  * re-derives every x_s ray from its reference pixel (:57-68); a rollback restores them (:1066, :1147);
- * read them back with ba_hip_get_camera_params.  The reference instantiates CalibSize = 5 for Calibu's
- * FOV camera, which is not in its tree: 4 is the size of the camera model this path has.
+ * read them back with ba_hip_get_camera_params.  calib_size = 5: the same for a FovCamera 0
+ * (fx, fy, u0, v0, w; ba_hip_set_camera_models) — the reference's SelfCalBundleAdjuster
+ * (BundleAdjuster.h:758-759).  calib_size must equal the parameter count of camera 0 (checked by
+ * ba_hip_finalize; the reference's fixed-size assignment at parallel_algos.h:115-118).
  * Both at once is refused (the reference's T_vs block wipes the intrinsics columns it shares a
  * j_kpr_ entry with, :1775-1783), as is any other size.  LmSize 1 only (parallel_algos.h:102-131).
  * Structural: call before ba_hip_finalize. */
@@ -127,6 +129,13 @@ int ba_hip_get_camera_params(ba_hip_engine* e, double* params4);
 /* ---- problem upload (replaces the AoS graph of Types.h:41-321) -------------------- */
 /* calibu::Rig cameras: pinhole params [fx,fy,u0,v0] and T_vs (BundleAdjuster.h:259-263) */
 int ba_hip_set_cameras(ba_hip_engine* e, uint32_t n, const double* params4, const double* t_vs7);
+/* Camera model of every camera of ba_hip_set_cameras (call after it; it resets them to 0):
+ * model 0 = calibu::LinearCamera (pinhole), 1 = calibu::FovCamera with distortion parameter w[c]
+ * (pix = K (f(r) p), p = P.xy / P.z, f(r) = atan(2 r tan(w/2)) / (r w) — Devernay & Faugeras 2001; Calibu is
+ * not in the reference tree, see oracle/outils.h).  w is read for model 1 only. */
+int ba_hip_set_camera_models(ba_hip_engine* e, uint32_t n, const int32_t* model, const double* w);
+/* w of every camera (0 for a LinearCamera) as the engine currently holds it */
+int ba_hip_get_camera_fov(ba_hip_engine* e, double* w);
 /* Options::use_per_pose_cam_params (BundleAdjuster.h:96; parallel_algos.h:54-57,
  * BundleAdjuster.cpp:162-176): every projection residual is evaluated with the pinhole
  * intrinsics [fx,fy,u0,v0] of its MEASUREMENT pose (PoseT::cam_params, Types.h:46) instead of the

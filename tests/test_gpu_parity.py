@@ -343,6 +343,58 @@ def test_weights_cameras_with_extrinsics_and_duplicate_observations(oracle_lib):
     assert rel_err(h.delta_p(), o.delta_p()) < 1e-8
 
 
+@pytest.mark.parametrize("lm_dim", [1, 3])
+@pytest.mark.parametrize("rig", ["fov", "fov_and_pinhole"])
+def test_fov_camera_matches_oracle(oracle_lib, lm_dim, rig):
+    """calibu::FovCamera (fx, fy, u0, v0, w — the camera of the reference's CalibSize = 5 instantiations)
+    in the ordinary adjuster: residuals, reduced system and step of the first iteration, then three
+    iterations of the whole solver against the oracle.  fov_and_pinhole: a rig of a FovCamera and a
+    LinearCamera, half of the non-reference observations made by the second one."""
+    po = oracle_lib
+    sc = scene.make_scene(40, 120, 6, lm_dim=lm_dim, seed=31, outlier_frac=0.0)
+    z_pin = sc.obs_z.copy()
+    scene.to_fov_camera(sc, 0.93)
+    cam_id = np.zeros(len(sc.obs_pose), dtype=np.uint32)
+    if rig == "fov_and_pinhole":
+        nsel = sc.obs_per_landmark + (1 if lm_dim == 1 else 0)
+        second = (np.arange(len(cam_id)) % nsel != 0) & (np.arange(len(cam_id)) % 2 == 1)
+        cam_id[second] = 1
+        sc.obs_z[second] = z_pin[second]
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+
+    def build(cls, opts):
+        b = cls(lm_dim, 6)
+        b.Init(opts)
+        b.AddCamera(sc.cam_params)
+        if rig == "fov_and_pinhole":
+            b.AddCamera(sc.cam_params[:4])
+        b.add_poses(sc.poses, is_active=pa)
+        b.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+        b.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm, cam_id=cam_id)
+        return b
+    o, h = build(po.OracleBundleAdjuster, gn_options(po, apply_results=0)), build(adjuster.BundleAdjuster, hip_options(apply_results=0))
+    o.Solve(1)
+    h.Solve(1)
+    assert rel_err(h.S(), o.S()) < 1e-11
+    assert rel_err(h.rhs(), o.rhs()) < 1e-10
+    assert rel_err(h.delta_p(), o.delta_p()) < 1e-7
+    assert rel_err(h.delta_l(), o.delta_l()) < 1e-7
+    assert abs(h.summary().proj_error - o.summary().proj_error) < 1e-10 * o.summary().proj_error
+    o, h = build(po.OracleBundleAdjuster, gn_options(po)), build(adjuster.BundleAdjuster, hip_options())
+    e0 = None
+    for it in range(3):
+        o.Solve(1)
+        h.Solve(1)
+        so, sh = o.summary(), h.summary()
+        assert so.result == sh.result == 0, it
+        assert abs(so.proj_error - sh.proj_error) < 1e-7 * so.proj_error, it
+        e0 = so.proj_error if e0 is None else e0
+    assert so.proj_error < e0
+    assert rel_err(h.poses()[0], o.poses()[0]) < 1e-7
+    assert rel_err(h.landmarks(), o.landmarks()) < 1e-7
+
+
 def test_poses_without_residuals_and_empty_landmarks(oracle_lib):
     po = oracle_lib
     sc = scene.make_scene(30, 40, 4, lm_dim=3, seed=12)
@@ -366,10 +418,11 @@ def test_poses_without_residuals_and_empty_landmarks(oracle_lib):
 
 
 # ---- the C++ host class used directly by a C++ application ---------------------------------
-@pytest.mark.parametrize("mode", [None, "--calibrate-intrinsics", "--calibrate-extrinsics"])
+@pytest.mark.parametrize("mode", [None, "--calibrate-intrinsics", "--calibrate-extrinsics", "--calibrate-fov"])
 def test_cpp_application_runs_on_the_engine(mode):
     """applications/visual_ba_demo: plain C++ against include/ba/BundleAdjuster.h — the visual
-    adjuster and the two self-calibration instantiations <1, 6, 4, false> / <1, 6, 0, true>."""
+    adjuster and the self-calibration instantiations <1, 6, 4, false> / <1, 6, 0, true> /
+    SelfCalBundleAdjuster = <1, 6, 5> on a FovCamera."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "ba_amd", "lib", "visual_ba_demo")
@@ -1935,11 +1988,16 @@ def test_calibration_marginals(oracle_lib, P):
     assert np.all(np.linalg.eigvalsh(0.5 * (cov_h + cov_h.T)) > 0)
 
 
-# ---- camera-intrinsics calibration (CalibSize = 4: fx, fy, u0, v0 of the pinhole model) ---------------
+# ---- camera-intrinsics calibration (CalibSize = 4: fx, fy, u0, v0 of the pinhole model; CalibSize = 5:
+# fx, fy, u0, v0, w of a FOV camera — the reference's SelfCalBundleAdjuster) -----------------------------
+FOV_W = 0.93
+CAMERA_MODELS = pytest.mark.parametrize("fov", [False, True], ids=["pinhole", "fov_camera"])
+
+
 def _intrinsics_pair(po, sc, pa, wrong, pose_dim=6, **kw):
-    o = po.OracleBundleAdjuster(1, pose_dim, calib_size=4)
+    o = po.OracleBundleAdjuster(1, pose_dim, calib_size=len(wrong))
     o.Init(gn_options(po, **kw))
-    h = adjuster.BundleAdjuster(1, pose_dim, calib_size=4)
+    h = adjuster.BundleAdjuster(1, pose_dim, calib_size=len(wrong))
     h.Init(hip_options(**kw))
     for b in (o, h):
         b.AddCamera(wrong)
@@ -1949,31 +2007,35 @@ def _intrinsics_pair(po, sc, pa, wrong, pose_dim=6, **kw):
     return o, h
 
 
-def _intrinsics_scene(P=40, L=160, K=8, seed=2, **kw):
+def _intrinsics_scene(P=40, L=160, K=8, seed=2, fov=False, **kw):
     sc = scene.make_scene(P, L, K, lm_dim=1, seed=seed, roll_amp=0.6, **kw)
+    if fov:
+        scene.to_fov_camera(sc, FOV_W)
     pa = np.ones(sc.num_poses, dtype=np.uint8)
     pa[::3] = 0
     sc.poses[::3] = sc.gt_poses[::3]
-    return sc, pa, np.asarray(sc.cam_params) * np.array([1.03, 0.97, 1.02, 0.98])
+    return sc, pa, np.asarray(sc.cam_params) * np.array([1.03, 0.97, 1.02, 0.98, 1.04][:len(sc.cam_params)])
 
 
 @pytest.mark.gpu
+@CAMERA_MODELS
 @pytest.mark.parametrize("triangular", [1, 0])
-def test_intrinsics_calibration_reduced_system_and_step(oracle_lib, triangular):
-    """CalibSize 4: dz_dcam_params per residual, the bordered (n + 4) system, the step and the
+def test_intrinsics_calibration_reduced_system_and_step(oracle_lib, triangular, fov):
+    """CalibSize 4 / 5: dz_dcam_params per residual, the bordered (n + K) system, the step and the
     marginals against the oracle (BundleAdjuster.cpp:493-583, 771-784; parallel_algos.h:114-118)."""
     po = oracle_lib
-    sc, pa, wrong = _intrinsics_scene(P=30, L=90, K=6, seed=7)
+    sc, pa, wrong = _intrinsics_scene(P=30, L=90, K=6, seed=7, fov=fov)
+    K = len(wrong)
     o, h = _intrinsics_pair(po, sc, pa, wrong, apply_results=0, use_triangular_matrices=triangular,
                             calculate_calibration_marginals=1)
     o.Solve(1)
     h.Solve(1)
     n = o.num_pose_params()
-    assert h.num_pose_params() == n and h.engine().num_calib_params() == 4
+    assert h.num_pose_params() == n and h.engine().num_calib_params() == K
     w = np.sqrt(o.proj_weights())[:, None, None]
     assert rel_err(h.proj_calib_jacobians(), w * o.proj_calib_jacobians()) < 1e-11
     So, Sh = o.S(), h.S()
-    assert Sh.shape == (n + 4, n + 4)
+    assert Sh.shape == (n + K, n + K)
     assert rel_err(Sh[:n, :n], So[:n, :n]) < 1e-12
     assert rel_err(Sh[:n, n:], So[:n, n:]) < 1e-11 and np.abs(So[:n, n:]).max() > 0.1
     assert rel_err(Sh[n:, n:], So[n:, n:]) < 1e-11
@@ -1986,13 +2048,14 @@ def test_intrinsics_calibration_reduced_system_and_step(oracle_lib, triangular):
 
 
 @pytest.mark.gpu
+@CAMERA_MODELS
 @pytest.mark.parametrize("use_dogleg", [0, 1])
-def test_intrinsics_calibration_iterations_track_oracle_and_recover_the_camera(oracle_lib, use_dogleg):
-    """Six iterations from wrong pinhole parameters: summaries, the rig's parameters, poses and
+def test_intrinsics_calibration_iterations_track_oracle_and_recover_the_camera(oracle_lib, use_dogleg, fov):
+    """Six iterations from wrong camera parameters (pinhole: four, FOV camera: five): summaries, the rig's parameters, poses and
     landmarks (whose rays are re-derived from the reference pixels after every step) follow the oracle,
     and the parameters end close to the ones the scene was rendered with."""
     po = oracle_lib
-    sc, pa, wrong = _intrinsics_scene(outlier_frac=0.0, pixel_sigma=0.3)
+    sc, pa, wrong = _intrinsics_scene(outlier_frac=0.0, pixel_sigma=0.3, fov=fov)
     o, h = _intrinsics_pair(po, sc, pa, wrong, use_dogleg=use_dogleg)
     err0 = np.linalg.norm(wrong - sc.cam_params)
     for it in range(6):
@@ -2011,11 +2074,12 @@ def test_intrinsics_calibration_iterations_track_oracle_and_recover_the_camera(o
 
 
 @pytest.mark.gpu
-def test_intrinsics_calibration_rejected_step_restores_the_parameters(oracle_lib):
+@CAMERA_MODELS
+def test_intrinsics_calibration_rejected_step_restores_the_parameters(oracle_lib, fov):
     """Unlike T_vs the intrinsics ARE restored when a step is rejected (params_backup,
     BundleAdjuster.cpp:1025-1028, 1066, 1099-1102, 1147)."""
     po = oracle_lib
-    sc, pa, wrong = _intrinsics_scene(P=30, L=90, K=6, seed=11)
+    sc, pa, wrong = _intrinsics_scene(P=30, L=90, K=6, seed=11, fov=fov)
     o, h = _intrinsics_pair(po, sc, pa, wrong)
     o.Solve(3)
     h.Solve(3)
@@ -2037,20 +2101,36 @@ def test_calibration_combinations_that_are_refused():
     with pytest.raises(hipapi.HipError):
         eng.set_calibration(4, True)      # the reference wipes the intrinsics columns in this combination
     with pytest.raises(hipapi.HipError):
-        eng.set_calibration(5, False)     # the pinhole model has four parameters
+        eng.set_calibration(6, False)     # no camera model with six parameters
     eng.close()
     with pytest.raises(ValueError):
         adjuster.BundleAdjuster(1, 6, do_tvs=True, calib_size=4)
+    # CalibSize must be the parameter count of camera 0 (parallel_algos.h:115-118 assigns a
+    # 2 x NumParams matrix to a 2 x CalibSize block): SolverError, nothing moved
+    sc = scene.make_scene(12, 30, 4, lm_dim=1, seed=1)
+    for calib_size, fov in ((5, False), (4, True)):
+        cam = np.append(sc.cam_params, FOV_W) if fov else np.asarray(sc.cam_params)
+        h = adjuster.BundleAdjuster(1, 6, calib_size=calib_size)
+        h.Init(hip_options())
+        h.AddCamera(cam)
+        h.add_poses(sc.poses)
+        h.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+        h.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+        h.Solve(1)
+        assert adjuster.RESULT_NAMES[h.summary().result] == "SolverError"
+        assert np.array_equal(h.camera_params(0), cam)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics", "fov"])
 def test_calibration_edge_cases_match_oracle(oracle_lib, kind):
     """Both calibration kinds on a graph with a landmark seen from 150 poses (the two-pass variant of
     the linearisation kernel), duplicate observations, inactive poses and landmarks, and weights:
     reduced system, border, step against the oracle."""
     po = oracle_lib
     sc = scene.make_scene(60, 200, 7, lm_dim=1, seed=123, roll_amp=0.6)
+    if kind == "fov":
+        scene.to_fov_camera(sc, FOV_W)
     rng = np.random.default_rng(4)
     nsel = sc.obs_per_landmark + 1
     z, pose, lm = sc.obs_z.copy(), sc.obs_pose.copy(), sc.obs_lm.copy()
@@ -2068,7 +2148,7 @@ def test_calibration_edge_cases_match_oracle(oracle_lib, kind):
     la = np.ones(sc.num_landmarks, dtype=np.uint8)
     la[[2, 50, 51]] = 0
     t_vs = T_VS_MOUNT
-    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=4)
+    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=len(sc.cam_params))
     objs = []
     for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, apply_results=0, use_triangular_matrices=0)),
                       (adjuster.BundleAdjuster, hip_options(apply_results=0, use_triangular_matrices=0))):
@@ -2093,11 +2173,11 @@ def test_calibration_edge_cases_match_oracle(oracle_lib, kind):
     assert rel_err(h.rhs(), o.rhs()) < 1e-9
     assert rel_err(h.delta_k(), o.delta_k()) < 1e-6 and rel_err(h.delta_p(), o.delta_p()) < 1e-6
     assert rel_err(h.delta_l(), o.delta_l()) < 1e-6
-    assert K == (6 if kind == "tvs" else 4)
+    assert K == {"tvs": 6, "intrinsics": 4, "fov": 5}[kind]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics", "fov"])
 @pytest.mark.parametrize("distributed", [0, 1], ids=["replicated_solve", "distributed_solve"])
 def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
     """Calibration unknowns with the landmarks sharded over three engines (threads + in-process
@@ -2121,8 +2201,10 @@ def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
         sc.landmarks = scene.remount_landmarks(sc, T_VS_MOUNT, t_vs0)
         cam0 = np.asarray(sc.cam_params, dtype=np.float64)
     else:
+        if kind == "fov":
+            scene.to_fov_camera(sc, FOV_W)
         t_vs0 = np.array([0, 0, 0, 0, 0, 0, 1.0])
-        cam0 = np.asarray(sc.cam_params) * np.array([1.02, 0.98, 1.01, 0.99])
+        cam0 = np.asarray(sc.cam_params) * np.array([1.02, 0.98, 1.01, 0.99, 1.03][:len(sc.cam_params)])
     nsel = sc.obs_per_landmark + 1
     keep = np.ones(len(sc.obs_pose), dtype=bool)
     keep[::nsel] = False
@@ -2131,11 +2213,11 @@ def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
     def make(lo, hi):
         sel = keep & (sc.obs_lm >= lo) & (sc.obs_lm < hi)
         eng = hipapi.Engine(1, 6)
-        eng.set_calibration(0 if kind == "tvs" else 4, kind == "tvs")
+        eng.set_calibration(0 if kind == "tvs" else len(cam0), kind == "tvs")
         eng.set_cameras(cam0, t_vs0)
         eng.set_poses(sc.poses, is_active=pa)
         eng.set_landmarks(sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi])
-        if kind == "intrinsics":
+        if kind != "tvs":
             eng.set_landmark_ref_pixels(z_ref[lo:hi])
         eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], sc.obs_lm[sel] - lo)
         eng.finalize()
@@ -2144,7 +2226,10 @@ def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
         return eng
 
     def calib_state(eng):
-        return eng.get_cameras(1)[0] if kind == "tvs" else eng.get_camera_params(1)[0]
+        if kind == "tvs":
+            return eng.get_cameras(1)[0]
+        p = eng.get_camera_params(1)[0]
+        return np.append(p, eng.get_camera_fov(1)[0]) if kind == "fov" else p
 
     L = sc.num_landmarks
     single = make(0, L)
@@ -2179,7 +2264,7 @@ def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
         assert rel_err(calib_state(engs[r]), calib_state(single)) < 1e-9
         assert np.array_equal(calib_state(engs[r]), calib_state(engs[0]))        # every rank moves the camera alike
     # the oracle on the whole scene
-    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=4)
+    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=len(cam0))
     o = po.OracleBundleAdjuster(1, 6, **kw)
     o.Init(gn_options(po))
     o.AddCamera(cam0, t_vs0)
@@ -2200,7 +2285,7 @@ def test_calibration_on_landmark_shards(oracle_lib, kind, distributed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
+@pytest.mark.parametrize("kind", ["tvs", "intrinsics", "fov"])
 def test_calibration_at_config1_scale_matches_oracle(oracle_lib, kind):
     """The self-calibration instantiations at the size of BASELINE.json configs[1] (1k poses / 100k
     landmarks / 1M residuals, a tenth of the poses held fixed): the first Gauss-Newton step
@@ -2216,7 +2301,10 @@ def test_calibration_at_config1_scale_matches_oracle(oracle_lib, kind):
         sc.landmarks = scene.remount_landmarks(sc, ident, t0)
         cam0, kw = np.asarray(sc.cam_params, dtype=np.float64), dict(do_tvs=True)
     else:
-        t0, cam0, kw = ident, np.asarray(sc.cam_params) * np.array([1.01, 0.99, 1.005, 0.995]), dict(calib_size=4)
+        if kind == "fov":
+            scene.to_fov_camera(sc, FOV_W)
+        cam0 = np.asarray(sc.cam_params) * np.array([1.01, 0.99, 1.005, 0.995, 1.01][:len(sc.cam_params)])
+        t0, kw = ident, dict(calib_size=len(cam0))
     objs = []
     for cls, opts in ((po.OracleBundleAdjuster, gn_options(po)), (adjuster.BundleAdjuster, hip_options(write_reduced_camera_matrix=0))):
         b = cls(1, 6, **kw)

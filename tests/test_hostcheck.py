@@ -35,15 +35,26 @@ def hc():
     return ctypes.CDLL(LIB)
 
 
+@pytest.fixture
+def fov_switch(hc):
+    """camera model of the hostcheck calls: back to the pinhole after the test"""
+    yield hc.ba_hostcheck_set_fov
+    hc.ba_hostcheck_set_fov(ctypes.c_double(0.0))
+
+
+@pytest.mark.parametrize("fov", [False, True], ids=["pinhole", "fov_camera"])
 @pytest.mark.parametrize("variant", [1, 0], ids=["proj_linearize", "proj_jacobians"])
 @pytest.mark.parametrize("lm_dim", [1, 3])
-def test_projection_jacobians_of_the_kernels_match_the_oracle(oracle_lib, hc, lm_dim, variant):
+def test_projection_jacobians_of_the_kernels_match_the_oracle(oracle_lib, hc, fov_switch, lm_dim, variant, fov):
     """variant 1: dmath.h proj_linearize — the form k_linearize evaluates (fewer transforms held in
     registers); variant 0: proj_jacobians, the literal closed form.  Both against the oracle's
     2x4 . 4x7 . 7x7 . 7x6 chains."""
     po = oracle_lib
     hc.ba_hostcheck_set_variant(variant)
     sc = scene.make_scene(30, 60, 5, lm_dim=lm_dim, seed=17)
+    if fov:
+        scene.to_fov_camera(sc, 0.93)
+        fov_switch(ctypes.c_double(0.93))
     t_vs = np.array([0.05, -0.02, 0.1, 0.0, 0.0, 0.0, 1.0])
     t_vs[3:] = scene.quat_exp(np.array([0.02, -0.03, 0.01]))
     o = po.OracleBundleAdjuster(lm_dim, 6)
@@ -121,13 +132,18 @@ def test_extrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc):
     assert worst < 1e-11, worst
 
 
-def test_intrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc):
-    """dz_dcam_params (CalibSize 4): dmath.h proj_intrinsics_rows against the oracle's
+@pytest.mark.parametrize("fov", [False, True], ids=["pinhole", "fov_camera"])
+def test_intrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc, fov_switch, fov):
+    """dz_dcam_params (CalibSize 4 / 5): dmath.h proj_intrinsics_rows against the oracle's
     -dTransfer_dparams(T_sw_m T_ws_r, z_ref, x_s(3)) (parallel_algos.h:115-118)."""
     po = oracle_lib
     sc = scene.make_scene(30, 60, 5, lm_dim=1, seed=19)
+    if fov:
+        scene.to_fov_camera(sc, 0.93)
+        fov_switch(ctypes.c_double(0.93))
+    K = 5 if fov else 4
     t_vs = np.concatenate([[0.05, -0.02, 0.1], scene.quat_exp(np.array([0.2, -0.3, 0.1]))])
-    o = po.OracleBundleAdjuster(1, 6, calib_size=4)
+    o = po.OracleBundleAdjuster(1, 6, calib_size=K)
     o.Init(gn_options(po, apply_results=0))
     o.AddCamera(sc.cam_params, t_vs)
     o.add_poses(sc.poses)
@@ -150,8 +166,8 @@ def test_intrinsics_jacobian_of_the_kernels_matches_the_oracle(oracle_lib, hc):
             _dp(np.asarray(sc.poses[pm], dtype=np.float64)), _dp(t_vs),
             _dp(np.asarray(sc.poses[pr], dtype=np.float64)), _dp(t_vs), _dp(jk))
         jk = jk.reshape(2, 6)
-        assert np.all(jk[:, 4:] == 0)
-        worst = max(worst, rel_err(jk[:, :4], jk_o[rid]))
+        assert np.all(jk[:, K:] == 0)
+        worst = max(worst, rel_err(jk[:, :K], jk_o[rid]))
     assert len(acc) > 100 and np.abs(jk_o).max() > 0.1
     assert worst < 1e-11, worst
 
