@@ -1,5 +1,6 @@
 """Randomised parity sweep of the self-calibration instantiations (scratch soak, not part of the suite):
-small scenes with random sizes, calibration kind (T_vs | pinhole parameters), PoseSize 6 | 15 (with IMU),
+small scenes with random sizes, calibration kind (T_vs | pinhole parameters | the five parameters of a FOV
+camera), PoseSize 6 | 15 (with IMU),
 dogleg on/off, random fixed poses / inactive landmarks, random wrong initial calibration; engine vs
 oracle over 3 iterations: result codes, errors, the camera, poses, landmarks."""
 import os, sys
@@ -15,7 +16,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 for trial in range(N):
     P = int(rng.integers(12, 60)); L = int(rng.integers(30, 250)); K = int(rng.integers(3, 8))
-    kind = str(rng.choice(["tvs", "intrinsics"])); pose_dim = int(rng.choice([6, 6, 15])); dog = int(rng.integers(0, 2))
+    kind = str(rng.choice(["tvs", "intrinsics", "fov"])); pose_dim = int(rng.choice([6, 6, 15])); dog = int(rng.integers(0, 2))
     seed = int(rng.integers(1, 10000))
     try:
         sc = scene.make_scene(P, L, K, lm_dim=1, seed=seed, roll_amp=0.0 if pose_dim == 15 else 0.6)
@@ -38,8 +39,11 @@ for trial in range(N):
         t0 = po.exp_decoupled(mount, rng.normal(0, 0.02, 6))
         sc.landmarks = scene.remount_landmarks(sc, mount, t0)
     else:
-        cam0 = cam0 * (1.0 + rng.normal(0, 0.02, 4))
-    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=4)
+        if kind == "fov":
+            scene.to_fov_camera(sc, float(rng.uniform(0.3, 1.2)))
+        cam0 = np.asarray(sc.cam_params, dtype=np.float64)
+        cam0 = cam0 * (1.0 + rng.normal(0, 0.02, len(cam0)))
+    kw = dict(do_tvs=True) if kind == "tvs" else dict(calib_size=len(cam0))
     objs = []
     for cls in (po.OracleBundleAdjuster, adjuster.BundleAdjuster):
         if cls is po.OracleBundleAdjuster:
