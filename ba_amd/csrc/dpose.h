@@ -750,8 +750,6 @@ BA_HD void imu_residual(const double* p1, const double* p2, const double* meas, 
     for (int e = w->lane; e < 160; e += 64) w->lds[e] = 0.0;  // cov | dpose_db
     __syncthreads();
   }
-#else
-  const bool lds_acc = false;
 #endif
   for (int i = 1; i < nmeas; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__)

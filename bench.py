@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--obs-per-landmark", type=int, default=10)
     ap.add_argument("--lm-dim", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--live-pmc", action="store_true",
+                    help="after the timed region, run the two rocprofv3 --pmc passes of this configuration as child "
+                         "processes (scratch/pmc_traffic.py; minutes) and report THEIR traffic instead of the committed summary")
     ap.add_argument("--no-api", action="store_true", help="skip the api_solve_ms pass of configs 1 / 3")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -401,6 +404,21 @@ def main():
         # rocprofv3 --pmc passes of this same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
         # per launch), null if no summary exists for this configuration
         pmc, pmc_file = newest_pmc(args.config)
+        if args.live_pmc and world == 1 and not api_driver:
+            # this process has released its engine; the passes are separate processes under rocprofv3
+            import subprocess
+            live = os.path.join(ROOT, "gpurun_out", "r02_pmc_traffic_cfg%d.json" % args.config)
+            if os.path.exists(live):
+                os.remove(live)
+            os.makedirs(os.path.dirname(live), exist_ok=True)
+            log("PMC passes (FETCH_SIZE, WRITE_SIZE) as child processes ...")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scratch", "pmc_traffic.py"), str(args.config)],
+                               stdout=sys.stderr)
+            try:
+                with open(live) as f:
+                    pmc, pmc_file = json.load(f)["kernels"], "measured by this run (--live-pmc: " + os.path.relpath(live, ROOT) + ")"
+            except (OSError, KeyError, ValueError):
+                log("PMC passes failed (rc %d); the committed summary is reported" % r.returncode)
         # 128x128 blocks on trailing matrices of >= 128 tiles, the capped 64-tile kernel below
         bulk_kernel = "k_update128<false>" if n >= 128 * 64 else "k_update2<true>"
 
