@@ -199,7 +199,7 @@ struct Impl : Iface {
 };
 
 Iface* make(int lm, int pd, int do_tvs, int calib_size) {
-  // CalibSize 4 = the pinhole parameters of camera 0 (LmSize 1, without DoTvs)
+  // CalibSize 4 = the pinhole parameters of a LinearCamera 0 (LmSize 1, without DoTvs)
   if (calib_size == 4 && !do_tvs && lm == 1) {
     if (pd == 6) return new Impl<1, 6, false, 4>();
     if (pd == 9) return new Impl<1, 9, false, 4>();

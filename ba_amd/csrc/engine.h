@@ -49,8 +49,8 @@ struct Engine {
   // Calibration unknowns behind the pose unknowns of the reduced system (ba_hip_set_calibration):
   // 0, or 6 = the decoupled update of T_vs of camera 0 (the reference's DoTvs instantiations).
   int calib_dim = 0;
-  // calib_tvs: the six unknowns are T_vs; otherwise (calib_dim == 4) the pinhole parameters
-  // (fx, fy, u0, v0) of camera 0 (CalibSize = 4; BundleAdjuster.cpp:46-69, parallel_algos.h:114-118)
+  // calib_tvs: the six unknowns are T_vs; otherwise (calib_dim == 4 | 5) the parameters of camera 0 — (fx, fy,
+  // u0, v0) of a LinearCamera, (fx, fy, u0, v0, w) of a FovCamera (CalibSize; BundleAdjuster.cpp:46-69, parallel_algos.h:114-118)
   bool calib_tvs = false;
   std::vector<double> cam_params_prev;   // params_backup of SolveInternal (:1025-1028): restored by a rollback
   std::vector<double> cam_w_prev;        // ... its fifth entry for a FOV camera

@@ -661,6 +661,83 @@ int ba_hip_integrate_imu(const double t_wp7[7], const double v_w3[3], const doub
   return 0;
 }
 
+// The same integration with the Jacobians of the reference's signature (Types.h:662-738): dpose_db
+// (10 x 6, over the gyro / accelerometer biases), dpose_dpose (10 x 10, over the start state
+// [t q v]) and the covariance c_res (10 x 10, in/out: C <- F C F^T + G R G^T per step) — formed, as in
+// the reference, only when one of the two Jacobians is asked for AND the noise diagonal r6 is given.
+int ba_hip_integrate_imu_jacobians(const double t_wp7[7], const double v_w3[3], const double bg3[3],
+                                   const double ba3[3], const double g3[3], const double* meas7, uint32_t nmeas,
+                                   const double r6[6], double* states10, double* dpose_db60,
+                                   double* dpose_dpose100, double* c_res100) {
+  if (!t_wp7 || !v_w3 || !bg3 || !ba3 || !g3 || !states10 || (nmeas && !meas7)) return -1;
+  bad::ImuState s;
+  for (int i = 0; i < 3; ++i) { s.t[i] = t_wp7[i]; s.v[i] = v_w3[i]; }
+  for (int i = 0; i < 4; ++i) s.q[i] = t_wp7[3 + i];
+  auto put = [&](uint32_t k) {
+    double* o = states10 + 10 * (size_t)k;
+    for (int i = 0; i < 3; ++i) { o[i] = s.t[i]; o[7 + i] = s.v[i]; }
+    for (int i = 0; i < 4; ++i) o[3 + i] = s.q[i];
+  };
+  put(0);
+  bad::DM<10, 6> db, dy_db;
+  bad::DM<10, 10> dd, dy_dy, cov;
+  db.zero();
+  dd.identity();
+  const bool jac = (dpose_db60 || dpose_dpose100) && r6;
+  if (c_res100) for (int i = 0; i < 100; ++i) cov.m[i] = c_res100[i];
+  for (uint32_t i = 1; i < nmeas; ++i) {
+    const double* z0 = meas7 + 7 * (size_t)(i - 1);
+    const double* z1 = meas7 + 7 * (size_t)i;
+    if (jac) {
+      s = bad::integrate_imu(s, z0, z1, bg3, ba3, g3, true, &dy_db, &dy_dy, c_res100 ? &cov : nullptr, r6);
+      db = bad::madd(dy_db, bad::mm(dy_dy, db));  // Types.h:712-714
+      dd = bad::mm(dy_dy, dd);                    // Types.h:716-718
+    } else {
+      s = bad::integrate_imu(s, z0, z1, bg3, ba3, g3, false, nullptr, nullptr, nullptr, nullptr);
+    }
+    put(i);
+  }
+  if (dpose_db60) for (int i = 0; i < 60; ++i) dpose_db60[i] = db.m[i];
+  if (dpose_dpose100) for (int i = 0; i < 100; ++i) dpose_dpose100[i] = dd.m[i];
+  if (c_res100 && jac) for (int i = 0; i < 100; ++i) c_res100[i] = cov.m[i];
+  return 0;
+}
+
+// ImuResidualT::GetPoseDerivative (Types.h:376-416): k = d/dt [t; rotation vector; v] of the state at
+// time z_start.time + dt between two samples, with dk_db (9 x 6) and dk_dx (9 x 10), both optional
+int ba_hip_imu_pose_derivative(const double state10[10], const double g3[3], const double z_start7[7],
+                               const double z_end7[7], const double bg3[3], const double ba3[3], double dt,
+                               double k9[9], double* dk_db54, double* dk_dx90) {
+  if (!state10 || !g3 || !z_start7 || !z_end7 || !bg3 || !ba3 || !k9) return -1;
+  bad::ImuState s;
+  for (int i = 0; i < 3; ++i) { s.t[i] = state10[i]; s.v[i] = state10[7 + i]; }
+  for (int i = 0; i < 4; ++i) s.q[i] = state10[3 + i];
+  bad::DM<9, 6> a;
+  bad::DM<9, 10> b;
+  bad::pose_derivative(s, g3, z_start7, z_end7, bg3, ba3, dt, k9, dk_db54 ? &a : nullptr, dk_dx90 ? &b : nullptr);
+  if (dk_db54) for (int i = 0; i < 54; ++i) dk_db54[i] = a.m[i];
+  if (dk_dx90) for (int i = 0; i < 90; ++i) dk_dx90[i] = b.m[i];
+  return 0;
+}
+
+// ImuResidualT::IntegratePose (Types.h:324-373): y = state advanced by k * dt (q <- exp(k_w dt) q, not
+// renormalised), with dy_dk (10 x 9) and the quaternion block dy_dy (4 x 4), both optional
+int ba_hip_imu_integrate_pose(const double state10[10], const double k9[9], double dt, double out10[10],
+                              double* dy_dk90, double* dy_dy16) {
+  if (!state10 || !k9 || !out10) return -1;
+  bad::ImuState s;
+  for (int i = 0; i < 3; ++i) { s.t[i] = state10[i]; s.v[i] = state10[7 + i]; }
+  for (int i = 0; i < 4; ++i) s.q[i] = state10[3 + i];
+  bad::DM<10, 9> a;
+  bad::DM<4, 4> b;
+  const bad::ImuState y = bad::integrate_pose(s, k9, dt, dy_dk90 ? &a : nullptr, dy_dy16 ? &b : nullptr);
+  for (int i = 0; i < 3; ++i) { out10[i] = y.t[i]; out10[7 + i] = y.v[i]; }
+  for (int i = 0; i < 4; ++i) out10[3 + i] = y.q[i];
+  if (dy_dk90) for (int i = 0; i < 90; ++i) dy_dk90[i] = a.m[i];
+  if (dy_dy16) for (int i = 0; i < 16; ++i) dy_dy16[i] = b.m[i];
+  return 0;
+}
+
 int ba_hip_set_imu_noise(ba_hip_engine* h, const double r6[6], const double rb6[6]) {
   ENG(h);
   e->prob.imu_noise.clear();
@@ -1177,7 +1254,7 @@ int ba_hip_get_proj_jacobians(ba_hip_engine* h, double* j_meas12, double* j_ref1
   return 0;
 }
 
-// 6 doubles per row: with CalibSize 4 the last two columns are zero
+// 6 doubles per row: with CalibSize 4 / 5 the last two / the last column are zero
 int ba_hip_get_calib_jacobians(ba_hip_engine* h, double* j_k12) {
   ENG(h);
   NEED_FINAL();

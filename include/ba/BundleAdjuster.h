@@ -125,6 +125,8 @@ class BundleAdjuster {
   typedef LandmarkT<Scalar, LmSize> Landmark;
   typedef ProjectionResidualT<Scalar, LmSize> ProjectionResidual;
   typedef ImuMeasurementT<Scalar> ImuMeasurement;
+  typedef UnaryResidualT<Scalar> UnaryResidual;    // reference :140
+  typedef BinaryResidualT<Scalar> BinaryResidual;  // reference :141
   typedef ImuResidualT<Scalar, kPoseDim, kPoseDim> ImuResidual;  // reference :142
   typedef ImuPoseT<Scalar> ImuPose;  // reference :144
   typedef ImuCalibrationT<Scalar> ImuCalibration;
@@ -132,6 +134,10 @@ class BundleAdjuster {
   typedef ba::Vector3t Vector3t;
   typedef ba::Vector4t Vector4t;
   typedef ba::Vector6t Vector6t;
+  typedef ba::Vector7t Vector7t;
+  typedef ba::Vector9t Vector9t;
+  typedef std::vector<Scalar> VectorXt;  // reference :152 (Eigen dynamic vector: per-pose camera parameters)
+  typedef ba::MatX MatrixXt;             // reference :153
   typedef ba::Matrix3t Matrix3t;
   typedef ba::SE3 SE3t;
 
@@ -764,7 +770,7 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::WriteReducedCam
   if (fp) std::fclose(fp);
   if (fl) std::fclose(fl);
   if (fr) std::fclose(fr);
-  if (kCalibDim > 0) {  // with CalibSize 4 the last two of the six columns are zero
+  if (kCalibDim > 0) {  // with CalibSize 4 / 5 the last two / the last of the six columns are zero
     std::vector<double> jk(12 * O), jtj(36, 0.0);
     if (!Check(ba_hip_get_calib_jacobians(engine_, jk.data()), "ba_hip_get_calib_jacobians")) return;
     if (FILE* f = std::fopen("j_kpr.txt", "w")) {

@@ -67,6 +67,8 @@ typedef Mat<2> Vector2t;
 typedef Mat<3> Vector3t;
 typedef Mat<4> Vector4t;
 typedef Mat<6> Vector6t;
+typedef Mat<7> Vector7t;
+typedef Mat<9> Vector9t;
 typedef Mat<3, 3> Matrix3t;
 typedef Mat<6, 6> Matrix6t;
 
@@ -292,6 +294,33 @@ struct LandmarkT {
   bool is_active = true, is_reliable = true;
 };
 
+// reference Types.h:246-253: the common head of every residual type
+template <typename Scalar, int kParamSize>
+struct ResidualT {
+  uint32_t residual_id = 0, residual_offset = 0;
+  Scalar mahalanobis_distance = 0;
+  Scalar weight = 1, orig_weight = 1;
+};
+// reference Types.h:255-266 / 268-280: the unary prior and the binary pose-pose constraint as the Add*
+// calls store them (measurement, information, its square root); the Jacobian blocks dz_dx* and the
+// residual vector live only on the device
+template <typename Scalar = double>
+struct UnaryResidualT : public ResidualT<Scalar, 6> {
+  static const uint32_t kResSize = 6;
+  uint32_t pose_id = 0;
+  SE3 t_wp;
+  Matrix6t cov_inv, cov_inv_sqrt;
+  bool use_rotation = true;
+};
+template <typename Scalar = double>
+struct BinaryResidualT : public ResidualT<Scalar, 6> {
+  static const uint32_t kResSize = 6;
+  uint32_t x1_id = 0, x2_id = 0;
+  SE3 t_12;
+  Matrix6t cov_inv, cov_inv_sqrt;
+  bool use_rotation = true;
+};
+
 // reference Types.h:246-253, 282-298: what callers read back of a projection residual (the
 // cached Jacobian blocks dz_dx_meas / dz_dx_ref / dz_dlm live only on the device)
 template <typename Scalar = double, int LmSize = 1>
@@ -337,6 +366,15 @@ struct ImuPoseT {
 extern "C" int ba_hip_integrate_imu(const double t_wp7[7], const double v_w3[3], const double bg3[3],
                                     const double ba3[3], const double g3[3], const double* meas7,
                                     uint32_t nmeas, double* states10);
+extern "C" int ba_hip_integrate_imu_jacobians(const double t_wp7[7], const double v_w3[3], const double bg3[3],
+                                              const double ba3[3], const double g3[3], const double* meas7,
+                                              uint32_t nmeas, const double r6[6], double* states10,
+                                              double* dpose_db60, double* dpose_dpose100, double* c_res100);
+extern "C" int ba_hip_imu_pose_derivative(const double state10[10], const double g3[3], const double z_start7[7],
+                                          const double z_end7[7], const double bg3[3], const double ba3[3], double dt,
+                                          double k9[9], double* dk_db54, double* dk_dx90);
+extern "C" int ba_hip_imu_integrate_pose(const double state10[10], const double k9[9], double dt, double out10[10],
+                                         double* dy_dk90, double* dy_dy16);
 
 // reference Types.h:300-321, the host-visible part (the Jacobian / covariance blocks dz_dx1, dz_dx2,
 // cov_inv ... live only on the device)
@@ -346,13 +384,16 @@ struct ImuResidualT {
   typedef ImuPoseT<Scalar> ImuPose;
   static const uint32_t kResSize = ResidualSize;
 
-  // reference Types.h:643-738: RK4 integration of the samples from `pose` (the Jacobian outputs of
-  // the reference's signature are device-only here); `poses` receives the start state and the
-  // state at every later sample.  Runs on the host with the code the device kernels use
-  // (ba_hip_integrate_imu in libba_hip.so).
+  // reference Types.h:643-738: RK4 integration of the samples from `pose`; `poses` receives the start
+  // state and the state at every later sample.  The Jacobian outputs of the reference's signature:
+  // dpose_db (state [t q v] over the two biases), dpose_dpose (over the start state), the covariance
+  // c_res (in/out) with the noise diagonal r — formed, as there, only when a Jacobian is asked for and
+  // r is given.  Runs on the host with the code the device kernels use (libba_hip.so).
   static ImuPose IntegrateResidual(const ImuPose& pose, const std::vector<ImuMeasurement>& measurements,
                                    const Vector3t& bg, const Vector3t& ba, const Vector3t& g,
-                                   std::vector<ImuPose>& poses) {
+                                   std::vector<ImuPose>& poses, Mat<10, 6>* dpose_db = nullptr,
+                                   Mat<10, 10>* dpose_dpose = nullptr, Mat<10, 10>* c_res = nullptr,
+                                   const Vector6t* r = nullptr) {
     const size_t n = measurements.size();
     std::vector<double> m(7 * std::max<size_t>(n, 1)), st(10 * std::max<size_t>(n, 1));
     for (size_t i = 0; i < n; ++i) {
@@ -363,7 +404,15 @@ struct ImuResidualT {
     pose.t_wp.to7(t7);
     const double v[3] = {pose.v_w[0], pose.v_w[1], pose.v_w[2]}, b1[3] = {bg[0], bg[1], bg[2]},
                  b2[3] = {ba[0], ba[1], ba[2]}, gg[3] = {g[0], g[1], g[2]};
-    ba_hip_integrate_imu(t7, v, b1, b2, gg, m.data(), (uint32_t)n, st.data());
+    if (dpose_db || dpose_dpose) {
+      double r6[6];
+      if (r) for (int k = 0; k < 6; ++k) r6[k] = (*r)[k];
+      ba_hip_integrate_imu_jacobians(t7, v, b1, b2, gg, m.data(), (uint32_t)n, r ? r6 : nullptr, st.data(),
+                                     dpose_db ? dpose_db->data() : nullptr,
+                                     dpose_dpose ? dpose_dpose->data() : nullptr, c_res ? c_res->data() : nullptr);
+    } else {
+      ba_hip_integrate_imu(t7, v, b1, b2, gg, m.data(), (uint32_t)n, st.data());
+    }
     poses.clear();
     const size_t rows = std::max<size_t>(n, 1);
     for (size_t i = 0; i < rows; ++i) {
@@ -378,16 +427,61 @@ struct ImuResidualT {
   }
   static ImuPose IntegrateResidual(const PoseT<Scalar>& pose, const std::vector<ImuMeasurement>& measurements,
                                    const Vector3t& bg, const Vector3t& ba, const Vector3t& g,
-                                   std::vector<ImuPose>& poses) {
-    return IntegrateResidual(ImuPose(pose), measurements, bg, ba, g, poses);
+                                   std::vector<ImuPose>& poses, Mat<10, 6>* dpose_db = nullptr,
+                                   Mat<10, 10>* dpose_dpose = nullptr, Mat<10, 10>* c_res = nullptr,
+                                   const Vector6t* r = nullptr) {
+    return IntegrateResidual(ImuPose(pose), measurements, bg, ba, g, poses, dpose_db, dpose_dpose, c_res, r);
   }
-  // reference Types.h:419-643, state only: one RK4 step between two samples
+  // reference Types.h:419-643: one RK4 step between two samples; dy_db / dy_dy0 are the Jacobians of the
+  // step over the biases / the start state (formed when both are given; c_prior with r: the covariance)
   static ImuPose IntegrateImu(const ImuPose& pose, const ImuMeasurement& z_start, const ImuMeasurement& z_end,
-                              const Vector3t& bg, const Vector3t& ba, const Vector3t& g) {
+                              const Vector3t& bg, const Vector3t& ba, const Vector3t& g,
+                              Mat<10, 6>* dy_db = nullptr, Mat<10, 10>* dy_dy0 = nullptr,
+                              Mat<10, 10>* c_prior = nullptr, const Vector6t* r = nullptr) {
     std::vector<ImuMeasurement> two = {z_start, z_end};
     std::vector<ImuPose> out;
+    if (dy_db && dy_dy0) {
+      // the covariance update needs a noise matrix; without one the Jacobians alone (zero noise)
+      const Vector6t r0;
+      return IntegrateResidual(pose, two, bg, ba, g, out, dy_db, dy_dy0, r ? c_prior : nullptr, r ? r : &r0);
+    }
     return IntegrateResidual(pose, two, bg, ba, g, out);
   }
+  // reference Types.h:376-416: k = [v; R (w + b_g); R (a + b_a) - g] with the two samples interpolated at
+  // z_start.time + dt; dk_db (9 x 6), dk_dx (9 x 10 over [t q v]) optional
+  static Mat<9, 1> GetPoseDerivative(const ImuPose& pose, const Vector3t& g_w, const ImuMeasurement& z_start,
+                                     const ImuMeasurement& z_end, const Vector3t& bg, const Vector3t& ba,
+                                     const Scalar dt, Mat<9, 6>* dk_db = nullptr, Mat<9, 10>* dk_dx = nullptr) {
+    double s10[10], z0[7], z1[7], k[9];
+    State10(pose, s10);
+    for (int i = 0; i < 3; ++i) { z0[i] = z_start.w[i]; z0[3 + i] = z_start.a[i]; z1[i] = z_end.w[i]; z1[3 + i] = z_end.a[i]; }
+    z0[6] = z_start.time; z1[6] = z_end.time;
+    const double gg[3] = {g_w[0], g_w[1], g_w[2]}, b1[3] = {bg[0], bg[1], bg[2]}, b2[3] = {ba[0], ba[1], ba[2]};
+    ba_hip_imu_pose_derivative(s10, gg, z0, z1, b1, b2, (double)dt, k, dk_db ? dk_db->data() : nullptr,
+                               dk_dx ? dk_dx->data() : nullptr);
+    Mat<9, 1> out;
+    for (int i = 0; i < 9; ++i) out[i] = k[i];
+    return out;
+  }
+  // reference Types.h:324-373: the state advanced by k * dt (rotation: q <- exp(k_w dt) q, not renormalised);
+  // pdy_dk (10 x 9) and the quaternion block pdy_dy (4 x 4) optional
+  static ImuPose IntegratePose(const ImuPose& pose, const Mat<9, 1>& k, const Scalar dt, Mat<10, 9>* pdy_dk = nullptr,
+                               Mat<4, 4>* pdy_dy = nullptr) {
+    double s10[10], k9[9], o[10];
+    State10(pose, s10);
+    for (int i = 0; i < 9; ++i) k9[i] = k[i];
+    ba_hip_imu_integrate_pose(s10, k9, (double)dt, o, pdy_dk ? pdy_dk->data() : nullptr, pdy_dy ? pdy_dy->data() : nullptr);
+    ImuPose y = pose;
+    y.t_wp = SE3::from7(o);  // the raw quaternion, as the reference keeps it (memcpy, Types.h:338-339)
+    for (int i = 0; i < 3; ++i) y.v_w[i] = o[7 + i];
+    return y;
+  }
+ private:
+  static void State10(const ImuPose& pose, double* s10) {
+    pose.t_wp.to7(s10);
+    for (int i = 0; i < 3; ++i) s10[7 + i] = pose.v_w[i];
+  }
+ public:
 
   uint32_t residual_id = 0, residual_offset = 0;
   uint32_t pose1_id = 0, pose2_id = 0;

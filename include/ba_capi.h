@@ -111,7 +111,7 @@ void ba_adjuster_get_timers(const ba_adjuster* a, ba_hip_timers* t);
 ba_hip_engine* ba_adjuster_engine(ba_adjuster* a);
 /* rig()->cameras_[cam_id]->Pose(): with do_tvs camera 0 moves with every applied step */
 void ba_adjuster_get_camera_pose(const ba_adjuster* a, uint32_t cam_id, double t_vs[7]);
-/* rig()->cameras_[cam_id]->GetParams(): with calib_size 4 camera 0's move with every applied step */
+/* rig()->cameras_[cam_id]->GetParams(): with calib_size 4 / 5 camera 0's move with every applied step */
 void ba_adjuster_get_camera_params(const ba_adjuster* a, uint32_t cam_id, double params[4]);
 /* the fifth parameter w of a FovCamera (0 for a LinearCamera) */
 double ba_adjuster_get_camera_fov(const ba_adjuster* a, uint32_t cam_id);

@@ -181,6 +181,25 @@ int ba_hip_set_imu_residuals(ba_hip_engine* e, uint32_t n, const uint32_t* pose1
  * later sample (the reference's `poses` vector).  Returns 0, or -1 on a NULL argument. */
 int ba_hip_integrate_imu(const double t_wp7[7], const double v_w3[3], const double bg3[3], const double ba3[3],
                          const double g3[3], const double* meas7, uint32_t nmeas, double* states10);
+/* The same with the Jacobian outputs of the reference's signature (Types.h:662-738), all optional:
+ * dpose_db60 (10 x 6, row-major: state [t q v] over the gyro / accelerometer biases), dpose_dpose100
+ * (10 x 10, over the start state) and the covariance c_res100 (10 x 10, in/out: C <- F C F^T + G R G^T
+ * per step, r6 = diagonal of R).  As in the reference they are formed only when one of the two
+ * Jacobians is asked for and r6 is not NULL. */
+int ba_hip_integrate_imu_jacobians(const double t_wp7[7], const double v_w3[3], const double bg3[3],
+                                   const double ba3[3], const double g3[3], const double* meas7, uint32_t nmeas,
+                                   const double r6[6], double* states10, double* dpose_db60,
+                                   double* dpose_dpose100, double* c_res100);
+/* ImuResidualT::GetPoseDerivative (Types.h:376-416): k9 = [v; R (w + b_g); R (a + b_a) - g] of the
+ * state10 = [t(3) q(4) v(3)] with the two samples interpolated at z_start.time + dt; dk_db54 (9 x 6)
+ * and dk_dx90 (9 x 10) may be NULL.  ImuResidualT::IntegratePose (Types.h:324-373): out10 = the state
+ * advanced by k9 * dt (q <- exp(k_w dt) q, not renormalised); dy_dk90 (10 x 9) and the quaternion
+ * block dy_dy16 (4 x 4) may be NULL.  Host code, no GPU. */
+int ba_hip_imu_pose_derivative(const double state10[10], const double g3[3], const double z_start7[7],
+                               const double z_end7[7], const double bg3[3], const double ba3[3], double dt,
+                               double k9[9], double* dk_db54, double* dk_dx90);
+int ba_hip_imu_integrate_pose(const double state10[10], const double k9[9], double dt, double out10[10],
+                              double* dy_dk90, double* dy_dy16);
 /* ImuCalibrationT::r and r_b (Types.h:112-159): diagonal of the IMU measurement noise (gyro x3,
  * accelerometer x3) and of the bias random walk, as parallel_algos.h:204,288 read them from imu_.
  * NULL pointers: derive both from the sigmas of ba_hip_options (what Init() does,

@@ -1948,5 +1948,19 @@ void orc_math_integrate(const double pose_t[7], const double v[3], const double*
   if (dpose_db) memcpy(dpose_db, db.a, 60 * 8);
   if (c) memcpy(c, cc.a, 100 * 8);
 }
+// the same with dpose_dpose (10 x 10 over the start state; Types.h:716-718)
+void orc_math_integrate_jacobians(const double pose_t[7], const double v[3], const double* meas, uint32_t n,
+                                  const double bg[3], const double ba[3], const double g[3], const double r6[6],
+                                  double* dpose_db, double* dpose_dpose, double* c) {
+  ImuPose start; start.t_wp = se3_from7(pose_t); start.time = 0;
+  Vec3 vbg, vba, vg; Vec6 r;
+  for (int i = 0; i < 3; ++i) { start.v_w[i] = v[i]; vbg[i] = bg[i]; vba[i] = ba[i]; vg[i] = g[i]; }
+  for (int i = 0; i < 6; ++i) r[i] = r6[i];
+  Mat<10, 6> db; Mat<10, 10> dd, cc;
+  IntegrateResidual(start, meas_from(meas, n), vbg, vba, vg, &db, &dd, &cc, &r);
+  memcpy(dpose_db, db.a, 60 * 8);
+  memcpy(dpose_dpose, dd.a, 100 * 8);
+  memcpy(c, cc.a, 100 * 8);
+}
 
 }  // extern "C"

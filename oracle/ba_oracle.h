@@ -187,6 +187,10 @@ void orc_math_integrate(const double pose_t[7], const double v[3], const double*
                         uint32_t n, const double bg[3], const double ba[3],
                         const double g[3], const double r6[6], double out_t[7],
                         double out_v[3], double* dpose_db_10x6, double* c_10x10);
+/* the same integration returning dpose_db (10x6), dpose_dpose (10x10, Types.h:716-718) and the covariance */
+void orc_math_integrate_jacobians(const double pose_t[7], const double v[3], const double* meas, uint32_t n,
+                                  const double bg[3], const double ba[3], const double g[3], const double r6[6],
+                                  double* dpose_db, double* dpose_dpose, double* c);
 
 #ifdef __cplusplus
 }

@@ -460,6 +460,16 @@ def integrate(pose_t, v, meas, bg, ba, g, r6=None, jac=False):
     return (out_t, out_v, db, c) if jac else (out_t, out_v)
 
 
+def integrate_jacobians(pose_t, v, meas, bg, ba, g, r6):
+    """dpose_db (10x6), dpose_dpose (10x10) and the covariance of IntegrateResidual (Types.h:662-738)."""
+    pose_t, v, meas, bg, ba, g, r = map(_d, (pose_t, v, meas, bg, ba, g, r6))
+    meas = meas.reshape(-1, 7)
+    db, dd, c = np.zeros((10, 6)), np.zeros((10, 10)), np.zeros((10, 10))
+    lib().orc_math_integrate_jacobians(_dp(pose_t), _dp(v), _dp(meas), meas.shape[0], _dp(bg), _dp(ba), _dp(g),
+                                       _dp(r), _dp(db), _dp(dd), _dp(c))
+    return db, dd, c
+
+
 def transfer(params, t_ba, pix, rho, jac=False):
     """Transfer(T_ba, pix, rho) and (jac) its Jacobian w.r.t. the camera parameters: 2x4 for the
     pinhole (fx, fy, u0, v0), 2x5 for the FOV camera (fx, fy, u0, v0, w)."""

@@ -34,6 +34,47 @@ int main() {
   // the bias is ADDED to the reading: -1 along x cancels the acceleration
   const BA::ImuPose biased = BA::ImuResidual::IntegrateResidual(start, meas, zero, ba::Vector3t({-1.0, 0.0, 0.0}), g, poses);
   CHECK(std::fabs(biased.v_w[0] - 0.5) < 1e-12);
+  // the Jacobian outputs of the reference's signatures (Types.h:419-738): bias Jacobian against a finite
+  // difference of the integration itself, IntegrateImu's step Jacobians chained by hand == IntegrateResidual's
+  {
+    ba::Mat<10, 6> dpose_db;
+    ba::Mat<10, 10> dpose_dpose, c_res;
+    ba::Vector6t r;
+    for (int i = 0; i < 6; ++i) r[i] = i < 3 ? 1e-4 : 1e-2;
+    std::vector<BA::ImuPose> tmp;
+    const BA::ImuPose e0 = BA::ImuResidual::IntegrateResidual(start, meas, zero, zero, g, tmp, &dpose_db, &dpose_dpose, &c_res, &r);
+    CHECK(e0.t_wp.t[0] == end.t_wp.t[0] && e0.v_w[0] == end.v_w[0]);
+    const double h = 1e-6;
+    const BA::ImuPose ep = BA::ImuResidual::IntegrateResidual(start, meas, zero, ba::Vector3t({h, 0.0, 0.0}), g, tmp);
+    const BA::ImuPose em = BA::ImuResidual::IntegrateResidual(start, meas, zero, ba::Vector3t({-h, 0.0, 0.0}), g, tmp);
+    CHECK(std::fabs((ep.t_wp.t[0] - em.t_wp.t[0]) / (2 * h) - dpose_db(0, 3)) < 1e-6);   // d t_x / d b_a,x = T^2 / 2
+    CHECK(std::fabs(dpose_db(0, 3) - 0.5 * T * T) < 1e-9 && std::fabs(dpose_db(7, 3) - T) < 1e-9);
+    CHECK(std::fabs(dpose_dpose(0, 7) - T) < 1e-12 && dpose_dpose(0, 0) == 1.0);          // d t / d v0 = T
+    CHECK(c_res(0, 0) > 0 && c_res(7, 7) > 0 && std::fabs(c_res(0, 7) - c_res(7, 0)) < 1e-15);
+    ba::Mat<10, 6> db, dy_db;
+    ba::Mat<10, 10> dy_dy;
+    BA::ImuPose q = start;
+    for (size_t i = 1; i < meas.size(); ++i) {
+      q = BA::ImuResidual::IntegrateImu(q, meas[i - 1], meas[i], zero, zero, g, &dy_db, &dy_dy);
+      ba::Mat<10, 6> nxt;
+      for (int rr = 0; rr < 10; ++rr)
+        for (int c = 0; c < 6; ++c) {
+          double sum = 0;
+          for (int k2 = 0; k2 < 10; ++k2) sum += dy_dy(rr, k2) * db(k2, c);
+          nxt(rr, c) = dy_db(rr, c) + sum;
+        }
+      db = nxt;
+    }
+    double worst = 0;
+    for (int rr = 0; rr < 10; ++rr)
+      for (int c = 0; c < 6; ++c) worst = std::fmax(worst, std::fabs(db(rr, c) - dpose_db(rr, c)));
+    CHECK(worst < 1e-12);
+    // GetPoseDerivative / IntegratePose: one explicit Euler step of the model
+    const ba::Mat<9, 1> k = BA::ImuResidual::GetPoseDerivative(start, g, meas[0], meas[1], zero, zero, 0.0);
+    CHECK(k[0] == 0.5 && std::fabs(k[6] - 1.0) < 1e-12 && std::fabs(k[8]) < 1e-12 && k[3] == 0.0);
+    const BA::ImuPose y = BA::ImuResidual::IntegratePose(start, k, 0.1);
+    CHECK(std::fabs(y.t_wp.t[0] - 0.05) < 1e-15 && std::fabs(y.v_w[0] - 0.6) < 1e-15 && y.t_wp.q[3] == 1.0);
+  }
   // from a PoseT
   BA::Pose pose;
   pose.v_w = ba::Vector3t({0.5, 0.0, 0.0});
