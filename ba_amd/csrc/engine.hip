@@ -738,6 +738,58 @@ int ba_hip_imu_integrate_pose(const double state10[10], const double k9[9], doub
   return 0;
 }
 
+// The Lie-group / quaternion helpers of the reference's Utils.h on the host (include/ba/Utils.h wraps
+// them with the reference's names): one dispatcher over the functions the kernels use (dmath.h, dpose.h).
+// a / b: the arguments as doubles (transforms as [t(3) q(4)], quaternions x,y,z,w); out: the result,
+// row-major.  Returns the number of doubles written, -1 for an unknown op or a missing argument.
+int ba_hip_lie(int op, const double* a, const double* b, double* out) {
+  using namespace bad;
+  if (!a || !out) return -1;
+  auto put = [&](const double* m, int n) { for (int i = 0; i < n; ++i) out[i] = m[i]; return n; };
+  const bool two = op == 5 || (op >= 7 && op <= 11) || op == 14 || op == 15 || op == 17;
+  if (two && !b) return -1;
+  switch (op) {
+    case 1: return put(dlog_dq(a).m, 12);                                     // Utils.h:137-185
+    case 2: return put(dq_exp_dw(v3(a[0], a[1], a[2])).m, 12);                // :252-266
+    case 3: return put(qR(a).m, 16);                                          // dq1q2_dq1(q2) :286-291
+    case 4: return put(qL(a).m, 16);                                          // dq1q2_dq2(q1) :277-282
+    case 5: return put(dqx_dq(a, v3(b[0], b[1], b[2])).m, 12);                // :295-312
+    case 6: { const M3 R = quat_to_rot(a[0], a[1], a[2], a[3]); return put(R.m, 9); }  // dqx_dx :316-333
+    case 7: log_decoupled(tq_from7(a), tq_from7(b), out); return 6;           // :354-360
+    case 8: {                                                                 // exp_decoupled :364-369
+      double qe[4], q[4];
+      so3_exp(v3(b[3], b[4], b[5]), qe);
+      quat_mul(a + 3, qe, q);
+      quat_normalize(q);
+      for (int i = 0; i < 3; ++i) out[i] = a[i] + b[i];
+      for (int i = 0; i < 4; ++i) out[3 + i] = q[i];
+      return 7;
+    }
+    case 9: return put(dlog_decoupled_dx(tq_from7(a), tq_from7(b)).m, 36);    // :374-384
+    case 10: return put(dLog_decoupled_dt1(tq_from7(a), tq_from7(b)).m, 42);  // :388-397
+    case 11: return put(dlog_decoupled_dt2(tq_from7(a), tq_from7(b)).m, 42);  // :401-447
+    case 12: return put(dexp_decoupled_dx(tq_from7(a)).m, 42);                // :451-489
+    case 13: return put(dinv_exp_decoupled_dx(tq_from7(a)).m, 42);            // :493-536
+    case 14: {                                                                // dt_x_dt(t, x) 4 x 7 :540-583
+      double J[28] = {0};
+      const DM<3, 4> d = dqx_dq(a + 3, v3(b[0], b[1], b[2]));
+      for (int r = 0; r < 3; ++r) {
+        J[r * 7 + r] = b[3];
+        for (int c = 0; c < 4; ++c) J[r * 7 + 3 + c] = d(r, c);
+      }
+      return put(J, 28);
+    }
+    case 15: return put(dt1_t2_dt1(tq_from7(a), tq_from7(b)).m, 49);          // :587-639
+    case 16: return put(dt1_t2_dt2(tq_from7(a)).m, 49);                       // :643-694
+    case 17: {                                                                // MultHomogeneous :72-82
+      const V3 r = qrot(a + 3, v3(b[0], b[1], b[2]));
+      out[0] = r.x + a[0] * b[3]; out[1] = r.y + a[1] * b[3]; out[2] = r.z + a[2] * b[3]; out[3] = b[3];
+      return 4;
+    }
+  }
+  return -1;
+}
+
 int ba_hip_set_imu_noise(ba_hip_engine* h, const double r6[6], const double rb6[6]) {
   ENG(h);
   e->prob.imu_noise.clear();

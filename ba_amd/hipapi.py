@@ -86,7 +86,7 @@ SYMBOLS = [
     "ba_hip_get_conditioning_error", "ba_hip_comm_unique_id", "ba_hip_comm_init", "ba_hip_comm_destroy", "ba_hip_allreduce_host", "ba_hip_get_proj_jacobians",
     "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians", "ba_hip_get_calibration_marginals", "ba_hip_set_landmark_ref_pixels", "ba_hip_get_camera_params",
     "ba_hip_set_camera_models", "ba_hip_get_camera_fov",
-    "ba_hip_integrate_imu_jacobians", "ba_hip_imu_pose_derivative", "ba_hip_imu_integrate_pose",
+    "ba_hip_integrate_imu_jacobians", "ba_hip_imu_pose_derivative", "ba_hip_imu_integrate_pose", "ba_hip_lie",
 ]
 
 

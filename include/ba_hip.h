@@ -200,6 +200,14 @@ int ba_hip_imu_pose_derivative(const double state10[10], const double g3[3], con
                                double k9[9], double* dk_db54, double* dk_dx90);
 int ba_hip_imu_integrate_pose(const double state10[10], const double k9[9], double dt, double out10[10],
                               double* dy_dk90, double* dy_dy16);
+/* The Lie-group / quaternion helpers of the reference's include/ba/Utils.h, host code shared with the kernels
+ * (include/ba/Utils.h wraps this entry with the reference's names).  Transforms travel as [t(3) q(4)],
+ * quaternions as x,y,z,w; results are row-major.  op: 1 dlog_dq(q) 3x4 | 2 dq_exp_dw(w) 4x3 | 3 dq1q2_dq1(q2) 4x4 |
+ * 4 dq1q2_dq2(q1) 4x4 | 5 dqx_dq(q, x3) 3x4 | 6 dqx_dx(q) 3x3 | 7 log_decoupled(a, b) 6 | 8 exp_decoupled(a, x6) 7 |
+ * 9 dlog_decoupled_dx(a, b) 6x6 | 10 dLog_decoupled_dt1(t1, t2) 6x7 | 11 dlog_decoupled_dt2(t1, t2) 6x7 |
+ * 12 dexp_decoupled_dx(t) 7x6 | 13 dinv_exp_decoupled_dx(t) 7x6 | 14 dt_x_dt(t, x4) 4x7 | 15 dt1_t2_dt1(t1, t2) 7x7 |
+ * 16 dt1_t2_dt2(t1) 7x7 | 17 MultHomogeneous(t, x4) 4.  Returns the number of doubles written, -1 on a bad call. */
+int ba_hip_lie(int op, const double* a, const double* b, double* out);
 /* ImuCalibrationT::r and r_b (Types.h:112-159): diagonal of the IMU measurement noise (gyro x3,
  * accelerometer x3) and of the bias random walk, as parallel_algos.h:204,288 read them from imu_.
  * NULL pointers: derive both from the sigmas of ba_hip_options (what Init() does,

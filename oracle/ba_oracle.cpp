@@ -1963,4 +1963,33 @@ void orc_math_integrate_jacobians(const double pose_t[7], const double v[3], con
   memcpy(c, cc.a, 100 * 8);
 }
 
+// The Utils.h helpers by op code (the numbering of ba_hip_lie, include/ba_hip.h) — test tap
+int orc_math_lie(int op, const double* a, const double* b, double* out) {
+  auto quat = [](const double* p) { Quat q; q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3]; return q; };
+  auto vec3 = [](const double* p) { Vec3 v; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; return v; };
+  auto vec4 = [](const double* p) { Vec4 v; for (int i = 0; i < 4; ++i) v[i] = p[i]; return v; };
+#define ORC_PUT(M, N) { const auto m_ = (M); memcpy(out, m_.a, (N) * sizeof(double)); return (N); }
+  switch (op) {
+    case 1: ORC_PUT(dlog_dq(quat(a)), 12)
+    case 2: ORC_PUT(dq_exp_dw(vec3(a)), 12)
+    case 3: ORC_PUT(dq1q2_dq1(quat(a)), 16)
+    case 4: ORC_PUT(dq1q2_dq2(quat(a)), 16)
+    case 5: ORC_PUT(dqx_dq(quat(a), vec3(b)), 12)
+    case 6: ORC_PUT(quat(a).matrix(), 9)
+    case 7: ORC_PUT(log_decoupled(se3_from7(a), se3_from7(b)), 6)
+    case 8: { Vec6 x; for (int i = 0; i < 6; ++i) x[i] = b[i]; se3_to7(exp_decoupled(se3_from7(a), x), out); return 7; }
+    case 9: ORC_PUT(dlog_decoupled_dx(se3_from7(a), se3_from7(b)), 36)
+    case 10: ORC_PUT(dLog_decoupled_dt1(se3_from7(a), se3_from7(b)), 42)
+    case 11: ORC_PUT(dlog_decoupled_dt2(se3_from7(a), se3_from7(b)), 42)
+    case 12: ORC_PUT(dexp_decoupled_dx(se3_from7(a)), 42)
+    case 13: ORC_PUT(dinv_exp_decoupled_dx(se3_from7(a)), 42)
+    case 14: ORC_PUT(dt_x_dt(se3_from7(a), vec4(b)), 28)
+    case 15: ORC_PUT(dt1_t2_dt1(se3_from7(a), se3_from7(b)), 49)
+    case 16: ORC_PUT(dt1_t2_dt2(se3_from7(a)), 49)
+    case 17: ORC_PUT(MultHomogeneous(se3_from7(a), vec4(b)), 4)
+  }
+#undef ORC_PUT
+  return -1;
+}
+
 }  // extern "C"

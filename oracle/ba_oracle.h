@@ -191,6 +191,8 @@ void orc_math_integrate(const double pose_t[7], const double v[3], const double*
 void orc_math_integrate_jacobians(const double pose_t[7], const double v[3], const double* meas, uint32_t n,
                                   const double bg[3], const double ba[3], const double g[3], const double r6[6],
                                   double* dpose_db, double* dpose_dpose, double* c);
+/* the Utils.h helpers by the op codes of ba_hip_lie (include/ba_hip.h); returns the doubles written */
+int orc_math_lie(int op, const double* a, const double* b, double* out);
 
 #ifdef __cplusplus
 }

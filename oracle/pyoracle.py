@@ -460,6 +460,15 @@ def integrate(pose_t, v, meas, bg, ba, g, r6=None, jac=False):
     return (out_t, out_v, db, c) if jac else (out_t, out_v)
 
 
+def lie(op, a, b=None):
+    """Utils.h helper number `op` (numbering of ba_hip_lie, include/ba_hip.h) -> flat result."""
+    a = _d(a)
+    bb = _d(b) if b is not None else None
+    out = np.empty(64)
+    n = lib().orc_math_lie(int(op), _dp(a), _dp(bb) if bb is not None else None, _dp(out))
+    return out[:n].copy()
+
+
 def integrate_jacobians(pose_t, v, meas, bg, ba, g, r6):
     """dpose_db (10x6), dpose_dpose (10x10) and the covariance of IntegrateResidual (Types.h:662-738)."""
     pose_t, v, meas, bg, ba, g, r = map(_d, (pose_t, v, meas, bg, ba, g, r6))
