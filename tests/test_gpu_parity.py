@@ -2119,6 +2119,16 @@ def test_calibration_combinations_that_are_refused():
         h.Solve(1)
         assert adjuster.RESULT_NAMES[h.summary().result] == "SolverError"
         assert np.array_equal(h.camera_params(0), cam)
+    # per-pose intrinsics are four pinhole parameters: not offered on a rig with a FovCamera
+    h = adjuster.BundleAdjuster(1, 6)
+    h.Init(hip_options())
+    h.AddCamera(np.append(sc.cam_params, FOV_W))
+    h.add_poses(sc.poses)
+    h.add_landmarks(sc.landmarks, sc.lm_ref_pose)
+    h.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
+    h.SetPoseCamParams(np.tile(np.asarray(sc.cam_params), (sc.num_poses, 1)))
+    h.Solve(1)
+    assert adjuster.RESULT_NAMES[h.summary().result] == "SolverError"
 
 
 @pytest.mark.gpu
