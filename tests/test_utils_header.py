@@ -130,3 +130,15 @@ int main() {
                            "-L", libdir, "-lba_hip", "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "utils header: ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_math_test_application():
+    """applications/math_test — the analytic-vs-numeric Jacobian report of the reference's program of that name
+    (main.cpp:26-148) on include/ba/Utils.h: every norm small, exit code 0.  Host only."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipapi.lib()  # builds the libraries and applications if needed
+    exe = os.path.join(root, "ba_amd", "lib", "math_test")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "math_test: ok" in out.stdout, out.stdout + out.stderr
+    for name in ("dlog_dq", "dExp_dq", "dTerror", "dlog_Terror"):
+        assert name in out.stdout
