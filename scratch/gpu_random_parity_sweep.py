@@ -12,7 +12,7 @@ po.build()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 worst = 0.0
-ONLY = set(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 else None
+ONLY = set(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 and sys.argv[3] not in ("", "all") else None
 for trial in range(N):
     P = int(rng.integers(6, 60)); L = int(rng.integers(10, 200)); K = int(rng.integers(3, min(P - 1, 8)))
     lm_dim = int(rng.choice([1, 3])); pose_dim = int(rng.choice([6, 6, 15])); dog = int(rng.integers(0, 2))
@@ -23,6 +23,9 @@ for trial in range(N):
         print('trial %2d skipped (scene generator)' % trial); continue
     if pose_dim == 15:
         scene.add_inertial(sc, period=60.0 * P / 100.0)
+    fov = len(sys.argv) > 4 and sys.argv[4] == "fov" and rng.random() < 0.5   # argv[4] = fov: half the scenes through a FOV camera
+    if fov:
+        scene.to_fov_camera(sc, float(rng.uniform(0.3, 1.2)))
     pa = np.ones(P, dtype=np.uint8); la = np.ones(L, dtype=np.uint8)
     if pose_dim == 6:
         pa[sc.anchor_poses] = 0
@@ -91,5 +94,5 @@ for trial in range(N):
     flag = "" if (ok and d < tol and dl < tol) else ("  (singular S: not comparable)" if cond > 1e14 else "  <-- CHECK")
     if cond <= 1e14:
         worst = max(worst, d, dl)
-    print("trial %2d P=%2d L=%3d K=%d lm=%d D=%2d dogleg=%d result=%d cond %.1e condV %.1e pose %.1e lm %.1e%s" % (trial, P, L, K, lm_dim, pose_dim, dog, so.result, cond, cond_v, d, dl, flag), flush=True)
+    print("trial %2d P=%2d L=%3d K=%d lm=%d D=%2d dogleg=%d %s result=%d cond %.1e condV %.1e pose %.1e lm %.1e%s" % (trial, P, L, K, lm_dim, pose_dim, dog, "fov" if fov else "pin", so.result, cond, cond_v, d, dl, flag), flush=True)
 print("worst rel diff %.2e" % worst)
