@@ -703,6 +703,7 @@ int launch_landmarks(Engine* e, double c_huber, int use_robust) {
   }
   e->prof_end(e->ev_landmarks);
 #undef BAE_ARGS
+#undef BAE_LIN_LAUNCH
   BAE_HIP(hipGetLastError());
   return 0;
 }

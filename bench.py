@@ -79,8 +79,10 @@ def usable_cpus(cap=16):
     return max(1, min(n, cap))
 
 
-def make_workload(cfg, P, L, K, lm_dim):
+def make_workload(cfg, P, L, K, lm_dim, fov_w=None):
     sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=2)
+    if fov_w:
+        scene.to_fov_camera(sc, fov_w)  # the same scene seen through a FOV camera (not a BASELINE configuration)
     if cfg["imu"]:
         scene.add_inertial(sc, period=60.0 * P / 100.0)
     return sc
@@ -238,6 +240,9 @@ def main():
     ap.add_argument("--obs-per-landmark", type=int, default=10)
     ap.add_argument("--lm-dim", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fov-w", type=float, default=None,
+                    help="variant workload: the scene through a calibu::FovCamera with this distortion parameter "
+                         "(times the FOV instantiations of the projection kernels; configs 1 / 3)")
     ap.add_argument("--live-pmc", action="store_true",
                     help="after the timed region, run the two rocprofv3 --pmc passes of this configuration as child "
                          "processes (scratch/pmc_traffic.py; minutes) and report THEIR traffic instead of the committed summary")
@@ -279,7 +284,7 @@ def main():
         dist.init_process_group(backend=backend)
 
     P, L, K, lm_dim = args.poses, args.landmarks, args.obs_per_landmark, args.lm_dim
-    sc = make_workload(cfg, P, L, K, lm_dim)
+    sc = make_workload(cfg, P, L, K, lm_dim, args.fov_w)
     log("scene ready: %d poses, %d landmarks" % (P, L))
 
     def barrier():
@@ -403,7 +408,7 @@ def main():
         # HBM-side traffic of the dominant kernel: not measurable live; taken from the committed
         # rocprofv3 --pmc passes of this same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE,
         # per launch), null if no summary exists for this configuration
-        pmc, pmc_file = newest_pmc(args.config)
+        pmc, pmc_file = newest_pmc(args.config) if not args.fov_w else ({}, None)
         if args.live_pmc and world == 1 and not api_driver:
             # this process has released its engine; the passes are separate processes under rocprofv3
             import subprocess
@@ -451,9 +456,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: %d poses / %d landmarks / %d reprojection residuals%s%s, "
-                                   "pinhole, LmSize=%d, PoseSize=%d, %s%s"
+                                   "%s, LmSize=%d, PoseSize=%d, %s%s"
                                    % (args.config, P, L, O, " + %d IMU pre-integration residuals" % (P - 1) if cfg["imu"] else "",
                                       " + unary priors every 100th pose + %d binary odometry constraints" % (P - 1) if cfg["priors"] else "",
+                                      ("VARIANT: FOV camera w = %g" % args.fov_w) if args.fov_w else "pinhole",
                                       lm_dim, cfg["D"], "dogleg trust region" if cfg["dogleg"] else "Gauss-Newton (no dogleg)",
                                       "" if cfg["imu"] else ", 2 anchor poses inactive"),
                        "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
