@@ -72,6 +72,32 @@ def test_host_imu_integration_jacobians_match_oracle(oracle_lib):
         assert L.ba_hip_integrate_imu_jacobians(p(t7), p(v), p(bg), p(ba), p(g), p(meas), C.c_uint32(len(meas)), None,
                                                 p(st), p(db2), None, None) == 0
         assert np.all(db2 == 0)
+    # the reference's own checks of these matrices (_Test_IntegrateResidual_StateJacobian / _BiasJacobian,
+    # Types.h:859-996): central differences of the integration over the start state — the four quaternion
+    # entries perturbed freely, no renormalisation — and over the six bias entries
+    i = 3
+    t7, v = np.ascontiguousarray(sc.poses[i], dtype=np.float64), np.ascontiguousarray(sc.init_vel[i], dtype=np.float64)
+    meas = np.ascontiguousarray(sc.imu_meas[i], dtype=np.float64).reshape(-1, 7)
+    g = np.ascontiguousarray(sc.gravity, dtype=np.float64)
+    bg, ba = np.array([1e-3, -2e-3, 5e-4]), np.array([1e-2, 2e-2, -1e-2])
+    st, db, dd = np.empty((len(meas), 10)), np.empty((10, 6)), np.empty((10, 10))
+    assert L.ba_hip_integrate_imu_jacobians(p(t7), p(v), p(bg), p(ba), p(g), p(meas), C.c_uint32(len(meas)), p(r6),
+                                            p(st), p(db), p(dd), None) == 0
+    h = 1e-6
+
+    def final(s10, b6):
+        return _integrate(s10[:7], s10[7:], b6[:3], b6[3:], g, meas)[-1]
+    s10, b6 = np.concatenate([t7, v]), np.concatenate([bg, ba])
+    for j in range(10):
+        e = np.zeros(10)
+        e[j] = h
+        fd = (final(s10 + e, b6) - final(s10 - e, b6)) / (2 * h)
+        assert np.abs(fd - dd[:, j]).max() < 1e-5 * max(1.0, np.abs(dd).max()), j
+    for j in range(6):
+        e = np.zeros(6)
+        e[j] = h
+        fd = (final(s10, b6 + e) - final(s10, b6 - e)) / (2 * h)
+        assert np.abs(fd - db[:, j]).max() < 1e-5 * max(1.0, np.abs(db).max()), j
     # GetPoseDerivative / IntegratePose: Jacobians against central differences of the functions themselves
     s10 = np.concatenate([sc.poses[2], sc.init_vel[2]]).astype(np.float64)
     z0, z1 = np.ascontiguousarray(sc.imu_meas[2][0], dtype=np.float64), np.ascontiguousarray(sc.imu_meas[2][1], dtype=np.float64)
