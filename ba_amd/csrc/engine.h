@@ -178,6 +178,16 @@ struct Engine {
   DBuf<double> invdiag;                  // inverse diagonal tiles of the Cholesky factor
   DBuf<double> partials;                 // reduction scratch
   DBuf<double> scalars_out;              // small result block (device) + host mirror
+  // Deferred scalars: between defer_begin() and defer_flush() the reductions of sum_partials / sum_small
+  // leave their results in scalars_out[16 ..) and only note where the host wants them; the flush is ONE
+  // device-to-host copy and ONE synchronisation for the whole phase call (a small window pays ~30 us per
+  // round trip: four of them made ba_hip_dogleg_terms 140 us).  Off for sharded engines, whose sums go
+  // through the all-reduce hook one by one.
+  bool defer_active = false;
+  int defer_n = 0;
+  double* defer_host[40];
+  double dog_h[8];                       // landing place of the dogleg sums (ba_hip_dogleg_terms)
+  double eval_h[4];                      // ... of the evaluation sums (ba_hip_eval_residuals)
   DBuf<unsigned long long> hist;         // selection histograms
   DBuf<int32_t> flags;                   // factorisation status block (k_chol.hip: setup_status_block)
   DBuf<double> pivot_floor;              // tol * |S_jj| per row (ba_hip_options::pivot_rel_tolerance)
@@ -226,12 +236,14 @@ size_t packed_lower_count(uint32_t n_pad);                        // pair gather
 int launch_backsub(Engine* e);                         // delta_l
 int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norms2_host);
 int launch_apply_step(Engine* e);                      // state[cur] -> state[1-cur]
-int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out);
+int launch_dogleg(Engine* e, int gn_available, double* h7);
 int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out);
 int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard = true);
+void defer_begin(Engine* e);   // k_reduce.hip
+int defer_flush(Engine* e);
 int launch_imu_early(Engine* e, double c_huber_proj);
-int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs);
-int launch_posepose_eval(Engine* e, ba_hip_errors* errs);
+int launch_posepose_build(Engine* e, double c_huber_proj, double* h3);
+int launch_posepose_eval(Engine* e, double* h3);
 int launch_posepose_jrhs(Engine* e, double* out);
 int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, int* status,
                    const uint8_t* nz_tiles);

@@ -65,8 +65,13 @@ struct EventTimer {
     (void)hipEventCreate(&b);
     (void)hipEventRecord(a, s);
   }
-  double stop_ms() {
-    (void)hipEventRecord(b, s);
+  // mark(): the end point in stream order; read_ms(): wait for it and read — apart, so that a phase call
+  // can mark several intervals and pay for ONE synchronisation at its end
+  void mark() { (void)hipEventRecord(b, s); marked = true; }
+  double stop_ms() { mark(); return read_ms(); }
+  bool marked = false;
+  double read_ms() {
+    if (!marked) mark();
     (void)hipEventSynchronize(b);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, a, b);
@@ -880,7 +885,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   EventTimer t_j(e->stream);
   if ((rc = launch_pose_prep(e))) return rc;
   if ((rc = launch_residuals(e, 0))) return rc;
-  e->timers.j_evaluation = t_j.stop_ms();
+  t_j.mark();
   EventTimer t_r(e->stream);
   double c_huber = 0.0;
   uint64_t n_total = st.O;
@@ -897,19 +902,22 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
     if ((rc = select_kth(e, e->obs_e.p, st.O, (uint64_t)std::floor(n_total * 0.5), &med))) return rc;
     c_huber = 1.2107 * std::sqrt(med);
   }
-  e->timers.robust_weights = t_r.stop_ms();
+  t_r.mark();
   if ((rc = launch_imu_early(e, c_huber))) return rc;  // overlaps the projection linearisation
   EventTimer t_l(e->stream);
+  // from here on every sum stays on the device until ONE copy at the end of the call (defer_flush): the
+  // assembly and the pose-pose kernels are enqueued without waiting for the linearisation to finish
+  double* hs = e->eval_h;  // proj | unary | binary | inertial
+  for (int i = 0; i < 4; ++i) hs[i] = 0.0;
+  defer_begin(e);
   if ((rc = launch_landmarks(e, c_huber, e->opt.use_robust_norm_for_proj_residuals))) return rc;
   // proj_error_ of BuildProblem (BundleAdjuster.cpp:1386): sum of w |r|^2 with the new weights, one
   // partial per linearisation wave
-  double proj_err = 0.0;
-  if ((rc = sum_partials(e, st.O ? st.n_chunks : 0, 1, &proj_err))) return rc;
-  e->timers.j_evaluation += t_l.stop_ms();
+  if ((rc = sum_partials(e, st.O ? st.n_chunks : 0, 1, hs))) { (void)defer_flush(e); return rc; }
+  t_l.mark();
   EventTimer t_s(e->stream);
   e->factored = false;
-  if ((rc = launch_gather_S(e))) return rc;
-  if ((rc = launch_posepose_build(e, c_huber, &errs))) return rc;
+  if ((rc = launch_gather_S(e)) || (rc = launch_posepose_build(e, c_huber, hs + 1))) { (void)defer_flush(e); return rc; }
   // copy the reduced rhs into the rhs row of A
   BAE_HIP(hipMemcpyAsync(e->A.p + (size_t)st.ld * st.ld, e->rhs_sc.p, (size_t)st.n * sizeof(double),
                          hipMemcpyDeviceToDevice, e->stream));
@@ -942,8 +950,12 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
                            hipMemcpyDeviceToDevice, e->stream));
     }
   }
-  e->timers.jtj_schur = t_s.stop_ms();
-  errs.proj_error = proj_err;
+  t_s.mark();
+  if ((rc = defer_flush(e))) return rc;
+  e->timers.j_evaluation = t_j.read_ms() + t_l.read_ms();
+  e->timers.robust_weights = t_r.read_ms();
+  e->timers.jtj_schur = t_s.read_ms();
+  errs.proj_error = hs[0]; errs.unary_error = hs[1]; errs.binary_error = hs[2]; errs.inertial_error = hs[3];
   if (out) *out = errs;
   return 0;
 }
@@ -982,11 +994,18 @@ int ba_hip_dogleg_terms(ba_hip_engine* h, int gn_available, ba_hip_dogleg_scalar
   ENG(h);
   NEED_FINAL();
   BAE_HIP(hipSetDevice(e->device));
-  int rc = launch_dogleg(e, gn_available, out);
-  if (rc) return rc;
-  double pp = 0.0;
-  if ((rc = launch_posepose_jrhs(e, &pp))) return rc;
-  out->j_rhs_sq += pp;
+  // every sum of this call stays on the device until ONE copy at the end (defer_flush)
+  memset(out, 0, sizeof(*out));
+  double* dh = e->dog_h;
+  defer_begin(e);
+  int rc = launch_dogleg(e, gn_available, dh);
+  if (!rc) rc = launch_posepose_jrhs(e, dh + 7);
+  const int rf = defer_flush(e);
+  if (rc || rf) return rc ? rc : rf;
+  out->rhs_p_sq = dh[0]; out->gn_p_sq = dh[1]; out->rhs_gn_p = dh[2];
+  out->rhs_l_sq = dh[3]; out->gn_l_sq = dh[4]; out->rhs_gn_l = dh[5];
+  out->j_rhs_sq = dh[6] + dh[7];
+  if (e->st.K && (rc = launch_calib_dogleg(e, gn_available, out))) return rc;
   return 0;
 }
 
@@ -995,8 +1014,10 @@ int ba_hip_compose_step(ba_hip_engine* h, double coef_rhs, double coef_gn, ba_hi
   NEED_FINAL();
   BAE_HIP(hipSetDevice(e->device));
   double n2[2];
+  defer_begin(e);  // both norms in one copy
   int rc = launch_compose_step(e, coef_rhs, coef_gn, n2);
-  if (rc) return rc;
+  const int rf = defer_flush(e);
+  if (rc || rf) return rc ? rc : rf;
   if (out) { out->step_p_norm = std::sqrt(n2[0]); out->step_l_norm = std::sqrt(n2[1]); }
   return 0;
 }
@@ -1077,12 +1098,15 @@ int ba_hip_eval_residuals(ba_hip_engine* h, ba_hip_errors* out) {
   BAE_HIP(hipSetDevice(e->device));
   ba_hip_errors errs = {0, 0, 0, 0};
   EventTimer t(e->stream);
+  double* hs = e->eval_h;  // proj | unary | binary | inertial: one copy for the four sums (defer_flush)
+  for (int i = 0; i < 4; ++i) hs[i] = 0.0;
+  defer_begin(e);
   int rc = launch_residuals(e, 1);
-  if (rc) return rc;
-  double s = 0.0;
-  if ((rc = sum_partials(e, (e->st.O + 255) / 256, 1, &s))) return rc;
-  errs.proj_error = s;
-  if ((rc = launch_posepose_eval(e, &errs))) return rc;
+  if (!rc) rc = sum_partials(e, (e->st.O + 255) / 256, 1, hs);
+  if (!rc) rc = launch_posepose_eval(e, hs + 1);
+  const int rf = defer_flush(e);
+  if (rc || rf) return rc ? rc : rf;
+  errs.proj_error = hs[0]; errs.unary_error = hs[1]; errs.binary_error = hs[2]; errs.inertial_error = hs[3];
   e->timers.evaluate_residuals = t.stop_ms();
   if (out) *out = errs;
   return 0;

@@ -315,6 +315,12 @@ __global__ void k_sum_small(int n, const double* __restrict__ v, double* __restr
 
 static int sum_small(Engine* e, int n, const double* d_v, double* host) {
   *host = 0.0;
+  if (e->defer_active && n > 0 && e->defer_n < 40) {  // see Engine::defer_active
+    hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(1), 0, e->stream, n, d_v, e->scalars_out.p + 16 + e->defer_n);
+    BAE_HIP(hipGetLastError());
+    e->defer_host[e->defer_n++] = host;
+    return 0;
+  }
   if (n > 0) {
     hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(1), 0, e->stream, n, d_v, e->scalars_out.p + 8);
     BAE_HIP(hipGetLastError());
@@ -403,7 +409,7 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
 }
 
 // BuildProblem part of the pose-pose residuals + scatter (after launch_gather_S).
-int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
+int launch_posepose_build(Engine* e, double c_huber_proj, double* h3) {  // h3: unary | binary | inertial error sums
   const Problem& pb = e->prob;
   const uint32_t nu = pb.num_unary, nb = pb.num_binary, ni = pb.num_imu;
   if (nu + nb + ni == 0 && !(e->sharded())) return 0;
@@ -436,7 +442,7 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
       BAE_HIP(hipGetLastError());
     }
   }
-  if ((rc = sum_small(e, nu, e->pp_err.p, &errs->unary_error))) return rc;
+  if ((rc = sum_small(e, nu, e->pp_err.p, h3))) return rc;
   if (nb) {
     hipLaunchKernelGGL(k_binary, dim3((nb + 63) / 64), dim3(64), 0, e->stream, (int)nb, 1, e->bin_p1.p,
                        e->bin_p2.p, e->bin_t.p, e->bin_cov_inv.p, e->bin_cov_inv_sqrt.p, e->bin_w.p,
@@ -444,14 +450,14 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
                        e->pp_err.p + nu);
     BAE_HIP(hipGetLastError());
   }
-  if ((rc = sum_small(e, nb, e->pp_err.p + nu, &errs->binary_error))) return rc;
+  if ((rc = sum_small(e, nb, e->pp_err.p + nu, h3 + 1))) return rc;
   // k_imu was started on the second stream right after the Huber constant was known
   // (launch_imu_early): join it here
   if (ni && e->imu_early_pending) {
     BAE_HIP(hipStreamWaitEvent(e->stream, e->ev_imu_done, 0));
     e->imu_early_pending = false;
   }
-  if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
+  if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, h3 + 2))) return rc;
   if (e->st.n_pp_entries > 0) {
     hipLaunchKernelGGL(k_pp_scatter, dim3(e->st.Pact), dim3(256), 0, e->stream, e->pose_dim, e->st.ld,
                        e->st.ld, e->pp_ptr.p, e->pp_ent.p, e->pose_mask.p + e->st.P, e->pp_h.p,
@@ -462,7 +468,7 @@ int launch_posepose_build(Engine* e, double c_huber_proj, ba_hip_errors* errs) {
 }
 
 // EvaluateResiduals for the pose-pose residuals (BundleAdjuster.cpp:190-256)
-int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
+int launch_posepose_eval(Engine* e, double* h3) {  // h3: unary | binary | inertial error sums
   const Problem& pb = e->prob;
   const uint32_t nu = pb.num_unary, nb = pb.num_binary, ni = pb.num_imu;
   if (nu + nb + ni == 0 && !(e->sharded())) return 0;
@@ -474,7 +480,7 @@ int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
                        e->pp_err.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p, e->pp_info.p, 0u, e->pp_err.p);
     BAE_HIP(hipGetLastError());
   }
-  if ((rc = sum_small(e, nu, e->pp_err.p, &errs->unary_error))) return rc;
+  if ((rc = sum_small(e, nu, e->pp_err.p, h3))) return rc;
   if (nb) {
     hipLaunchKernelGGL(k_binary, dim3((nb + 63) / 64), dim3(64), 0, e->stream, (int)nb, 2, e->bin_p1.p,
                        e->bin_p2.p, e->bin_t.p, e->bin_cov_inv.p, e->bin_cov_inv_sqrt.p, e->bin_w.p,
@@ -482,7 +488,7 @@ int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
                        e->pp_err.p + nu);
     BAE_HIP(hipGetLastError());
   }
-  if ((rc = sum_small(e, nb, e->pp_err.p + nu, &errs->binary_error))) return rc;
+  if ((rc = sum_small(e, nb, e->pp_err.p + nu, h3 + 1))) return rc;
   if (ni) {
     hipLaunchKernelGGL(k_imu, dim3((ni + 63) / 64), dim3(64), 0, e->stream, (int)ni, 2, e->pose_dim, 0,
                        0.0, e->imu_p1.p, e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p,
@@ -491,7 +497,7 @@ int launch_posepose_eval(Engine* e, ba_hip_errors* errs) {
                        (double*)nullptr, (uint8_t*)nullptr, (const double*)nullptr);
     BAE_HIP(hipGetLastError());
   }
-  if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, &errs->inertial_error))) return rc;
+  if ((rc = sum_small(e, ni, e->pp_err.p + nu + nb, h3 + 2))) return rc;
   return 0;
 }
 

@@ -648,7 +648,41 @@ __global__ void k_sum_partials_l1(uint32_t nparts, uint32_t nblk, const double* 
   if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
+void defer_begin(Engine* e) {
+  e->defer_active = !e->sharded();
+  e->defer_n = 0;
+}
+int defer_flush(Engine* e) {
+  const bool was = e->defer_active;
+  const int n = e->defer_n;
+  e->defer_active = false;
+  e->defer_n = 0;
+  if (!was || n == 0) return 0;
+  double host[40];
+  BAE_HIP(hipMemcpyAsync(host, e->scalars_out.p + 16, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  BAE_HIP(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; ++i) *e->defer_host[i] = host[i];
+  return 0;
+}
+
 int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard) {
+  if (e->defer_active && nparts != 0 && e->defer_n + (int)ncomp <= 40) {
+    // deferred: the sum stays on the device until defer_flush (never reached by a sharded engine)
+    const double* src = e->partials.p;
+    if (ncomp == 1 && nparts > 8192) {
+      hipLaunchKernelGGL(k_sum_partials_l1, dim3(64), dim3(256), 0, e->stream, nparts, 64u, (const double*)e->partials.p,
+                         e->scalars_out.p + 64);
+      BAE_HIP(hipGetLastError());
+      src = e->scalars_out.p + 64;
+      nparts = 64;
+    }
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, e->stream, nparts, ncomp, src,
+                       e->scalars_out.p + 16 + e->defer_n);
+    BAE_HIP(hipGetLastError());
+    for (uint32_t c = 0; c < ncomp; ++c) e->defer_host[e->defer_n + c] = host_out + c;
+    e->defer_n += (int)ncomp;
+    return 0;
+  }
   if (nparts == 0) {
     for (uint32_t c = 0; c < ncomp; ++c) host_out[c] = 0.0;
   } else {
@@ -879,12 +913,8 @@ int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norm
                        e->rhs_p.p, e->gn_p.p, e->step_p.p, e->partials.p);
     BAE_HIP(hipGetLastError());
     // the pose step is replicated on every shard: no cross-shard sum
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, e->stream, nb, 1u, e->partials.p,
-                       e->scalars_out.p);
-    BAE_HIP(hipGetLastError());
-    BAE_HIP(hipMemcpyAsync(&norms2_host[0], e->scalars_out.p, sizeof(double),
-                           hipMemcpyDeviceToHost, e->stream));
-    BAE_HIP(hipStreamSynchronize(e->stream));
+    int rc = sum_partials(e, nb, 1, &norms2_host[0], false);
+    if (rc) return rc;
   }
   if (st.L > 0 && e->lm_dim > 0 && st.Lact > 0) {
     const uint32_t nb = (st.L + 255) / 256;
@@ -989,18 +1019,18 @@ __global__ void k_jrhs(uint32_t O, int D, int LM, const uint32_t* __restrict__ o
   if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
 }
 
-int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
+// The seven sums land in h7 = (rhs_p_sq, gn_p_sq, rhs_gn_p | rhs_l_sq, gn_l_sq, rhs_gn_l | j_rhs_sq): a buffer
+// that outlives a deferred flush (Engine::dog_h); ba_hip_dogleg_terms moves them into the result.
+int launch_dogleg(Engine* e, int gn_available, double* h7) {
   const Structure& st = e->st;
-  memset(out, 0, sizeof(*out));
-  double h[3];
+  for (int i = 0; i < 7; ++i) h7[i] = 0.0;
   int rc;
   if (st.np > 0) {  // pose parts: replicated on every shard
     const uint32_t nb = (st.np + 255) / 256;
     hipLaunchKernelGGL(k_dots_pose, dim3(nb), dim3(256), 0, e->stream, st.np, gn_available,
                        e->rhs_p.p, e->gn_p.p, e->partials.p, nb);
     BAE_HIP(hipGetLastError());
-    if ((rc = sum_partials(e, nb, 3, h, false))) return rc;
-    out->rhs_p_sq = h[0]; out->gn_p_sq = h[1]; out->rhs_gn_p = h[2];
+    if ((rc = sum_partials(e, nb, 3, h7, false))) return rc;
   }
   {  // landmark parts: sharded
     const uint32_t nb = (st.L > 0 && e->lm_dim > 0) ? (st.L + 255) / 256 : 0;
@@ -1009,8 +1039,7 @@ int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
                          e->lm_opt.p, e->lm_bl.p, e->gn_l.p, e->partials.p, nb);
       BAE_HIP(hipGetLastError());
     }
-    if ((rc = sum_partials(e, nb, 3, h, true))) return rc;
-    out->rhs_l_sq = h[0]; out->gn_l_sq = h[1]; out->rhs_gn_l = h[2];
+    if ((rc = sum_partials(e, nb, 3, h7 + 3, true))) return rc;
   }
   {  // || J_pr rhs_p + J_l rhs_l ||^2 over the observations (BundleAdjuster.cpp:881-906)
     const uint32_t nb = st.O > 0 ? (st.O + 255) / 256 : 0;
@@ -1020,10 +1049,8 @@ int launch_dogleg(Engine* e, int gn_available, ba_hip_dogleg_scalars* out) {
                          e->obs_jl.p, e->rhs_p.p, e->lm_bl.p, e->partials.p);
       BAE_HIP(hipGetLastError());
     }
-    if ((rc = sum_partials(e, nb, 1, h, true))) return rc;
-    out->j_rhs_sq = h[0];
+    if ((rc = sum_partials(e, nb, 1, h7 + 6, true))) return rc;
   }
-  if (st.K && (rc = launch_calib_dogleg(e, gn_available, out))) return rc;
   return 0;
 }
 
