@@ -788,10 +788,73 @@ k_select_scan(unsigned long long* __restrict__ sel, unsigned long long* __restri
   for (int b = 0; b < 32; ++b) hist[32 * lane + b] = 0;  // ready for the next pass
 }
 
+// Small inputs (a sliding window's residuals): the six passes in ONE workgroup — histogram in LDS, the
+// walk over the bins by the first wavefront exactly as k_select_scan does it — instead of twelve launches.
+__global__ void __launch_bounds__(1024)
+k_select_small(uint32_t n, const double* __restrict__ v, unsigned long long k0, unsigned long long* __restrict__ sel) {
+  __shared__ unsigned int h[2048];
+  __shared__ unsigned long long st[4];  // prefix, mask, remaining rank, error
+  const int tid = threadIdx.x;
+  if (tid == 0) { st[0] = 0; st[1] = 0; st[2] = k0; st[3] = 0; }
+  for (int pass = 0; pass < 6; ++pass) {
+    const int shift = pass == 5 ? 0 : 53 - 11 * pass;
+    const unsigned int dmask = pass == 5 ? 511u : 2047u;
+    const int nbins = pass == 5 ? 512 : 2048;
+    for (int i = tid; i < 2048; i += 1024) h[i] = 0;
+    __syncthreads();
+    const unsigned long long prefix = st[0], pmask = st[1];
+    for (uint32_t i = tid; i < n; i += 1024) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(v[i]);
+      if ((b & pmask) == prefix) atomicAdd(&h[(b >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int lane = tid;
+      const unsigned long long k = st[2];
+      unsigned long long loc = 0;
+      for (int b = 0; b < 32; ++b) loc += h[32 * lane + b];
+      unsigned long long incl = loc;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+      }
+      const unsigned long long excl = incl - loc;
+      const bool mine = (k >= excl) && (k < incl) && (32 * lane < nbins);
+      unsigned long long r = k - excl;
+      int b = 0;
+      if (mine)
+        for (; b < 32; ++b) {
+          const unsigned long long hb = h[32 * lane + b];
+          if (r < hb) break;
+          r -= hb;
+        }
+      const unsigned long long found = __ballot(mine);
+      if (mine) {
+        st[0] = prefix | (((unsigned long long)(32 * lane + b)) << shift);
+        st[1] = pmask | ((unsigned long long)dmask << shift);
+        st[2] = r;
+      }
+      if (lane == 0 && found == 0) st[3] = 1;  // rank out of range
+    }
+    __syncthreads();
+  }
+  if (tid < 4) sel[tid] = st[tid];
+}
+
 static int select_kth_device(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out) {
   static const int shifts[6] = {53, 42, 31, 20, 9, 0};
   unsigned long long init[4] = {0ull, 0ull, (unsigned long long)k, 0ull};
   unsigned long long* sel = e->hist.p + 2048;
+  if (n_local <= 65536u) {
+    hipLaunchKernelGGL(k_select_small, dim3(1), dim3(1024), 0, e->stream, n_local, d_values, (unsigned long long)k, sel);
+    BAE_HIP(hipGetLastError());
+    unsigned long long res[4];
+    BAE_HIP(hipMemcpyAsync(res, sel, sizeof(res), hipMemcpyDeviceToHost, e->stream));
+    BAE_HIP(hipStreamSynchronize(e->stream));
+    if (res[3]) return e->fail_msg("select_kth: rank out of range");
+    memcpy(out, &res[0], sizeof(double));
+    return 0;
+  }
   BAE_HIP(hipMemsetAsync(e->hist.p, 0, 2048 * sizeof(unsigned long long), e->stream));
   BAE_HIP(hipMemcpyAsync(sel, init, sizeof(init), hipMemcpyHostToDevice, e->stream));
   uint32_t grid = (n_local + 255) / 256;

@@ -44,7 +44,7 @@ def both(po, sc, lm_dim, active=None, lm_active=None, pose_dim=6, **kw):
 def test_select_kth_is_exact():
     eng = hipapi.Engine(1, 6)
     rng = np.random.default_rng(0)
-    for n in (1, 2, 7, 255, 256, 257, 1000, 100001, 1 << 20):
+    for n in (1, 2, 7, 255, 256, 257, 1000, 65536, 65537, 100001, 1 << 20):  # <= 65536: the one-workgroup kernel
         v = rng.random(n) ** 3 * 50
         v[rng.integers(0, n, max(1, n // 10))] = 0.0  # ties and exact zeros
         for k in {0, n // 2, n - 1}:
