@@ -867,6 +867,109 @@ BA_HD void imu_step_jacobians(const double* p1, const double* meas, int k, const
   for (int i = l0; i < 100; i += ls) out160[60 + i] = dy_dy.m[i];
 }
 
+#if defined(__HIPCC__)
+// The step Jacobians of sample k with ONE WAVEFRONT per sample and the whole RK4 Jacobian chain resident in
+// LDS (w->lds, 986 doubles): the four stage Jacobians dkN_db / dkN_dy, the running dy_db / dy_dy0 and the
+// small constructed blocks (dk_db, dk_dy of pose_derivative; dy_dk, the 4x4 quaternion block of
+// integrate_pose).  Every lane runs the states and the closed-form blocks (cheap, uniform), copies its share
+// of them to LDS, and owns one or two elements of each structured product — the expressions of mm_dy_dk,
+// mm_dk_dy, madd and add_ident of integrate_imu's Jacobian branch, element by element in the same order.
+// The scalar form keeps ~700 doubles of these matrices in dynamically indexed private memory per lane.
+__device__ __forceinline__ void imu_step_jacobians_wave(const double* p1, const double* meas, int k, const double* g,
+                                                        double* __restrict__ out160, const WaveCtx* w) {
+  constexpr int L_DKB = 0, L_DKY = 54, L_DYK = 144, L_DYY = 234, L_YB = 250, L_YY = 310, L_KB = 410, L_KY = 626;
+  double* L = w->lds;
+  const int lane = w->lane;
+  ImuState s;
+  for (int i = 0; i < 3; ++i) { s.t[i] = p1[i]; s.v[i] = p1[7 + i]; }
+  for (int i = 0; i < 4; ++i) s.q[i] = p1[3 + i];
+  const double* bg = p1 + 10;
+  const double* ba = p1 + 13;
+  for (int i = 1; i < k; ++i)
+    s = integrate_imu(s, meas + 7 * (i - 1), meas + 7 * i, bg, ba, g, false, nullptr, nullptr, nullptr, nullptr);
+  const double* z0 = meas + 7 * (k - 1);
+  const double* z1 = meas + 7 * k;
+  const double dt = z1[6] - z0[6];
+  if (dt == 0) {  // integrate_imu: dy_db = 0, dy_dy0 = I
+    for (int e = lane; e < 160; e += 64) out160[e] = (e >= 60 && (e - 60) % 11 == 0) ? 1.0 : 0.0;
+    return;
+  }
+  auto put = [&](int off, const double* m, int n) { for (int e = lane; e < n; e += 64) L[off + e] = m[e]; };
+  // o = mm_dy_dk(DYK, X) [+ identity blocks]: X at xo with N columns, result at oo
+  auto prod_dy_dk = [&](int xo, int N, int oo, bool ident) {
+    for (int e = lane; e < 10 * N; e += 64) {
+      const int r = e / N, c = e - r * N;
+      double v;
+      if (r < 3) v = 0.0 + L[L_DYK + r * 9 + r] * L[xo + r * N + c];
+      else if (r < 7) {
+        v = 0.0;
+        for (int kk = 3; kk < 6; ++kk) v += L[L_DYK + r * 9 + kk] * L[xo + kk * N + c];
+      } else v = 0.0 + L[L_DYK + r * 9 + (r - 1)] * L[xo + (r - 1) * N + c];
+      if (ident) {  // add_ident (Types.h:488-490)
+        if ((r < 3 || r >= 7) && r == c) v += 1.0;
+        if (r >= 3 && r < 7 && c >= 3 && c < 7) v += 1.0 * L[L_DYY + (r - 3) * 4 + (c - 3)];
+      }
+      L[oo + e] = v;
+    }
+  };
+  // o = [DKB +] mm_dk_dy(DKY, Y): Y at yo with N columns, result at oo
+  auto prod_dk_dy = [&](int yo, int N, int oo, bool add_dkb) {
+    for (int e = lane; e < 9 * N; e += 64) {
+      const int r = e / N, c = e - r * N;
+      double v;
+      if (r < 3) v = 0.0 + L[L_DKY + r * 10 + 7 + r] * L[yo + (7 + r) * N + c];
+      else {
+        v = 0.0;
+        for (int kk = 3; kk < 7; ++kk) v += L[L_DKY + r * 10 + kk] * L[yo + kk * N + c];
+      }
+      L[oo + e] = add_dkb ? L[L_DKB + e] + 1.0 * v : v;
+    }
+  };
+  double k1[9], k2[9], k3[9], k4[9], kt[9];
+  DM<9, 6> dk_db;
+  DM<9, 10> dk_dy;
+  DM<10, 9> dy_dk;
+  DM<4, 4> dyy;
+  // stage 1
+  pose_derivative(s, g, z0, z1, bg, ba, 0, k1, &dk_db, &dk_dy);
+  const ImuState y1 = integrate_pose(s, k1, dt * 0.5, &dy_dk, &dyy);
+  put(L_KB, dk_db.m, 54); put(L_KY, dk_dy.m, 90); put(L_DYK, dy_dk.m, 90); put(L_DYY, dyy.m, 16);
+  __syncthreads();
+  prod_dy_dk(L_KB, 6, L_YB, false); prod_dy_dk(L_KY, 10, L_YY, true);
+  __syncthreads();
+  // stages 2 .. 4: dkN = dk + dk_dy . (dy of the previous stage); then the stage's own dy
+  ImuState yprev = y1;
+  for (int stg = 1; stg < 4; ++stg) {
+    double* kk = stg == 1 ? k2 : stg == 2 ? k3 : k4;
+    pose_derivative(yprev, g, z0, z1, bg, ba, stg == 3 ? dt : dt / 2, kk, &dk_db, &dk_dy);
+    put(L_DKB, dk_db.m, 54); put(L_DKY, dk_dy.m, 90);
+    __syncthreads();
+    prod_dk_dy(L_YB, 6, L_KB + stg * 54, true); prod_dk_dy(L_YY, 10, L_KY + stg * 90, false);
+    if (stg == 3) break;
+    yprev = integrate_pose(s, kk, stg == 1 ? dt * 0.5 : dt, &dy_dk, &dyy);
+    __syncthreads();  // the products above read YB / YY and wrote KB / KY; DYK / DYY are free
+    put(L_DYK, dy_dk.m, 90); put(L_DYY, dyy.m, 16);
+    __syncthreads();
+    prod_dy_dk(L_KB + stg * 54, 6, L_YB, false); prod_dy_dk(L_KY + stg * 90, 10, L_YY, true);
+    __syncthreads();
+  }
+  __syncthreads();
+  // total derivative k1 + 2 k2 + 2 k3 + k4 and its Jacobians (into DKB / DKY), the final step
+  for (int i = 0; i < 9; ++i) kt[i] = k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i];
+  for (int e = lane; e < 54; e += 64)
+    L[L_DKB + e] = L[L_KB + e] + 2 * L[L_KB + 54 + e] + 2 * L[L_KB + 108 + e] + L[L_KB + 162 + e];
+  for (int e = lane; e < 90; e += 64)
+    L[L_DKY + e] = L[L_KY + e] + 2 * L[L_KY + 90 + e] + 2 * L[L_KY + 180 + e] + L[L_KY + 270 + e];
+  (void)integrate_pose(s, kt, dt / 6.0, &dy_dk, &dyy);
+  put(L_DYK, dy_dk.m, 90); put(L_DYY, dyy.m, 16);
+  __syncthreads();
+  prod_dy_dk(L_DKB, 6, L_YB, false); prod_dy_dk(L_DKY, 10, L_YY, true);
+  __syncthreads();
+  for (int e = lane; e < 160; e += 64) out160[e] = L[L_YB + e];  // YB (60) | YY (100) are adjacent
+  __syncthreads();
+}
+#endif
+
 // blocks J^T S^-1 J, J^T S^-1 r with S^-1 = cov_inv * weight (BundleAdjuster.cpp:1526)
 #if defined(__HIPCC__)
 // Wave mode of imu_blocks: operands in LDS (info | dz1 | dz2 | j1t | j2t, 5 x 225 doubles), the three

@@ -114,7 +114,7 @@ struct Engine {
   int dbg_host_structure = 0;            // 1: build the static lists on the host (structure.h) (key 5)
   int dbg_linearize_variant = 0;         // 0 LDS-staged factor rows, 1 direct stores (key 4)
   int dbg_tile_order = 0;                // 0 row-major tiles, 1 XCD-aware columns (key 2)
-  int dbg_imu_wave = -1;                 // k_imu: -1 by count, 0 lane per residual, 1 wavefront per residual, 2 fused single pass (key 6)
+  int dbg_imu_wave = -1;                 // k_imu: -1 by count, 0 lanes, 1 wavefront per residual, 2 fused single pass, 4 wavefront per residual and per sample (key 6)
   int dbg_all_tiles = 0;                 // 1: assemble / zero every lower tile, not only the factor's pattern (key 3)
   DBuf<uint2> pair_ent;                  // (rowA, rowB) rank-1 terms of the off-diagonal blocks
   DBuf<uint32_t> pose_ptr, pose_mid;     // [Pact+1], [Pact]

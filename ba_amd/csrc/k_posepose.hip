@@ -124,13 +124,15 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
       double* __restrict__ res_out /* mode 2, optional: the residual vectors, 15 per residual */,
       int cov_once, double* __restrict__ frozen, uint8_t* __restrict__ cov_done,
       const double* __restrict__ steps /* k_imu_steps, or null: integrate with Jacobians here */) {
-  if (mode == 3) {
+  __shared__ double wave_lds[1280];  // products: both operands + output (<= 3 x 225); the inverse: 2 x 225; accumulation: 420; blocks: 5 x 225; step chain: 986
+  if (mode == 3 || mode == 5) {
     // Step Jacobians of the pre-integration, one lane per IMU sample (dpose.h: imu_step_jacobians);
     // n = number of samples, RS = number of residuals; `mptr` is the CSR of the samples over the
     // residuals (the residual of sample j by binary search).  A mode of this kernel rather than a kernel
     // of its own: two kernels with different private-memory sizes alternating on one queue make the
     // runtime re-size the queue's scratch at every launch.
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    // mode 5: a wavefront per sample (dpose.h: imu_step_jacobians_wave), j uniform over the workgroup
+    const uint32_t j = mode == 5 ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (uint32_t)n) return;
     uint32_t lo = 0, hi = (uint32_t)RS;
     while (hi - lo > 1) {
@@ -141,6 +143,12 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     if (k == 0 || j >= mptr[ri + 1]) return;          // sample 0 starts the integration: no step ends there
     if (cov_once && cov_done[ri]) return;             // frozen covariance / bias Jacobian: not needed
     const double gg[3] = {grav[0], grav[1], grav[2]};
+    if (mode == 5) {
+      const WaveCtx ws = {wave_lds, (int)threadIdx.x};
+      imu_step_jacobians_wave(state + (size_t)p1[ri] * kPoseState, meas + (size_t)mptr[ri] * 7, (int)k, gg,
+                              const_cast<double*>(steps) + (size_t)j * 160, &ws);
+      return;
+    }
     imu_step_jacobians(state + (size_t)p1[ri] * kPoseState, meas + (size_t)mptr[ri] * 7, (int)k, gg,
                        const_cast<double*>(steps) + (size_t)j * 160);
     return;
@@ -149,7 +157,6 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
   // (uniform loads), the dense 10x10 / 15x15 products are dealt to the lanes through LDS (dpose.h:
   // WaveCtx; bitwise the scalar results), the outputs are stored lane-strided.  For moderate residual
   // counts: the private memory of a dispatch grows with its wavefronts.
-  __shared__ double wave_lds[1280];  // products: both operands + output (<= 3 x 225); the inverse: 2 x 225; accumulation: 420; blocks: 5 x 225
   const bool wave = mode == 4;
   const WaveCtx wctx = {wave_lds, (int)threadIdx.x};
   const WaveCtx* wc = wave ? &wctx : nullptr;
@@ -384,7 +391,12 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
     if (!fused && n_meas) {
       BAE_HIP(e->imu_steps.alloc((size_t)n_meas * 160));
       steps = e->imu_steps.p;
-      hipLaunchKernelGGL(k_imu, dim3((n_meas + 63) / 64), dim3(64), 0, s2, (int)n_meas, 3, (int)ni, 0, 0.0, e->imu_p1.p,
+      // the step pass with a wavefront per SAMPLE and its Jacobian chain in LDS (mode 5) is an experiment
+      // (ba_hip_debug_set key 6 = 4): 130 us less device time on a 30-pose window, nothing on the wall clock
+      // of Solve(1) — the host is the bound there — and every wavefront of k_imu reserves the kernel's
+      // full private-memory frame, which a launch of one wavefront per sample multiplies
+      const bool wave_s = e->dbg_imu_wave == 4;
+      hipLaunchKernelGGL(k_imu, dim3(wave_s ? n_meas : (n_meas + 63) / 64), dim3(64), 0, s2, (int)n_meas, wave_s ? 5 : 3, (int)ni, 0, 0.0, e->imu_p1.p,
                          e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                          e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
                          e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,
@@ -393,7 +405,7 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
     // a wavefront per residual (mode 4) up to 16k residuals; one lane per residual beyond
     // (ba_hip_debug_set key 6: 0 = one lane per residual, 1 = a wavefront per residual, -1 = by count)
     static const uint32_t wave_max = getenv("BA_HIP_IMU_WAVE_MAX") ? (uint32_t)atoi(getenv("BA_HIP_IMU_WAVE_MAX")) : 16384u;
-    const bool wave = steps && (e->dbg_imu_wave < 0 ? ni <= wave_max : e->dbg_imu_wave != 0);
+    const bool wave = steps && (e->dbg_imu_wave < 0 ? ni <= wave_max : e->dbg_imu_wave != 0);  // (2: fused, no steps)
     hipLaunchKernelGGL(k_imu, dim3(wave ? ni : (ni + 63) / 64), dim3(64), 0, s2, (int)ni, wave ? 4 : 1, e->pose_dim,
                        e->opt.use_robust_norm_for_inertial_residuals, c_huber_proj, e->imu_p1.p,
                        e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,

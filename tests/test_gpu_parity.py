@@ -2341,9 +2341,10 @@ def test_calibration_at_config1_scale_matches_oracle(oracle_lib, kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("pose_dim", [9, 15])
 def test_inertial_linearisation_variants_agree(pose_dim):
-    """k_imu's three forms — single pass (step Jacobians inside), two passes with one lane per residual,
-    two passes with a wavefront per residual (dense products dealt to the lanes through LDS) — run the
-    same operations in the same order (bitwise equal when compiled for the host, tests/test_hostcheck.py;
+    """k_imu's forms — single pass (step Jacobians inside, variant 2), two passes with one lane per sample /
+    residual (0), a wavefront per residual (dense products dealt to the lanes through LDS) over the
+    lane-per-sample step pass (1, what runs), the same over a wavefront per sample with the RK4 Jacobian
+    chain resident in LDS (4, experiment) — run the same operations in the same order (bitwise equal when compiled for the host, tests/test_hostcheck.py;
     on the device the compiler contracts multiply-adds per code shape): S, rhs and the Gauss-Newton step
     agree to a few units in the last place."""
     P = 40
@@ -2362,7 +2363,7 @@ def test_inertial_linearisation_variants_agree(pose_dim):
         return h.summary().inertial_error, h.S(), h.rhs(), h.delta_p()
     ref = run(2)
     assert np.abs(ref[1]).max() > 0 and ref[0] > 0
-    for variant in (0, 1):
+    for variant in (0, 1, 4):
         got = run(variant)
         assert abs(got[0] - ref[0]) <= 1e-12 * ref[0]
         assert rel_err(got[1], ref[1]) < 1e-12 and rel_err(got[2], ref[2]) < 1e-12, variant
