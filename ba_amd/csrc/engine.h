@@ -183,6 +183,7 @@ struct Engine {
   // device-to-host copy and ONE synchronisation for the whole phase call (a small window pays ~30 us per
   // round trip: four of them made ba_hip_dogleg_terms 140 us).  Off for sharded engines, whose sums go
   // through the all-reduce hook one by one.
+  std::vector<hipEvent_t> timer_events;  // pool of the phase timers (engine.hip: EventTimer)
   bool defer_active = false;
   int defer_n = 0;
   double* defer_host[40];

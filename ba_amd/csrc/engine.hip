@@ -57,27 +57,43 @@ static int upload(Engine* e, DBuf<T>& buf, const std::vector<T>& v, size_t min_c
   return 0;
 }
 
+// Phase timer on the engine's stream.  The two events come from a pool the engine keeps (creating and
+// destroying a pair per phase call cost a small window ~10 us each time).
 struct EventTimer {
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t s;
-  explicit EventTimer(hipStream_t st) : s(st) {
-    (void)hipEventCreate(&a);
-    (void)hipEventCreate(&b);
+  Engine* eng;
+  explicit EventTimer(Engine* e) : s(e->stream), eng(e) {
+    a = take();
+    b = take();
     (void)hipEventRecord(a, s);
   }
+  ~EventTimer() { give(); }  // (an error path that never read the timer)
   // mark(): the end point in stream order; read_ms(): wait for it and read — apart, so that a phase call
   // can mark several intervals and pay for ONE synchronisation at its end
   void mark() { (void)hipEventRecord(b, s); marked = true; }
   double stop_ms() { mark(); return read_ms(); }
   bool marked = false;
   double read_ms() {
+    if (!a) return 0.0;
     if (!marked) mark();
     (void)hipEventSynchronize(b);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, a, b);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    give();
     return ms;
+  }
+ private:
+  hipEvent_t take() {
+    if (!eng->timer_events.empty()) { hipEvent_t ev = eng->timer_events.back(); eng->timer_events.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+  }
+  void give() {
+    if (a) eng->timer_events.push_back(a);
+    if (b) eng->timer_events.push_back(b);
+    a = b = nullptr;
   }
 };
 
@@ -479,6 +495,8 @@ void ba_hip_destroy(ba_hip_engine* h) {
   comm_release(e);
   if (e->ev_imu_done) { (void)hipEventDestroy(e->ev_imu_done); (void)hipEventDestroy(e->ev_imu_start); }
   if (e->ev_fork) { (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
+  for (hipEvent_t ev : e->timer_events) (void)hipEventDestroy(ev);
+  e->timer_events.clear();
   for (hipEvent_t ev : e->ev_panel) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->ev_bulk) (void)hipEventDestroy(ev);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -882,11 +900,11 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   ba_hip_errors errs = {0, 0, 0, 0};
   int rc;
   // projection errors at the linearisation point -> Huber sigma
-  EventTimer t_j(e->stream);
+  EventTimer t_j(e);
   if ((rc = launch_pose_prep(e))) return rc;
   if ((rc = launch_residuals(e, 0))) return rc;
   t_j.mark();
-  EventTimer t_r(e->stream);
+  EventTimer t_r(e);
   double c_huber = 0.0;
   uint64_t n_total = st.O;
   if (e->sharded()) {
@@ -904,7 +922,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   }
   t_r.mark();
   if ((rc = launch_imu_early(e, c_huber))) return rc;  // overlaps the projection linearisation
-  EventTimer t_l(e->stream);
+  EventTimer t_l(e);
   // from here on every sum stays on the device until ONE copy at the end of the call (defer_flush): the
   // assembly and the pose-pose kernels are enqueued without waiting for the linearisation to finish
   double* hs = e->eval_h;  // proj | unary | binary | inertial
@@ -915,7 +933,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   // partial per linearisation wave
   if ((rc = sum_partials(e, st.O ? st.n_chunks : 0, 1, hs))) { (void)defer_flush(e); return rc; }
   t_l.mark();
-  EventTimer t_s(e->stream);
+  EventTimer t_s(e);
   e->factored = false;
   if ((rc = launch_gather_S(e)) || (rc = launch_posepose_build(e, c_huber, hs + 1))) { (void)defer_flush(e); return rc; }
   // copy the reduced rhs into the rhs row of A
@@ -966,7 +984,7 @@ int ba_hip_solve_gn(ba_hip_engine* h) {
   BAE_HIP(hipSetDevice(e->device));
   const Structure& st = e->st;
   int status = 0, rc;
-  EventTimer t(e->stream);
+  EventTimer t(e);
   // CalculateGn runs only with active poses (BundleAdjuster.cpp:959-964, 1089-1094): with none, the
   // calibration unknowns are not solved for either (delta_k stays empty in the reference)
   const bool skip = st.K && st.Pact == 0;
@@ -984,7 +1002,7 @@ int ba_hip_solve_gn(ba_hip_engine* h) {
     e->factored = true;
   }
   e->timers.solve = t.stop_ms();
-  EventTimer tb(e->stream);
+  EventTimer tb(e);
   if ((rc = launch_backsub(e))) return rc;
   e->timers.back_substitution = tb.stop_ms();
   return status ? BA_HIP_FACTORIZATION_ERROR : 0;
@@ -1026,7 +1044,7 @@ int ba_hip_apply_step(ba_hip_engine* h) {
   ENG(h);
   NEED_FINAL();
   BAE_HIP(hipSetDevice(e->device));
-  EventTimer t(e->stream);
+  EventTimer t(e);
   int rc = launch_apply_step(e);
   if (rc) return rc;
   e->cur = 1 - e->cur;
@@ -1097,7 +1115,7 @@ int ba_hip_eval_residuals(ba_hip_engine* h, ba_hip_errors* out) {
   NEED_FINAL();
   BAE_HIP(hipSetDevice(e->device));
   ba_hip_errors errs = {0, 0, 0, 0};
-  EventTimer t(e->stream);
+  EventTimer t(e);
   double* hs = e->eval_h;  // proj | unary | binary | inertial: one copy for the four sums (defer_flush)
   for (int i = 0; i < 4; ++i) hs[i] = 0.0;
   defer_begin(e);
