@@ -188,6 +188,7 @@ struct Engine {
   int defer_n = 0;
   double* defer_host[40];
   double dog_h[8];                       // landing place of the dogleg sums (ba_hip_dogleg_terms)
+  bool dog_jrhs_valid = false;           // dog_h[6], dog_h[7] (|J rhs|^2: projection / pose-pose part) belong to the current linearisation
   double eval_h[4];                      // ... of the evaluation sums (ba_hip_eval_residuals)
   DBuf<unsigned long long> hist;         // selection histograms
   DBuf<int32_t> flags;                   // factorisation status block (k_chol.hip: setup_status_block)
@@ -237,7 +238,7 @@ size_t packed_lower_count(uint32_t n_pad);                        // pair gather
 int launch_backsub(Engine* e);                         // delta_l
 int launch_compose_step(Engine* e, double coef_rhs, double coef_gn, double* norms2_host);
 int launch_apply_step(Engine* e);                      // state[cur] -> state[1-cur]
-int launch_dogleg(Engine* e, int gn_available, double* h7);
+int launch_dogleg(Engine* e, int gn_available, double* h7, bool skip_jrhs);
 int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, double* out);
 int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, bool cross_shard = true);
 void defer_begin(Engine* e);   // k_reduce.hip

@@ -899,6 +899,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   const Structure& st = e->st;
   ba_hip_errors errs = {0, 0, 0, 0};
   int rc;
+  e->dog_jrhs_valid = false;
   // projection errors at the linearisation point -> Huber sigma
   EventTimer t_j(e);
   if ((rc = launch_pose_prep(e))) return rc;
@@ -1015,11 +1016,15 @@ int ba_hip_dogleg_terms(ba_hip_engine* h, int gn_available, ba_hip_dogleg_scalar
   // every sum of this call stays on the device until ONE copy at the end (defer_flush)
   memset(out, 0, sizeof(*out));
   double* dh = e->dog_h;
+  // the steepest-descent denominator |J rhs|^2 does not involve the Gauss-Newton step: the second call of
+  // an iteration (gn_available, BundleAdjuster.cpp:971-1002) reuses what the first one summed
+  const bool reuse = gn_available && e->dog_jrhs_valid;
   defer_begin(e);
-  int rc = launch_dogleg(e, gn_available, dh);
-  if (!rc) rc = launch_posepose_jrhs(e, dh + 7);
+  int rc = launch_dogleg(e, gn_available, dh, reuse);
+  if (!rc && !reuse) rc = launch_posepose_jrhs(e, dh + 7);
   const int rf = defer_flush(e);
-  if (rc || rf) return rc ? rc : rf;
+  if (rc || rf) { e->dog_jrhs_valid = false; return rc ? rc : rf; }
+  e->dog_jrhs_valid = true;
   out->rhs_p_sq = dh[0]; out->gn_p_sq = dh[1]; out->rhs_gn_p = dh[2];
   out->rhs_l_sq = dh[3]; out->gn_l_sq = dh[4]; out->rhs_gn_l = dh[5];
   out->j_rhs_sq = dh[6] + dh[7];

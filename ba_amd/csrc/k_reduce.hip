@@ -1084,9 +1084,10 @@ __global__ void k_jrhs(uint32_t O, int D, int LM, const uint32_t* __restrict__ o
 
 // The seven sums land in h7 = (rhs_p_sq, gn_p_sq, rhs_gn_p | rhs_l_sq, gn_l_sq, rhs_gn_l | j_rhs_sq): a buffer
 // that outlives a deferred flush (Engine::dog_h); ba_hip_dogleg_terms moves them into the result.
-int launch_dogleg(Engine* e, int gn_available, double* h7) {
+// skip_jrhs: the denominator term is known from an earlier call at the same linearisation (h7[6] untouched)
+int launch_dogleg(Engine* e, int gn_available, double* h7, bool skip_jrhs) {
   const Structure& st = e->st;
-  for (int i = 0; i < 7; ++i) h7[i] = 0.0;
+  for (int i = 0; i < (skip_jrhs ? 6 : 7); ++i) h7[i] = 0.0;
   int rc;
   if (st.np > 0) {  // pose parts: replicated on every shard
     const uint32_t nb = (st.np + 255) / 256;
@@ -1104,7 +1105,7 @@ int launch_dogleg(Engine* e, int gn_available, double* h7) {
     }
     if ((rc = sum_partials(e, nb, 3, h7 + 3, true))) return rc;
   }
-  {  // || J_pr rhs_p + J_l rhs_l ||^2 over the observations (BundleAdjuster.cpp:881-906)
+  if (!skip_jrhs) {  // || J_pr rhs_p + J_l rhs_l ||^2 over the observations (BundleAdjuster.cpp:881-906)
     const uint32_t nb = st.O > 0 ? (st.O + 255) / 256 : 0;
     if (nb) {
       hipLaunchKernelGGL(k_jrhs, dim3(nb), dim3(256), 0, e->stream, st.O, e->pose_dim, e->lm_dim,
