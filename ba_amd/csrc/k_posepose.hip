@@ -125,14 +125,13 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
       int cov_once, double* __restrict__ frozen, uint8_t* __restrict__ cov_done,
       const double* __restrict__ steps /* k_imu_steps, or null: integrate with Jacobians here */) {
   __shared__ double wave_lds[1280];  // products: both operands + output (<= 3 x 225); the inverse: 2 x 225; accumulation: 420; blocks: 5 x 225; step chain: 986
-  if (mode == 3 || mode == 5) {
+  if (mode == 3) {
     // Step Jacobians of the pre-integration, one lane per IMU sample (dpose.h: imu_step_jacobians);
     // n = number of samples, RS = number of residuals; `mptr` is the CSR of the samples over the
     // residuals (the residual of sample j by binary search).  A mode of this kernel rather than a kernel
     // of its own: two kernels with different private-memory sizes alternating on one queue make the
     // runtime re-size the queue's scratch at every launch.
-    // mode 5: a wavefront per sample (dpose.h: imu_step_jacobians_wave), j uniform over the workgroup
-    const uint32_t j = mode == 5 ? blockIdx.x : blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (uint32_t)n) return;
     uint32_t lo = 0, hi = (uint32_t)RS;
     while (hi - lo > 1) {
@@ -143,12 +142,6 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
     if (k == 0 || j >= mptr[ri + 1]) return;          // sample 0 starts the integration: no step ends there
     if (cov_once && cov_done[ri]) return;             // frozen covariance / bias Jacobian: not needed
     const double gg[3] = {grav[0], grav[1], grav[2]};
-    if (mode == 5) {
-      const WaveCtx ws = {wave_lds, (int)threadIdx.x};
-      imu_step_jacobians_wave(state + (size_t)p1[ri] * kPoseState, meas + (size_t)mptr[ri] * 7, (int)k, gg,
-                              const_cast<double*>(steps) + (size_t)j * 160, &ws);
-      return;
-    }
     imu_step_jacobians(state + (size_t)p1[ri] * kPoseState, meas + (size_t)mptr[ri] * 7, (int)k, gg,
                        const_cast<double*>(steps) + (size_t)j * 160);
     return;
@@ -342,6 +335,33 @@ static int sum_small(Engine* e, int n, const double* d_v, double* host) {
   return 0;
 }
 
+// The step pass with ONE WAVEFRONT PER SAMPLE and the RK4 Jacobian chain resident in LDS (dpose.h:
+// imu_step_jacobians_wave) — for sliding windows, where a few hundred samples cannot fill the device and the
+// lane-per-sample form (k_imu mode 3) is one long private-memory chain per lane: 179 -> ~50 us on a 30-pose
+// window.  Every lane repeats the scalar part (state prefix, closed-form blocks), so beyond a few thousand
+// samples the lane-per-sample form is the faster one again (configs[2], 50k samples: 3.1 ms against 7.7 ms for
+// both passes).  A kernel of its own: its private frame is a tenth of k_imu's.
+__global__ void __launch_bounds__(64)
+k_imu_steps_wave(int n, int RS, const uint32_t* __restrict__ p1, const uint32_t* __restrict__ mptr,
+                 const double* __restrict__ meas, const double* __restrict__ grav, const double* __restrict__ state,
+                 int cov_once, const uint8_t* __restrict__ cov_done, double* __restrict__ steps) {
+  __shared__ double lds[1024];
+  const uint32_t j = blockIdx.x;
+  if (j >= (uint32_t)n) return;
+  uint32_t lo = 0, hi = (uint32_t)RS;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (mptr[mid] <= j) lo = mid; else hi = mid;
+  }
+  const uint32_t ri = lo, k = j - mptr[ri];
+  if (k == 0 || j >= mptr[ri + 1]) return;
+  if (cov_once && cov_done[ri]) return;
+  const double gg[3] = {grav[0], grav[1], grav[2]};
+  const WaveCtx ws = {lds, (int)threadIdx.x};
+  imu_step_jacobians_wave(state + (size_t)p1[ri] * kPoseState, meas + (size_t)mptr[ri] * 7, (int)k, gg,
+                          steps + (size_t)j * 160, &ws);
+}
+
 // The inertial residuals of BuildProblem (k_imu: one lane per residual, RK4 + 15x15 algebra — a few
 // milliseconds of latency-bound work on ~80 wavefronts) depend on the state and on the projection
 // Huber constant only, not on the projection linearisation: they run on the engine's second stream
@@ -383,6 +403,8 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
   if (ni) {
     // two launches: the step Jacobians of every sample in parallel, then one lane per residual for the
     // sequential part (states, accumulations, the 15x15 algebra).  BA_HIP_IMU_FUSED=1: the single-launch form
+    static const int variant_env = getenv("BA_HIP_IMU_VARIANT") ? atoi(getenv("BA_HIP_IMU_VARIANT")) : -1;  // experiments: as debug key 6
+    if (variant_env >= 0 && e->dbg_imu_wave < 0) e->dbg_imu_wave = variant_env;
     static const bool fused_env = getenv("BA_HIP_IMU_FUSED") != nullptr;
     const bool fused = fused_env || e->dbg_imu_wave == 2;  // (key 6 = 2: the single-pass form)
     const uint32_t n_meas = (uint32_t)(pb.imu_meas.size() / 7);
@@ -391,12 +413,16 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
     if (!fused && n_meas) {
       BAE_HIP(e->imu_steps.alloc((size_t)n_meas * 160));
       steps = e->imu_steps.p;
-      // the step pass with a wavefront per SAMPLE and its Jacobian chain in LDS (mode 5) is an experiment
-      // (ba_hip_debug_set key 6 = 4): 130 us less device time on a 30-pose window, nothing on the wall clock
-      // of Solve(1) — the host is the bound there — and every wavefront of k_imu reserves the kernel's
-      // full private-memory frame, which a launch of one wavefront per sample multiplies
-      const bool wave_s = e->dbg_imu_wave == 4;
-      hipLaunchKernelGGL(k_imu, dim3(wave_s ? n_meas : (n_meas + 63) / 64), dim3(64), 0, s2, (int)n_meas, wave_s ? 5 : 3, (int)ni, 0, 0.0, e->imu_p1.p,
+      // a wavefront per sample (k_imu_steps_wave) while the samples are few, one lane per sample (mode 3) beyond
+      // (ba_hip_debug_set key 6: 4 forces the former, 0 / 1 the latter)
+      static const uint32_t steps_wave_max = getenv("BA_HIP_IMU_STEPS_WAVE_MAX") ? (uint32_t)atoi(getenv("BA_HIP_IMU_STEPS_WAVE_MAX")) : 2048u;
+      const bool wave_s = e->dbg_imu_wave < 0 ? n_meas <= steps_wave_max : e->dbg_imu_wave == 4;
+      if (wave_s)
+        hipLaunchKernelGGL(k_imu_steps_wave, dim3(n_meas), dim3(64), 0, s2, (int)n_meas, (int)ni, e->imu_p1.p, e->imu_ptr.p,
+                           e->imu_meas.p, e->imu_consts.p, state, e->imu_cov_once ? 1 : 0, e->imu_cov_done.p,
+                           e->imu_steps.p);
+      else
+        hipLaunchKernelGGL(k_imu, dim3((n_meas + 63) / 64), dim3(64), 0, s2, (int)n_meas, 3, (int)ni, 0, 0.0, e->imu_p1.p,
                          e->imu_p2.p, e->imu_ptr.p, e->imu_meas.p, e->imu_consts.p, e->imu_consts.p + 3,
                          e->pose_active.p, state, e->imu_cov_inv.p, e->pp_h.p, e->pp_g.p, e->pp_dz.p,
                          e->pp_info.p, nu + nb, e->pp_err.p + nu + nb, (double*)nullptr, e->imu_cov_once ? 1 : 0,

@@ -343,8 +343,8 @@ int ba_hip_get_structure_stats(ba_hip_engine* e, ba_hip_structure_stats* out);
  * key 4 = linearisation variant (0 LDS-staged rows, 1 direct stores), key 5 = 1: build the static
  * lists on the host (structure.h) instead of on the device at the next ba_hip_finalize, key 6 = variant
  * of the inertial linearisation (-1 chosen by residual count, 0 one lane per sample / per residual, 1 a
- * wavefront per residual, 2 the single-pass form with the step Jacobians inside, 4 a wavefront per residual
- * AND per sample). */
+ * wavefront per residual over the lane-per-sample step pass, 2 the single-pass form with the step Jacobians
+ * inside, 4 a wavefront per residual AND per sample). */
 int ba_hip_debug_set(ba_hip_engine* e, int key, int value);
 int ba_hip_set_profiling(ba_hip_engine* e, int enable);
 int ba_hip_get_kernel_stats(ba_hip_engine* e, ba_hip_kernel_stats* out);

@@ -12,7 +12,7 @@ for P, L in ((30, 1500), (100, 5000)):
     scene.populate(h, sc, imu=True)
     h.Solve(2)
     for rep in range(3):
-        for v in (1, 4):
+        for v in (tuple(int(x) for x in sys.argv[1:]) or (1, 4)):
             h.engine().debug_set(6, v)
             h.Solve(1)
             t = time.perf_counter()

@@ -2343,8 +2343,9 @@ def test_calibration_at_config1_scale_matches_oracle(oracle_lib, kind):
 def test_inertial_linearisation_variants_agree(pose_dim):
     """k_imu's forms — single pass (step Jacobians inside, variant 2), two passes with one lane per sample /
     residual (0), a wavefront per residual (dense products dealt to the lanes through LDS) over the
-    lane-per-sample step pass (1, what runs), the same over a wavefront per sample with the RK4 Jacobian
-    chain resident in LDS (4, experiment) — run the same operations in the same order (bitwise equal when compiled for the host, tests/test_hostcheck.py;
+    lane-per-sample step pass (1), the same over a wavefront per sample with the RK4 Jacobian chain resident
+    in LDS (4: k_imu_steps_wave, what runs on windows of up to 2048 samples) — run the same operations in
+    the same order (bitwise equal when compiled for the host, tests/test_hostcheck.py;
     on the device the compiler contracts multiply-adds per code shape): S, rhs and the Gauss-Newton step
     agree to a few units in the last place."""
     P = 40
