@@ -162,60 +162,49 @@ BA_HD void invert_leading(DM<N, N>& a, int n) {
     for (int c = 0; c < n; ++c) a(r, c) = inv(r, c);
 }
 
-// The same elimination with the 2 n^2 entries of [a | inv] dealt to the lanes of one wavefront and both
-// matrices in LDS (w->lds: 2 * N * N doubles): per column the pivot search (every lane reads the
-// column: same decision everywhere), the row swap, the scaling of the pivot row and the elimination
-// of all other rows, each entry by the expression of invert_leading — bitwise the same inverse.
+// The same elimination with the 2 n^2 entries of [a | inv] dealt to the lanes of one wavefront and the
+// matrices in LDS (w->lds: 4 * N * N doubles, two copies of [a | inv]): column by column every lane finds
+// the pivot (it reads the column: same decision everywhere) and writes its entries of the NEXT copy from
+// the current one — row swap, scaling of the pivot row and elimination of the other rows in one pass,
+// each entry by the expression of invert_leading (bitwise the same inverse), one barrier per column.
 template <int N>
 BA_HD void invert_leading(DM<N, N>& a, int n, const WaveCtx* w) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (w) {
-    double* A = w->lds;
-    double* I = w->lds + N * N;
+    double* B0 = w->lds;              // [A | I] of even columns
+    double* B1 = w->lds + 2 * N * N;  // ... of odd columns
     const int lane = w->lane;
-    for (int e = lane; e < N * N; e += 64) { A[e] = a.m[e]; I[e] = ((e / N) == (e % N)) ? 1.0 : 0.0; }
+    for (int e = lane; e < N * N; e += 64) { B0[e] = a.m[e]; B0[N * N + e] = ((e / N) == (e % N)) ? 1.0 : 0.0; }
     __syncthreads();
     for (int col = 0; col < n; ++col) {
+      const double* S = (col & 1) ? B1 : B0;
+      double* D = (col & 1) ? B0 : B1;
       int piv = col;
-      double best = fabs(A[col * N + col]);
+      double best = fabs(S[col * N + col]);
       for (int r = col + 1; r < n; ++r) {
-        const double v = fabs(A[r * N + col]);
+        const double v = fabs(S[r * N + col]);
         if (v > best) { best = v; piv = r; }
       }
-      __syncthreads();
-      if (piv != col && lane < 2 * n) {
-        double* M = lane < n ? A : I;
-        const int c = lane < n ? lane : lane - n;
-        const double t = M[piv * N + c]; M[piv * N + c] = M[col * N + c]; M[col * N + c] = t;
-      }
-      __syncthreads();
-      const double s = 1.0 / A[col * N + col];
-      __syncthreads();
-      if (lane < 2 * n) {
-        double* M = lane < n ? A : I;
-        const int c = lane < n ? lane : lane - n;
-        M[col * N + c] *= s;
-      }
-      __syncthreads();
-      // every other row r: x(r, c) -= f_r * x(col, c) with f_r = a(r, col) read before anything moves
-      double fa[8];
-      int cnt = 0;
-      for (int e = lane; e < 2 * n * n; e += 64, ++cnt) {
-        const int r = (e % (n * n)) / n;
-        fa[cnt] = A[r * N + col];
-      }
-      __syncthreads();
-      cnt = 0;
-      for (int e = lane; e < 2 * n * n; e += 64, ++cnt) {
+      const double s = 1.0 / S[piv * N + col];  // a(col, col) after the swap
+      for (int e = lane; e < 2 * n * n; e += 64) {
         const int m = e / (n * n), rc = e % (n * n), r = rc / n, c = rc % n;
-        if (r == col || fa[cnt] == 0.0) continue;
-        double* M = m ? I : A;
-        M[r * N + c] -= fa[cnt] * M[col * N + c];
+        const double* M = S + m * N * N;
+        const double pc = M[piv * N + c] * s;  // the scaled pivot row
+        double v;
+        if (r == col) v = pc;
+        else {
+          const int rs = r == piv ? col : r;   // the row that sits at r after the swap
+          const double f = S[rs * N + col];
+          v = M[rs * N + c];
+          if (f != 0.0) v -= f * pc;
+        }
+        D[m * N * N + r * N + c] = v;
       }
       __syncthreads();
     }
+    const double* R = ((n & 1) ? B1 : B0) + N * N;
     for (int r = 0; r < n; ++r)
-      for (int c = 0; c < n; ++c) a(r, c) = I[r * N + c];
+      for (int c = 0; c < n; ++c) a(r, c) = R[r * N + c];
     __syncthreads();
     return;
   }

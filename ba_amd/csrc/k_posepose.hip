@@ -124,7 +124,7 @@ k_imu(int n, int mode, int RS, int use_robust, double c_huber, const uint32_t* _
       double* __restrict__ res_out /* mode 2, optional: the residual vectors, 15 per residual */,
       int cov_once, double* __restrict__ frozen, uint8_t* __restrict__ cov_done,
       const double* __restrict__ steps /* k_imu_steps, or null: integrate with Jacobians here */) {
-  __shared__ double wave_lds[1280];  // products: both operands + output (<= 3 x 225); the inverse: 2 x 225; accumulation: 420; blocks: 5 x 225; step chain: 986
+  __shared__ double wave_lds[1280];  // products: both operands + output (<= 3 x 225); the inverse: 4 x 225; accumulation: 420; blocks: 5 x 225; step chain: 986
   if (mode == 3) {
     // Step Jacobians of the pre-integration, one lane per IMU sample (dpose.h: imu_step_jacobians);
     // n = number of samples, RS = number of residuals; `mptr` is the CSR of the samples over the
