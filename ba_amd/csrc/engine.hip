@@ -866,6 +866,7 @@ int ba_hip_get_conditioning_error(ba_hip_engine* h, double* proj_sq_sum) {
 int ba_hip_begin_solve(ba_hip_engine* h) {
   ENG(h);
   NEED_FINAL();
+  e->dog_jrhs_valid = false;
   BAE_HIP(hipSetDevice(e->device));
   if (!e->prob.pose_cam_params.empty() && e->prob.pose_cam_params.size() != 4 * (size_t)e->prob.num_poses)
     return e->fail_msg("per-pose camera parameters: one [fx,fy,u0,v0] per pose expected");
@@ -889,6 +890,7 @@ int ba_hip_set_pose_masks(ba_hip_engine* h, uint32_t n, const uint16_t* masks) {
   ENG(h);
   NEED_FINAL();
   if (n != e->st.P) return e->fail_msg("mask count != pose count");
+  e->dog_jrhs_valid = false;
   return set_masks_device(e, std::vector<uint16_t>(masks, masks + n));
 }
 
