@@ -24,8 +24,10 @@ from oracle import pyoracle as po  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def make(name, lm_dim, P, L, K, seed, iters, dogleg=0):
+def make(name, lm_dim, P, L, K, seed, iters, dogleg=0, fov_w=None):
     sc = scene.make_scene(P, L, K, lm_dim=lm_dim, seed=seed)
+    if fov_w:
+        scene.to_fov_camera(sc, fov_w)  # cam_params gets its fifth entry: a calibu::FovCamera
     act = np.ones(P, dtype=np.uint8)
     act[sc.anchor_poses] = 0
     ba = po.OracleBundleAdjuster(lm_dim, 6)
@@ -52,3 +54,4 @@ if __name__ == "__main__":
     make("config1_lm1", 1, 50, 200, 10, seed=101, iters=4)
     make("config1_lm3", 3, 50, 200, 10, seed=103, iters=4)
     make("config1_lm1_dogleg", 1, 50, 200, 10, seed=105, iters=4, dogleg=1)
+    make("config1_lm1_fov", 1, 50, 200, 10, seed=107, iters=4, fov_w=0.93)
