@@ -468,7 +468,8 @@ int ba_hip_create(int lm_dim, int pose_dim, int device, void* stream, ba_hip_eng
   return 0;
 }
 
-#define ENG(h) Engine* e = reinterpret_cast<Engine*>(h)
+// (every entry point starts outside a deferred-sum scope, whatever an earlier call's error path left behind)
+#define ENG(h) Engine* e = reinterpret_cast<Engine*>(h); e->defer_active = false; e->defer_n = 0
 
 void ba_hip_destroy(ba_hip_engine* h) {
   if (!h) return;
