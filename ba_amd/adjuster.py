@@ -65,7 +65,7 @@ SYMBOLS = [
     "ba_adjuster_is_landmark_reliable", "ba_adjuster_landmark_outlier_ratio",
     "ba_adjuster_get_projection_residual", "ba_adjuster_get_imu_residual",
     "ba_adjuster_get_summary", "ba_adjuster_get_cond_errors", "ba_adjuster_get_timers", "ba_adjuster_engine",
-    "ba_adjuster_set_allreduce", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
+    "ba_adjuster_set_allreduce", "ba_adjuster_set_communicator", "ba_adjuster_solve_is_distributed", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
     "ba_adjuster_get_last_calib_step", "ba_adjuster_get_calibration_marginals", "ba_adjuster_get_camera_params",
     "ba_adjuster_add_camera_fov", "ba_adjuster_get_camera_fov",
 ]
@@ -392,3 +392,14 @@ class BundleAdjuster:
             return
         self._cb = hipapi.ALLREDUCE_FN(lambda ctx, ptr, count, dtype: int(fn(ptr, count, dtype)))
         self.L.ba_adjuster_set_allreduce(self.h, self._cb, None, int(rank), int(nranks))
+
+    def set_communicator(self, unique_id, rank, nranks, distributed_solve=True):
+        """ba::BundleAdjuster::SetCommunicator: the engine's own RCCL communicator (unique_id = 128 bytes from
+        hipapi.Engine.comm_unique_id() on rank 0); None clears it.  The next Solve() joins (collective)."""
+        if unique_id is None:
+            self.L.ba_adjuster_set_communicator(self.h, None, 0, 1, 0)
+            return
+        self.L.ba_adjuster_set_communicator(self.h, C.c_char_p(unique_id), int(rank), int(nranks), 1 if distributed_solve else 0)
+
+    def solve_is_distributed(self):
+        return bool(self.L.ba_adjuster_solve_is_distributed(self.h))

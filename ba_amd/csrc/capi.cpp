@@ -40,6 +40,8 @@ struct Iface {
   virtual void timers(ba_hip_timers* t) const = 0;
   virtual ba_hip_engine* engine() = 0;
   virtual void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) = 0;
+  virtual void set_communicator(const void* id128, int rank, int nranks, int distributed) = 0;
+  virtual int solve_is_distributed() = 0;
   virtual void camera_pose(uint32_t cam, double* t7) const = 0;
   virtual void camera_params(uint32_t cam, double* p4) const = 0;
   virtual void last_calib_step(double* d6) const = 0;
@@ -179,6 +181,11 @@ struct Impl : Iface {
   }
   void timers(ba_hip_timers* t) const override { *t = ba.GetLastTimers(); }
   ba_hip_engine* engine() override { return ba.engine(); }
+  void set_communicator(const void* id128, int rank, int nranks, int distributed) override {
+    if (id128) ba.SetCommunicator(id128, rank, nranks, distributed != 0);
+    else ba.ClearCommunicator();
+  }
+  int solve_is_distributed() override { return ba.SolveIsDistributed() ? 1 : 0; }
   void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) override {
     ba.SetAllReduce(fn, ctx, rank, nranks);
   }
@@ -322,5 +329,7 @@ void ba_adjuster_get_camera_params(const ba_adjuster* a, uint32_t cam_id, double
 void ba_adjuster_get_last_calib_step(const ba_adjuster* a, double delta_k[6]) { a->p->last_calib_step(delta_k); }
 uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[36]) { return a->p->marginals(cov); }
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) { a->p->set_allreduce(fn, ctx, rank, nranks); }
+void ba_adjuster_set_communicator(ba_adjuster* a, const void* id128, int rank, int nranks, int distributed_solve) { a->p->set_communicator(id128, rank, nranks, distributed_solve); }
+int ba_adjuster_solve_is_distributed(ba_adjuster* a) { return a->p->solve_is_distributed(); }
 
 }  // extern "C"

@@ -25,6 +25,11 @@ struct RcclApi {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclCommSplit) CommSplit = nullptr;   // optional: absent -> the side transfers share the chain communicator
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string err;
 };
@@ -48,7 +53,12 @@ RcclApi* rccl() {
     BAE_SYM(Broadcast, ncclBroadcast)
     BAE_SYM(ReduceScatter, ncclReduceScatter)
     BAE_SYM(GetErrorString, ncclGetErrorString)
+    BAE_SYM(Send, ncclSend)
+    BAE_SYM(Recv, ncclRecv)
+    BAE_SYM(GroupStart, ncclGroupStart)
+    BAE_SYM(GroupEnd, ncclGroupEnd)
 #undef BAE_SYM
+    api.CommSplit = reinterpret_cast<decltype(api.CommSplit)>(dlsym(api.lib, "ncclCommSplit"));
   });
   return api.lib ? &api : nullptr;
 }
@@ -67,7 +77,7 @@ int native_allreduce(void* ctx, void* dev_ptr, size_t count, int dtype) {
   const ncclResult_t r = a->AllReduce(dev_ptr, dev_ptr, count, dtype == 0 ? ncclDouble : ncclUint64, ncclSum,
                                       static_cast<ncclComm_t>(e->comm), e->stream);
   if (r != ncclSuccess) { rccl_fail(e, "ncclAllReduce", r); return 1; }
-  return hipStreamSynchronize(e->stream) == hipSuccess ? 0 : 1;
+  return hipStreamSynchronize(e->stream) == hipSuccess ? 0 : 1;  // (bytes are counted by the callers' wrapper)
 }
 
 // collectives hook signature (ba_hip_collective_fn): op 1 broadcast, op 2 in-place reduce-scatter
@@ -92,6 +102,8 @@ int native_collective(void* ctx, int op, void* dev_ptr, size_t count, int root) 
 }  // namespace
 
 int dist_broadcast(Engine* e, double* buf, size_t count, int root, hipStream_t s) {
+  (root == e->rank ? e->cstats.chain_bytes_sent : e->cstats.chain_bytes_recv) += 8.0 * (double)count;
+  e->cstats.chain_messages++;
   if (e->comm && e->coll == native_collective) {
     RcclApi* a = rccl();
     const ncclResult_t r = a->Broadcast(buf, buf, count, ncclDouble, root, static_cast<ncclComm_t>(e->comm), s);
@@ -103,10 +115,57 @@ int dist_broadcast(Engine* e, double* buf, size_t count, int root, hipStream_t s
   return 0;
 }
 
+int dist_exchange(Engine* e, const std::vector<DistXfer>& x, bool side, hipStream_t s) {
+  if (x.empty()) return 0;
+  for (const DistXfer& t : x) {
+    double& ctr = side ? (t.send ? e->cstats.side_bytes_sent : e->cstats.side_bytes_recv)
+                       : (t.send ? e->cstats.chain_bytes_sent : e->cstats.chain_bytes_recv);
+    ctr += 8.0 * (double)t.count;
+    if (t.send) (side ? e->cstats.side_messages : e->cstats.chain_messages)++;
+  }
+  if (e->comm && e->coll == native_collective) {
+    RcclApi* a = rccl();
+    ncclComm_t comm = static_cast<ncclComm_t>(side && e->comm2 ? e->comm2 : e->comm);
+    ncclResult_t r = a->GroupStart();
+    if (r != ncclSuccess) return rccl_fail(e, "ncclGroupStart", r);
+    for (const DistXfer& t : x) {
+      r = t.send ? a->Send(t.buf, t.count, ncclDouble, t.peer, comm, s) : a->Recv(t.buf, t.count, ncclDouble, t.peer, comm, s);
+      if (r != ncclSuccess) { (void)a->GroupEnd(); return rccl_fail(e, t.send ? "ncclSend" : "ncclRecv", r); }
+    }
+    r = a->GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(e, "ncclGroupEnd", r);
+    return 0;
+  }
+  // hook: sends never block on the receiver (contract of op 3), so "all sends, then all receives" cannot deadlock
+  BAE_HIP(hipStreamSynchronize(s));
+  for (const DistXfer& t : x)
+    if (t.send && e->coll(e->coll_ctx, 3, t.buf, t.count, t.peer) != 0) return e->fail_msg("send hook failed");
+  for (const DistXfer& t : x)
+    if (!t.send && e->coll(e->coll_ctx, 4, t.buf, t.count, t.peer) != 0) return e->fail_msg("receive hook failed");
+  return 0;
+}
+
+int dist_allreduce_stream(Engine* e, double* buf, size_t count, hipStream_t s) {
+  e->cstats.allreduce_bytes += 8.0 * (double)count;
+  if (e->comm && e->allreduce == native_allreduce) {
+    RcclApi* a = rccl();
+    const ncclResult_t r = a->AllReduce(buf, buf, count, ncclDouble, ncclSum, static_cast<ncclComm_t>(e->comm), s);
+    if (r != ncclSuccess) return rccl_fail(e, "ncclAllReduce", r);
+    return 0;
+  }
+  BAE_HIP(hipStreamSynchronize(s));
+  if (e->allreduce(e->allreduce_ctx, buf, count, 0) != 0) return e->fail_msg("allreduce hook failed");
+  return 0;
+}
+
 void comm_release(Engine* e) {
   if (!e->comm) return;
-  if (RcclApi* a = rccl()) (void)a->CommDestroy(static_cast<ncclComm_t>(e->comm));
+  if (RcclApi* a = rccl()) {
+    if (e->comm2) (void)a->CommDestroy(static_cast<ncclComm_t>(e->comm2));
+    (void)a->CommDestroy(static_cast<ncclComm_t>(e->comm));
+  }
   e->comm = nullptr;
+  e->comm2 = nullptr;
 }
 
 }  // namespace bae
@@ -139,11 +198,22 @@ int ba_hip_comm_init(ba_hip_engine* h, const void* id128, int rank, int nranks) 
   const ncclResult_t r = a->CommInitRank(&comm, nranks, id, rank);
   if (r != ncclSuccess) return rccl_fail(e, "ncclCommInitRank", r);
   e->comm = comm;
+  // side communicator of the distributed solve (the bulk of every panel travels on its own stream, beside
+  // the chain's messages): a duplicate of the first one.  Collective over all ranks, like the init itself.
+  e->comm2 = nullptr;
+  if (a->CommSplit && !getenv("BA_HIP_ONE_COMM")) {
+    ncclComm_t c2 = nullptr;
+    const ncclResult_t r2 = a->CommSplit(comm, 0, rank, &c2, nullptr);
+    if (r2 != ncclSuccess) return rccl_fail(e, "ncclCommSplit", r2);
+    e->comm2 = c2;
+  }
   e->allreduce = native_allreduce; e->allreduce_ctx = e;
   e->coll = native_collective; e->coll_ctx = e;
   e->rank = rank; e->nranks = nranks;
   e->comm_force = nranks == 1;   // one rank: still run the sharded code paths (test of the RCCL calls)
   e->nzL_valid = false;          // the tile pattern of S is the union over the shards
+  e->dist_plan_version = ~0ull;
+  e->dog_jrhs_valid = false;
   return 0;
 }
 
@@ -153,6 +223,8 @@ int ba_hip_comm_destroy(ba_hip_engine* h) {
   e->allreduce = nullptr; e->allreduce_ctx = nullptr; e->coll = nullptr; e->coll_ctx = nullptr;
   e->rank = 0; e->nranks = 1; e->comm_force = false;
   e->nzL_valid = false;
+  e->dist_plan_version = ~0ull;
+  e->dog_jrhs_valid = false;
   return 0;
 }
 

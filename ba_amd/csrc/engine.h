@@ -7,6 +7,7 @@
 
 #include "../../include/ba_hip.h"
 #include "structure.h"
+#include "dist_plan.h"
 
 namespace bae {
 
@@ -131,7 +132,20 @@ struct Engine {
   DBuf<uint32_t> dist_rows;
   std::vector<uint32_t> dist_rows_off;
   uint64_t dist_rows_version = ~0ull;
-  DBuf<double> dist_msg;                 // panel broadcast message (distributed solve)
+  DBuf<double> dist_msg;                 // square broadcast message (distributed solve)
+  // plan of the distributed solve (dist_plan.h): ownership map, per-panel row lists and messages
+  DistPlan dist_plan;
+  uint64_t dist_plan_version = ~0ull;
+  std::string dist_layout_name;
+  DBuf<uint32_t> dist_tiles;             // DistPlan::tiles on the device
+  DBuf<double> dist_usend, dist_urecv;   // urgent point-to-point staging (chain stream)
+  DBuf<double> dist_ssend, dist_srecv;   // side point-to-point staging (side stream)
+  DBuf<double> dist_back;                // backward substitution: partial sums of a panel + their reduction
+  hipStream_t stream3 = nullptr;         // distributed solve: bulk trailing updates
+  hipStream_t stream4 = nullptr;         // distributed solve: side communicator
+  void* comm2 = nullptr;                 // side communicator (ncclCommSplit of comm)
+  std::vector<hipEvent_t> ev_dist;       // 5 events per panel: urgent, packed, side, next, bulk
+  ba_hip_comm_stats cstats = {};
   DBuf<double> packed;                   // packed lower triangle + rhs row (all-reduce staging)
 
   // pose-pose residuals (unary | binary | imu slots)
@@ -215,6 +229,12 @@ struct Engine {
   int fail_msg(const char* what);
 };
 
+// the installed all-reduce (hook or native), with the byte counter of ba_hip_get_comm_stats
+inline int shard_allreduce(Engine* e, void* dev_ptr, size_t count, int dtype) {
+  e->cstats.allreduce_bytes += 8.0 * (double)count;
+  return e->allreduce(e->allreduce_ctx, dev_ptr, count, dtype);
+}
+
 #define BAE_HIP(call)                                                    \
   do {                                                                   \
     hipError_t _e = (call);                                              \
@@ -260,6 +280,13 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
 // broadcast of `count` doubles from `root`, ordered into `s`: native RCCL enqueues without a host
 // round trip; with a caller-supplied hook the stream is drained first (hook contract)
 int dist_broadcast(Engine* e, double* buf, size_t count, int root, hipStream_t s);
+// One group of point-to-point transfers, ordered into `s`: `side` selects the side communicator.  Native
+// RCCL: ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd; hook: the stream is drained, sends first (they
+// do not block), then the receives.
+struct DistXfer { double* buf; size_t count; int peer; bool send; };
+int dist_exchange(Engine* e, const std::vector<DistXfer>& x, bool side, hipStream_t s);
+// in-place SUM over the ranks of `count` doubles, ordered into `s` (chain communicator)
+int dist_allreduce_stream(Engine* e, double* buf, size_t count, hipStream_t s);
 void comm_release(Engine* e);
 int check_solve_residual(Engine* e, const double* dS, const double* dx, const double* db, double* out2);
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz);

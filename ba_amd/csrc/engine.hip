@@ -482,6 +482,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(wave_rng); REL(tile_order); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
   REL(imu_frozen); REL(imu_steps); REL(imu_cov_done); REL(pose_cam);
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
+  REL(dist_tiles); REL(dist_usend); REL(dist_urecv); REL(dist_ssend); REL(dist_srecv); REL(dist_back);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(diag_blocks); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
@@ -500,6 +501,9 @@ void ba_hip_destroy(ba_hip_engine* h) {
   e->timer_events.clear();
   for (hipEvent_t ev : e->ev_panel) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->ev_bulk) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->ev_dist) (void)hipEventDestroy(ev);
+  if (e->stream3) (void)hipStreamDestroy(e->stream3);
+  if (e->stream4) (void)hipStreamDestroy(e->stream4);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
   delete e;
@@ -839,6 +843,7 @@ int ba_hip_set_gravity(ba_hip_engine* h, const double g3[3]) {
 
 int ba_hip_finalize(ba_hip_engine* h) {
   ENG(h);
+  e->dog_jrhs_valid = false;  // the factor rows are rebuilt: no cached sum survives
   BAE_HIP(hipSetDevice(e->device));
   Problem& pb = e->prob;
   if (pb.pose_active.size() != pb.num_poses) pb.pose_active.assign(pb.num_poses, 1);
@@ -914,7 +919,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   if (e->sharded()) {
     double cnt = (double)st.O;
     BAE_HIP(hipMemcpy(e->scalars_out.p, &cnt, sizeof(double), hipMemcpyHostToDevice));
-    if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
+    if (shard_allreduce(e, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpy(&cnt, e->scalars_out.p, sizeof(double), hipMemcpyDeviceToHost));
     n_total = (uint64_t)(cnt + 0.5);
   }
@@ -925,7 +930,14 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
     c_huber = 1.2107 * std::sqrt(med);
   }
   t_r.mark();
-  if ((rc = launch_imu_early(e, c_huber))) return rc;  // overlaps the projection linearisation
+  // The inertial kernels run on the second stream.  Sliding windows (few samples: latency-bound wavefront forms)
+  // start them right away, beside the projection linearisation.  Large problems start them BEHIND k_linearize, under
+  // the tile assembly: the lane-per-sample form keeps 28 KB of private memory per lane, and its scratch traffic beside
+  // the bandwidth-bound k_linearize slowed that kernel 4-5x (configs[4]: 3.8-5.6 ms against 1.05 ms alone) for the
+  // same wall time (profiles/r03_imu_ab.txt); the assembly is latency-bound on its row gathers
+  // and four times as long as both inertial passes.
+  const bool imu_late = e->prob.imu_meas.size() / 7 > 4096;
+  if (!imu_late && (rc = launch_imu_early(e, c_huber))) return rc;
   EventTimer t_l(e);
   // from here on every sum stays on the device until ONE copy at the end of the call (defer_flush): the
   // assembly and the pose-pose kernels are enqueued without waiting for the linearisation to finish
@@ -933,6 +945,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   for (int i = 0; i < 4; ++i) hs[i] = 0.0;
   defer_begin(e);
   if ((rc = launch_landmarks(e, c_huber, e->opt.use_robust_norm_for_proj_residuals))) return rc;
+  if (imu_late && (rc = launch_imu_early(e, c_huber))) { (void)defer_flush(e); return rc; }
   // proj_error_ of BuildProblem (BundleAdjuster.cpp:1386): sum of w |r|^2 with the new weights, one
   // partial per linearisation wave
   if ((rc = sum_partials(e, st.O ? st.n_chunks : 0, 1, hs))) { (void)defer_flush(e); return rc; }
@@ -952,8 +965,8 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
       BAE_HIP(hipStreamSynchronize(e->stream));
       // the union tile pattern decides which tiles of S travel (a collective on first use)
       if (!e->nzL_valid && (rc = factor_tile_pattern(e))) return rc;
-      if (e->allreduce(e->allreduce_ctx, e->rhs_sc.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
-      if (e->allreduce(e->allreduce_ctx, e->rhs_p.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
+      if (shard_allreduce(e, e->rhs_sc.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
+      if (shard_allreduce(e, e->rhs_p.p, st.ld, 0) != 0) return e->fail_msg("allreduce hook failed");
       if ((rc = dist_reduce_scatter_S(e))) return rc;
       BAE_HIP(hipMemcpyAsync(e->A.p + (size_t)st.ld * st.ld, e->rhs_sc.p, (size_t)st.n * sizeof(double),
                              hipMemcpyDeviceToDevice, e->stream));
@@ -963,10 +976,10 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
     BAE_HIP(e->packed.alloc(cnt));
     if ((rc = launch_pack_lower(e, 0))) return rc;
     BAE_HIP(hipStreamSynchronize(e->stream));
-    if (e->allreduce(e->allreduce_ctx, e->packed.p, cnt, 0) != 0)
+    if (shard_allreduce(e, e->packed.p, cnt, 0) != 0)
       return e->fail_msg("allreduce hook failed");
     if ((rc = launch_pack_lower(e, 1))) return rc;
-    if (e->allreduce(e->allreduce_ctx, e->rhs_p.p, st.ld, 0) != 0)
+    if (shard_allreduce(e, e->rhs_p.p, st.ld, 0) != 0)
       return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpyAsync(e->rhs_sc.p, e->A.p + (size_t)st.ld * st.ld, (size_t)st.n * sizeof(double),
                            hipMemcpyDeviceToDevice, e->stream));
@@ -1193,6 +1206,7 @@ uint32_t ba_hip_num_calib_params(const ba_hip_engine* h) {
 }
 int ba_hip_set_calibration(ba_hip_engine* h, int calib_size, int do_tvs) {
   ENG(h);
+  e->dog_jrhs_valid = false;
   if (calib_size != 0 && calib_size != 4 && calib_size != 5)
     return e->fail_msg("CalibSize must be 0, 4 (LinearCamera: fx, fy, u0, v0) or 5 (FovCamera: fx, fy, u0, v0, w)");
   if (calib_size && do_tvs)
@@ -1500,10 +1514,54 @@ int ba_hip_allreduce_host(ba_hip_engine* h, void* host, size_t count, int dtype)
   hipError_t err = hipMemcpy(d.p, host, count * 8, hipMemcpyHostToDevice);
   int rc = 0;
   if (err != hipSuccess) rc = e->fail(err, "hipMemcpy");
-  if (!rc && e->allreduce(e->allreduce_ctx, d.p, count, dtype) != 0) rc = e->fail_msg("allreduce hook failed");
+  if (!rc && shard_allreduce(e, d.p, count, dtype) != 0) rc = e->fail_msg("allreduce hook failed");
   if (!rc && (err = hipMemcpy(host, d.p, count * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = e->fail(err, "hipMemcpy");
   d.release();
   return rc;
+}
+
+int ba_hip_get_comm_stats(ba_hip_engine* h, ba_hip_comm_stats* out) {
+  ENG(h);
+  if (!out) return e->fail_msg("null output");
+  *out = e->cstats;
+  return 0;
+}
+
+int ba_hip_reset_comm_stats(ba_hip_engine* h) {
+  ENG(h);
+  memset(&e->cstats, 0, sizeof(e->cstats));
+  return 0;
+}
+
+int ba_hip_dist_plan_stats(uint32_t nblk, const uint8_t* nz_lower, int nranks, const char* layout, uint32_t kout,
+                           ba_hip_dist_plan_stats_t* out) {
+  if (!out || nranks < 1 || nblk == 0) return -1;
+  const uint32_t G = kout ? kout : choose_kout(nblk);
+  OwnMap map;
+  std::string name;
+  if (!build_own_map((uint32_t)nranks, layout, G, &map, &name)) return -1;
+  const DistPlanStats s = dist_plan_stats(build_dist_plan(nblk, map, nz_lower));
+  out->factor_bytes = s.factor_bytes;
+  out->chain_recv_max = s.chain_recv_max; out->chain_recv_total = s.chain_recv_total;
+  out->side_recv_max = s.side_recv_max; out->side_recv_total = s.side_recv_total;
+  out->chain_sent_total = s.chain_sent_total; out->side_sent_total = s.side_sent_total;
+  out->recv_max = s.recv_max; out->backward_allreduce_bytes = s.backward_allreduce_bytes;
+  out->messages_chain = s.messages_chain; out->messages_side = s.messages_side;
+  out->panels = s.panels; out->ranks = s.ranks; out->classes = s.classes; out->kout = G;
+  return 0;
+}
+
+int ba_hip_get_factor_tile_pattern(ba_hip_engine* h, uint32_t nblk, uint8_t* nz_lower) {
+  ENG(h);
+  NEED_FINAL();
+  if (!e->nzL_valid) {
+    BAE_HIP(hipSetDevice(e->device));
+    const int rc = factor_tile_pattern(e);
+    if (rc) return rc;
+  }
+  if (e->nzL_host.size() != (size_t)nblk * nblk) return e->fail_msg("tile count mismatch");
+  memcpy(nz_lower, e->nzL_host.data(), e->nzL_host.size());
+  return 0;
 }
 
 int ba_hip_solve_is_distributed(ba_hip_engine* h) {
@@ -1514,6 +1572,7 @@ int ba_hip_solve_is_distributed(ba_hip_engine* h) {
 int ba_hip_set_collectives(ba_hip_engine* h, ba_hip_collective_fn fn, void* ctx) {
   ENG(h);
   e->coll = fn; e->coll_ctx = ctx;
+  e->dist_plan_version = ~0ull;
   return 0;
 }
 
@@ -1521,6 +1580,8 @@ int ba_hip_set_allreduce(ba_hip_engine* h, ba_hip_allreduce_fn fn, void* ctx, in
   ENG(h);
   e->allreduce = fn; e->allreduce_ctx = ctx; e->rank = rank; e->nranks = nranks < 1 ? 1 : nranks;
   e->nzL_valid = false;  // the tile pattern of S is the union over the shards
+  e->dist_plan_version = ~0ull;
+  e->dog_jrhs_valid = false;  // a local sum may have become a cross-shard one
   return 0;
 }
 

@@ -337,7 +337,7 @@ template <bool BULK>
 __global__ void __launch_bounds__(256, BULK ? 2 : 4)
 k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
           uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, int swz,
-          const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout) {
+          const uint8_t* __restrict__ nz, const OwnMap own) {
   __shared__ double X[2][NB][LDK2];
   __shared__ double Y[2][NB][LDK2];
   __shared__ uint32_t klist[32];  // the tile columns of [kb0, kb1) with a structurally nonzero product
@@ -367,8 +367,8 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
     i = c + blockIdx.x;
     if (i > nblk) return;
   }
-  // distributed solve: a rank only updates the column panels it owns (panel p -> rank p mod N)
-  if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
+  // distributed solve: a rank only updates the tiles it owns (dist_plan.h)
+  if (!own_tile(own, i, c, nblk)) return;
   update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, X, Y, klist);
 }
 
@@ -395,7 +395,7 @@ template <bool RECT>  // RECT: the rectangle variant (separate kernel name in pr
 __global__ void __launch_bounds__(256, 2)
 k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t m2, uint32_t kb0,
             uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, uint32_t sbl,
-            const uint8_t* __restrict__ nz, uint32_t own_rank, uint32_t own_n, uint32_t own_kout,
+            const uint8_t* __restrict__ nz, const OwnMap own,
             uint32_t nrow64, uint32_t r0, uint32_t rect_cols) {
   __shared__ double X[2][NB2][LDK2];
   __shared__ double Y[2][NB2][LDK2];
@@ -409,7 +409,7 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
     const uint32_t mcols = RECT ? 2 * rect_cols : nblk - c0, y = blockIdx.x / mcols;
     const uint32_t c = c0 + blockIdx.x % mcols, i = nblk - y;
     if (y > ((nblk - r0) & 1u) || c > i || c >= nblk) return;  // (nrow64 is rounded up to a multiple of 8)
-    if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
+    if (!own_tile(own, i, c, nblk)) return;
     update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, reinterpret_cast<double(*)[NB][LDK2]>(&X[0][0][0]),
                 reinterpret_cast<double(*)[NB][LDK2]>(&Y[0][0][0]), klist);
     return;
@@ -435,7 +435,7 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
     if (C > R || R >= m2) return;
   }
   const uint32_t c = c0 + 2 * C, i = r0 + 2 * R;
-  if (own_n > 1 && (c / own_kout) % own_n != own_rank) return;
+  if (!own_tile(own, i, c, nblk)) return;  // (a 128-block never straddles an ownership block: G is even)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // pattern mask of the K range (lane l: tile column kb0 + l) and pivot-sign check
   const uint32_t kl = kb0 + (uint32_t)lane;
@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(256, 2)
 k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
               uint32_t kb1, double* __restrict__ dsgn, double* __restrict__ opbuf,
               int* __restrict__ colneg, int* __restrict__ status, const uint8_t* __restrict__ nz,
-              uint32_t row_end) {
+              uint32_t row_end, const uint32_t* __restrict__ rowlist) {
   struct UpdLds { double X[2][NB][LDK2]; double Y[2][NB][LDK2]; };
   __shared__ uint32_t klist[32];  // active tile columns (tile-sparse factor, see k_update2)
   constexpr size_t kLds = sizeof(TileLds) > sizeof(UpdLds) ? sizeof(TileLds) : sizeof(UpdLds);
@@ -766,9 +766,10 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
   TileLds& sh = *reinterpret_cast<TileLds*>(smem);
   __builtin_amdgcn_s_setprio(2);
   const uint32_t c = c0 + blockIdx.y;
-  const uint32_t i = c + blockIdx.x;
-  if (i > nblk || i >= row_end) return;  // row_end: rows from there on belong to a k_update128 launch
-  const bool special = (blockIdx.x == 0 && blockIdx.y == 0);  // the diagonal tile (c0,c0)
+  // rowlist (distributed solve): the row tiles this rank works on, ascending, instead of all rows from c on
+  const uint32_t i = rowlist ? rowlist[blockIdx.x] : c + blockIdx.x;
+  if (i > nblk || i >= row_end || i < c) return;  // row_end: rows from there on belong to a k_update128 launch
+  const bool special = (i == c0 && c == c0);  // the diagonal tile (c0,c0): first workgroup of the launch
   if (!special) {  // every other tile: the plain trailing update
     update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, u.X, u.Y, klist);
     return;
@@ -877,11 +878,11 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
 // rows below the diagonal tile d (row tiles d+1 .., the last block is the rhs row)
 __global__ void __launch_bounds__(256)
 k_trsm_op(double* __restrict__ A, uint32_t ld, uint32_t d, uint32_t nblk,
-          const double* __restrict__ opbuf, const uint8_t* __restrict__ nz) {
+          const double* __restrict__ opbuf, const uint8_t* __restrict__ nz, const uint32_t* __restrict__ rowlist) {
   __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
-  const uint32_t i = d + 1 + blockIdx.x;
+  const uint32_t i = rowlist ? rowlist[blockIdx.x] : d + 1 + blockIdx.x;
   if (nz && i < nblk && !nz[(size_t)i * nblk + d]) return;  // structurally zero tile: stays zero
   const int rows = (i == nblk) ? 1 : NB;
   const int myrow = 16 * wave + li;
@@ -948,7 +949,7 @@ k_linvT(const double* __restrict__ opbuf, const double* __restrict__ dsgn, doubl
 // Workgroup 0 also stores x_i.
 __global__ void __launch_bounds__(256)
 k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
-           const double* __restrict__ linvT, double* __restrict__ x, const uint8_t* __restrict__ nz) {
+           const double* __restrict__ linvT, double* __restrict__ x, const uint8_t* __restrict__ nz, uint32_t col0) {
   __shared__ double xi[NB];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x;
@@ -968,7 +969,7 @@ k_backward(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
     if (blockIdx.x == 0) x[(size_t)i * NB + tid] = v;
   }
   __syncthreads();
-  const uint32_t col = blockIdx.x * 256 + tid;
+  const uint32_t col = col0 + blockIdx.x * 256 + tid;  // col0: first column updated (distributed solve: the panel's)
   if (col < i * NB && (!nz || nz[(size_t)i * nblk + (col >> 6)])) {  // structurally zero tiles of L: nothing to subtract
     const double* Li = A + ((size_t)i * NB) * ld + col;
     double s = 0.0;
@@ -993,7 +994,7 @@ __device__ __forceinline__ void matvec64(const double* __restrict__ M, size_t st
 }
 __global__ void __launch_bounds__(256)
 k_backward2(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
-            const double* __restrict__ linvT, double* __restrict__ x, const uint8_t* __restrict__ nz) {
+            const double* __restrict__ linvT, double* __restrict__ x, const uint8_t* __restrict__ nz, uint32_t col0) {
   __shared__ double x1[NB], x0[NB], y0[NB];
   __shared__ double part[4][NB];
   const int tid = threadIdx.x;
@@ -1021,7 +1022,7 @@ k_backward2(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
     if (blockIdx.x == 0) x[(size_t)i * NB + tid] = v;
   }
   __syncthreads();
-  const uint32_t col = blockIdx.x * 256 + tid;
+  const uint32_t col = col0 + blockIdx.x * 256 + tid;
   if (col < i * NB) {
     const double* L1 = A + ((size_t)(i + 1) * NB) * ld + col;
     const double* L0 = A + ((size_t)i * NB) * ld + col;
@@ -1039,19 +1040,21 @@ k_backward2(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
   }
 }
 
-// the whole backward substitution: pairs of block rows, a single one first if the count is odd
+// the backward substitution over the block rows [lo, hi), last first, updating the columns from tile lo on:
+// pairs of block rows, a single one first if the count is odd.  (0, nblk) is the whole substitution.
 static void launch_backward(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, const double* linvT, double* dx,
-                            const uint8_t* nz) {
-  uint32_t ii = nblk;
-  if (ii & 1u) {
+                            const uint8_t* nz, uint32_t lo = 0, uint32_t hi = 0xffffffffu) {
+  uint32_t ii = std::min(hi, nblk);
+  const uint32_t col0 = lo * NB;
+  if ((ii - lo) & 1u) {
     --ii;
-    const uint32_t cols = ii * NB, grid = cols == 0 ? 1 : (cols + 255) / 256;
-    hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx, nz);
+    const uint32_t cols = (ii - lo) * NB, grid = cols == 0 ? 1 : (cols + 255) / 256;
+    hipLaunchKernelGGL(k_backward, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx, nz, col0);
   }
-  while (ii >= 2) {
+  while (ii >= lo + 2) {
     ii -= 2;
-    const uint32_t cols = ii * NB, grid = cols == 0 ? 1 : (cols + 255) / 256;
-    hipLaunchKernelGGL(k_backward2, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx, nz);
+    const uint32_t cols = (ii - lo) * NB, grid = cols == 0 ? 1 : (cols + 255) / 256;
+    hipLaunchKernelGGL(k_backward2, dim3(grid), dim3(256), 0, s, dA, ld, ii, nblk, linvT, dx, nz, col0);
   }
 }
 
@@ -1073,7 +1076,7 @@ int factor_tile_pattern(Engine* e) {
     DBuf<double> d;
     BAE_HIP(d.alloc(cnt.size()));
     BAE_HIP(hipMemcpy(d.p, cnt.data(), cnt.size() * sizeof(double), hipMemcpyHostToDevice));
-    if (e->allreduce(e->allreduce_ctx, d.p, cnt.size(), 0) != 0) { d.release(); return e->fail_msg("allreduce hook failed"); }
+    if (shard_allreduce(e, d.p, cnt.size(), 0) != 0) { d.release(); return e->fail_msg("allreduce hook failed"); }
     BAE_HIP(hipMemcpy(cnt.data(), d.p, cnt.size() * sizeof(double), hipMemcpyDeviceToHost));
     d.release();
     for (size_t i = 0; i < nz.size(); ++i) nz[i] = cnt[i] > 0.5 ? 1 : 0;
@@ -1110,40 +1113,35 @@ uint32_t choose_kout(uint32_t nblk) {
 }
 
 // ---------------------------------------------------------------------------------
-// Distributed reduced solve.  Column panels of KOUT tiles
-// are dealt to the ranks round-robin (panel p -> rank p mod N).  Per iteration:
-//   * reduce-scatter: the partial S of every landmark shard is summed onto the owners of its
-//     panels (dist_reduce_scatter_S), instead of an all-reduce of the whole matrix;
-//   * panel J: its owner runs the serial chain (k_trsm_op / k_step_update) on its columns,
-//     packs the factor columns (rows from the panel's first row down to the rhs row), the pivot
-//     signs and the factor packets into one message and BROADCASTS it; everybody else unpacks;
-//   * trailing update with panel J: the owner of panel J+1 applies it to that panel (and
-//     factorises its first diagonal tile in the same launch), every rank applies it to the
-//     panels it owns further right (ownership filter of k_update128 / k_update2) on its second stream,
-//     overlapping the next panel's chain and broadcast;
-//   * the backward substitution is replicated (every rank holds all of L after the broadcasts).
-// Enabled when the caller installed the collectives hook (ba_hip_set_collectives), more than
-// one rank takes part, and the reduced system need not stay readable (keep_reduced_system).
+// Distributed reduced solve (replaces CalculateGn,
+// /root/reference/src/BundleAdjuster.cpp:748-833, across the GPUs of a node).  Ownership of the tile blocks
+// and the message plan: dist_plan.h.  Per iteration:
+//   * reduce-scatter: the partial S of every landmark shard is summed onto the owners of its tile blocks
+//     (dist_reduce_scatter_S), instead of an all-reduce of the whole matrix;
+//   * panel J, four streams per rank:
+//       chain  (e->stream,  chain communicator)  the owner of block (J, J) factorises the SQUARE and broadcasts it
+//              with its factor packets; the owner of block (J+1, J) substitutes those rows and sends them to the
+//              ranks that multiply their class (URGENT: the next square needs them); the owner of block
+//              (J+1, J+1) applies panel J to it and factorises its first diagonal tile in the same launch;
+//       panel  (e->stream2) substitution + in-panel updates of the other row tiles this rank owns in panel J,
+//              packing of their messages, then panel J applied to the tiles it owns in column block J+1;
+//       side   (e->stream4, side communicator)   those messages, point to point, and their unpacking;
+//       bulk   (e->stream3) panel J applied to the tiles it owns right of column block J+1 (k_update128).
+//     Only the square and one block row per panel travel on the chain stream; everything else has until the
+//     step its block row reaches the diagonal.
+//   * forward substitution rides along (the rhs row is a row of every square); the backward substitution
+//     walks the panels from the last: partial sums over the own tiles of the panel, one small all-reduce,
+//     then the square's own rows (every rank holds every square) — the step is bitwise equal on all ranks.
+// Enabled when the caller installed the collectives hook (ba_hip_set_collectives) or the native
+// communicator, more than one rank takes part, and the reduced system need not stay readable
+// (keep_reduced_system).  BA_HIP_DIST_LAYOUT = tri | grid | col | row overrides the layout.
 bool dist_solve_enabled(const Engine* e) {
   static const bool off = getenv("BA_HIP_NO_DIST_SOLVE") != nullptr;
   return e->coll && e->sharded() && !e->opt.keep_reduced_system && !off;
 }
 
-// rows [r0, r0 + nrows) x columns [c0, c0 + w) of A  <->  dense row-major block in buf
-__global__ void __launch_bounds__(256)
-k_copy_panel(double* __restrict__ A, uint32_t ld, uint32_t r0, uint32_t c0, uint32_t w,
-             double* __restrict__ buf, int unpack) {
-  const uint32_t r = blockIdx.x;
-  double* row = A + (size_t)(r0 + r) * ld + c0;
-  double* brow = buf + (size_t)r * w;
-  for (uint32_t cc = threadIdx.x; cc < w; cc += 256) {
-    if (unpack) row[cc] = brow[cc];
-    else brow[cc] = row[cc];
-  }
-}
-
-// the same for a list of 64-row tiles followed by the rhs row (row n_pad): message of a panel
-// without the structurally zero tiles
+// a list of 64-row tiles (then, if the grid says so, the rhs row = row n_pad) x columns [c0, c0 + w) of A
+// <->  dense row-major block in buf: messages carry no structurally zero tiles
 __global__ void __launch_bounds__(256)
 k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restrict__ tiles, uint32_t ntiles,
                   uint32_t n_pad, uint32_t c0, uint32_t w, double* __restrict__ buf, int unpack) {
@@ -1157,37 +1155,54 @@ k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restric
   }
 }
 
-// The serial chain of one outer panel [J, Jend) on stream s (its owner in the distributed solve).
+// The serial chain of one outer panel [J, Jend) on stream s.
 // Two-level inside the panel: sub-panels of KIN tile columns are factorised right-looking, one
 // K = 64 update of the rest of the sub-panel per tile column; at the end of a sub-panel the
 // remaining columns of the outer panel get ONE update with all KIN columns (K = 256) — a third of
 // the tile updates of a flat right-looking panel at KOUT = 16, and mostly four times as deep.
 // Every update launch also factorises the next diagonal tile (k_step_update).
+// Distributed solve: `rl` lists the row tiles to work on (ascending, rl_n of them) instead of every row
+// from the panel down; rl_square: the list starts with the panel's own tiles J .. Jend-1 (the square — its
+// diagonal tiles are factorised here); otherwise all its rows lie below the panel and the factor packets
+// of the diagonal tiles are already there (received with the square).
 static const uint32_t KIN = 4;
 static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t Jend,
-                               double* dsgn, double* opbuf, int* colneg, int* flags, const uint8_t* nz) {
+                               double* dsgn, double* opbuf, int* colneg, int* flags, const uint8_t* nz,
+                               const uint32_t* rl = nullptr, uint32_t rl_n = 0, bool rl_square = false) {
   // Large systems (the chain's tile updates are bandwidth-bound there and cost the bulk update their
   // full duration): sub-panels of 8, left-looking inside — every column is read and written once
   // per sub-panel instead of once per earlier column.  Small systems are latency-bound on the
   // diagonal tile: right-looking keeps its update shallow (K = 64).
   const bool left = nblk >= 512;
   const uint32_t KINv = left ? 2 * KIN : KIN;
+  // rows from tile `from` on: the whole range, or the tail of the list
+  auto rows_from = [&](uint32_t from, const uint32_t** lp, uint32_t* cnt) {
+    if (!rl) { *lp = nullptr; *cnt = nblk - from + 1; return; }
+    const uint32_t skip = rl_square ? std::min(from - J, rl_n) : 0u;
+    *lp = rl + skip; *cnt = rl_n - skip;
+  };
+  if (rl && rl_n == 0) return;
   for (uint32_t sub = J; sub < Jend; sub += KINv) {
     const uint32_t sub_end = std::min(sub + KINv, Jend);
     for (uint32_t jj = sub; jj < sub_end; ++jj) {
-      hipLaunchKernelGGL(k_trsm_op, dim3(nblk - jj), dim3(256), 0, s, dA, ld, jj, nblk, (const double*)opbuf, nz);
-      if (jj + 1 < sub_end) {
+      const uint32_t* lp; uint32_t cnt;
+      rows_from(jj + 1, &lp, &cnt);
+      if (cnt) hipLaunchKernelGGL(k_trsm_op, dim3(cnt), dim3(256), 0, s, dA, ld, jj, nblk, (const double*)opbuf, nz, lp);
+      if (jj + 1 < sub_end && cnt) {
         if (left)  // column jj + 1 alone, with every earlier column of the sub-panel at once
-          hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, 1), dim3(256), 0, s, dA, ld, nblk, jj + 1, sub,
-                             jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
+          hipLaunchKernelGGL(k_step_update, dim3(cnt, 1), dim3(256), 0, s, dA, ld, nblk, jj + 1, sub,
+                             jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u, lp);
         else       // the rest of the sub-panel with column jj
-          hipLaunchKernelGGL(k_step_update, dim3(nblk - (jj + 1) + 1, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
-                             nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
+          hipLaunchKernelGGL(k_step_update, dim3(cnt, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
+                             nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u, lp);
       }
     }
-    if (sub_end < Jend)
-      hipLaunchKernelGGL(k_step_update, dim3(nblk - sub_end + 1, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk,
-                         sub_end, sub, sub_end, dsgn, opbuf, colneg, flags, nz, nblk + 1u);
+    if (sub_end < Jend) {
+      const uint32_t* lp; uint32_t cnt;
+      rows_from(sub_end, &lp, &cnt);
+      if (cnt) hipLaunchKernelGGL(k_step_update, dim3(cnt, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk,
+                                  sub_end, sub, sub_end, dsgn, opbuf, colneg, flags, nz, nblk + 1u, lp);
+    }
   }
 }
 
@@ -1206,37 +1221,36 @@ static void launch_next_panel_update(hipStream_t s, double* dA, uint32_t ld, uin
   if (!no128 && r0 + min_rows <= nblk && ncols % 2u == 0 && c0 % 2u == 0) {
     const uint32_t m = nblk - r0, m2 = m / 2, rect_cols = ncols / 2;
     hipLaunchKernelGGL(k_step_update, dim3(ncols, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn, opbuf,
-                       colneg, flags, nz, r0);
+                       colneg, flags, nz, r0, (const uint32_t*)nullptr);
     const uint32_t nrow64 = (ncols * (1 + (m & 1u)) + 7) / 8 * 8;
     hipLaunchKernelGGL(k_update128<true>, dim3(nrow64 + m2 * rect_cols), dim3(256), 0, s, dA, ld, nblk, c0, m2, kb0, kb1,
-                       (const double*)dsgn, (const int*)colneg, 0u, nz, 0u, 1u, 1u, nrow64, r0, rect_cols);
+                       (const double*)dsgn, (const int*)colneg, 0u, nz, own_map_single(), nrow64, r0, rect_cols);
     return;
   }
   hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn,
-                     opbuf, colneg, flags, nz, nblk + 1u);
+                     opbuf, colneg, flags, nz, nblk + 1u, (const uint32_t*)nullptr);
 }
 
 // Bulk trailing update of the tile rows / columns >= a_end (and the rhs row) with the tile columns
 // [J, Jend).  Big trailing matrices: 128x128 blocks over the even part (k_update128, XCD-aware 4x4
 // super-blocks = the footprint of the 64-tile kernel's 8x8; the rhs row and an odd last tile row
 // ride along as 64-tiles); otherwise the 64-tile kernel, capped (`full` = false) to leave the
-// serial chain room.
+// serial chain room.  `own`: the tiles this rank updates (distributed solve).
 // One launch, bracketed by the profiling events.
 static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t a_end,
                                    uint32_t J, uint32_t Jend, const double* dsgn, const int* colneg,
-                                   const uint8_t* nz, bool full, uint32_t own_rank, uint32_t own_n,
-                                   uint32_t own_kout) {
+                                   const uint8_t* nz, bool full, const OwnMap& own) {
   static const bool no128 = getenv("BA_HIP_NO128") != nullptr;  // A/B switch
   static const uint32_t sbl = getenv("BA_HIP_SBL") ? (uint32_t)atoi(getenv("BA_HIP_SBL")) : 3u;
   const uint32_t m = nblk - a_end;
-  if (full && !no128 && m >= 16 && (a_end % 2u) == 0 && (own_n <= 1 || own_kout % 2u == 0)) {
+  if (full && !no128 && m >= 16 && (a_end % 2u) == 0 && (own.n <= 1 || own.G % 2u == 0)) {
     const uint32_t m2 = m / 2, sbl2 = 2, sbe2 = 1u << sbl2;
     const uint32_t nsr = (m2 + sbe2 - 1) / sbe2, nsb = nsr * (nsr + 1) / 2;
     // leftover 64-tiles first (a multiple of 8 workgroups keeps the XCD phase of the blocks)
     const uint32_t nrow64 = (m * (1 + (m & 1u)) + 7) / 8 * 8;
     if (e) e->prof_begin(e->ev_syrk, s);
     hipLaunchKernelGGL(k_update128<false>, dim3(nrow64 + ((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk,
-                       a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own_rank, own_n, own_kout, nrow64, a_end, 0u);
+                       a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own, nrow64, a_end, 0u);
     if (e) e->prof_end(e->ev_syrk, s);
     return;
   }
@@ -1248,86 +1262,108 @@ static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld
   if (e) e->prof_begin(e->ev_syrk, s);
   if (full)
     hipLaunchKernelGGL(k_update2<false>, dim3(grid1), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn, colneg,
-                       swzf, nz, own_rank, own_n, own_kout);
+                       swzf, nz, own);
   else
     hipLaunchKernelGGL(k_update2<true>, dim3(grid1), dim3(256), 0, s, dA, ld, nblk, a_end, J, Jend, dsgn, colneg,
-                       swzf, nz, own_rank, own_n, own_kout);
+                       swzf, nz, own);
   if (e) e->prof_end(e->ev_syrk, s);
 }
 
-struct DistLayout {
-  uint32_t kout, npanels;
-  std::vector<size_t> off;  // offset of panel p inside its owner's chunk
-  size_t chunk;             // padded chunk size (doubles)
-};
-
-// rows_off[p + 1] - rows_off[p] = row tiles of panel p that travel
-static DistLayout dist_layout(uint32_t nblk, uint32_t nranks, const std::vector<uint32_t>& rows_off) {
-  DistLayout d;
-  d.kout = choose_kout(nblk);
-  d.npanels = (nblk + d.kout - 1) / d.kout;
-  d.off.assign(d.npanels, 0);
-  std::vector<size_t> used(nranks, 0);
-  for (uint32_t p = 0; p < d.npanels; ++p) {
-    const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
-    const size_t rows = (size_t)(rows_off[p + 1] - rows_off[p]) * NB, w = (size_t)(Jend - J) * NB;
-    d.off[p] = used[p % nranks];
-    used[p % nranks] += rows * w;
+// ---- the plan of the distributed solve for the current pattern / communicator ------------------------
+static int ensure_dist_plan(Engine* e, uint32_t nblk, bool pat) {
+  const uint32_t KOUT = choose_kout(nblk);
+  const char* lay_env = getenv("BA_HIP_DIST_LAYOUT");
+  const uint64_t want = (pat ? e->nzL_version : 0) * 1024 + KOUT * 4 + (pat ? 1 : 0);
+  if (e->dist_plan_version == want && e->dist_plan.nblk == nblk && e->dist_plan.map.n == (uint32_t)e->nranks &&
+      e->dist_plan.map.rank == (uint32_t)e->rank)
+    return 0;
+  OwnMap map;
+  std::string why;
+  if (!build_own_map((uint32_t)e->nranks, lay_env, KOUT, &map, &e->dist_layout_name, &why)) {
+    e->err = "distributed solve: " + why;
+    return -1;
   }
-  d.chunk = 0;
-  for (size_t u : used) d.chunk = std::max(d.chunk, u);
-  d.chunk = (d.chunk + 63) / 64 * 64;
-  return d;
+  map.rank = (uint32_t)e->rank;
+  // one rank with the native communicator (comm_force): the rank sends its rows to itself — every pack /
+  // transfer / unpack path runs on a one-GPU box
+  e->dist_plan = build_dist_plan(nblk, map, pat ? e->nzL_host.data() : nullptr, e->nranks == 1);
+  BAE_HIP(e->dist_tiles.alloc(std::max<size_t>(e->dist_plan.tiles.size(), 1)));
+  if (!e->dist_plan.tiles.empty())
+    BAE_HIP(hipMemcpy(e->dist_tiles.p, e->dist_plan.tiles.data(), e->dist_plan.tiles.size() * sizeof(uint32_t),
+                      hipMemcpyHostToDevice));
+  e->dist_plan_version = want;
+  e->dist_srows_version = ~0ull;
+  return 0;
 }
 
-// Reduce-scatter of S onto the panel owners.  Only the row tiles of a panel that hold a
-// structurally nonzero tile of S on SOME shard travel (the union pattern of
-// factor_tile_pattern, identical on every rank; S itself is half as dense as its factor): the
-// other tiles are zero on every rank already.
+// Reduce-scatter of S onto the owners of its tile blocks.  Only the row tiles of a panel that hold a
+// structurally nonzero tile of S on SOME shard travel (the union pattern of factor_tile_pattern, identical
+// on every rank; S itself is half as dense as its factor): the other tiles are zero on every rank already.
+// Chunk of destination rank r: for every panel, the row tiles of that panel whose block r owns.
 int dist_reduce_scatter_S(Engine* e) {
   const uint32_t ld = e->st.ld, nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
-  const uint32_t KOUT = choose_kout(nblk), npanels = (nblk + KOUT - 1) / KOUT;
   const bool pat = e->nzS_host.size() == (size_t)nblk * nblk;
-  const uint64_t want = pat ? e->nzL_version * 64 + KOUT : ~1ull;
-  if (e->dist_srows_version != want || e->dist_srows_off.size() != npanels + 1) {
+  { const int prc = ensure_dist_plan(e, nblk, pat && e->nzL_host.size() == (size_t)nblk * nblk); if (prc) return prc; }
+  const DistPlan& pl = e->dist_plan;
+  const uint32_t npanels = pl.nb;
+  const uint64_t want = e->dist_plan_version;
+  if (e->dist_srows_version != want || e->dist_srows_off.size() != (size_t)npanels * N + 1) {
     std::vector<uint32_t> list;
-    e->dist_srows_off.assign(npanels + 1, 0);
+    e->dist_srows_off.assign((size_t)npanels * N + 1, 0);
     for (uint32_t p = 0; p < npanels; ++p) {
-      const uint32_t J = p * KOUT, Jend = std::min(J + KOUT, nblk);
-      for (uint32_t i = J; i < nblk; ++i) {
-        bool on = !pat || i < Jend;
-        for (uint32_t kb = J; kb < Jend && !on; ++kb) on = e->nzS_host[(size_t)i * nblk + kb] != 0;
-        if (on) list.push_back(i);
+      const uint32_t J = pl.panels[p].c0, Jend = pl.panels[p].c1;
+      for (uint32_t r = 0; r < N; ++r) {
+        OwnMap m = pl.map;
+        m.rank = r;
+        for (uint32_t i = J; i < nblk; ++i) {
+          if (!own_tile(m, i, J, nblk)) continue;
+          bool on = !pat || i < Jend;
+          for (uint32_t kb = J; kb < Jend && !on; ++kb) on = e->nzS_host[(size_t)i * nblk + kb] != 0;
+          if (on) list.push_back(i);
+        }
+        e->dist_srows_off[(size_t)p * N + r + 1] = (uint32_t)list.size();
       }
-      e->dist_srows_off[p + 1] = (uint32_t)list.size();
     }
     BAE_HIP(e->dist_srows.alloc(std::max<size_t>(list.size(), 1)));
     if (!list.empty())
       BAE_HIP(hipMemcpy(e->dist_srows.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     e->dist_srows_version = want;
   }
-  const DistLayout d = dist_layout(nblk, N, e->dist_srows_off);
-  BAE_HIP(e->packed.alloc(d.chunk * N));
-  // the padding between the panels of a chunk is summed too: keep it finite
-  BAE_HIP(hipMemsetAsync(e->packed.p, 0, d.chunk * N * sizeof(double), e->stream));
-  for (uint32_t p = 0; p < d.npanels; ++p) {
-    const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
-    const uint32_t ntl = e->dist_srows_off[p + 1] - e->dist_srows_off[p];
-    if (ntl == 0) continue;
-    hipLaunchKernelGGL(k_copy_panel_rows, dim3(ntl * NB), dim3(256), 0, e->stream, e->A.p, ld,
-                       (const uint32_t*)(e->dist_srows.p + e->dist_srows_off[p]), ntl, nblk * NB, J * NB,
-                       (Jend - J) * NB, e->packed.p + (size_t)(p % N) * d.chunk + d.off[p], 0);
-  }
+  // offsets inside the chunks: panels in order
+  std::vector<size_t> off((size_t)npanels * N, 0), used(N, 0);
+  for (uint32_t p = 0; p < npanels; ++p)
+    for (uint32_t r = 0; r < N; ++r) {
+      const size_t k = (size_t)p * N + r;
+      const size_t rows = (size_t)(e->dist_srows_off[k + 1] - e->dist_srows_off[k]) * NB;
+      off[k] = used[r];
+      used[r] += rows * (size_t)(pl.panels[p].c1 - pl.panels[p].c0) * NB;
+    }
+  size_t chunk = 0;
+  for (size_t u : used) chunk = std::max(chunk, u);
+  chunk = (chunk + 63) / 64 * 64;
+  BAE_HIP(e->packed.alloc(chunk * N));
+  // the padding behind the shorter chunks is summed too: keep it finite
+  BAE_HIP(hipMemsetAsync(e->packed.p, 0, chunk * N * sizeof(double), e->stream));
+  for (uint32_t p = 0; p < npanels; ++p)
+    for (uint32_t r = 0; r < N; ++r) {
+      const size_t k = (size_t)p * N + r;
+      const uint32_t ntl = e->dist_srows_off[k + 1] - e->dist_srows_off[k];
+      if (ntl == 0) continue;
+      hipLaunchKernelGGL(k_copy_panel_rows, dim3(ntl * NB), dim3(256), 0, e->stream, e->A.p, ld,
+                         (const uint32_t*)(e->dist_srows.p + e->dist_srows_off[k]), ntl, nblk * NB, pl.panels[p].c0 * NB,
+                         (pl.panels[p].c1 - pl.panels[p].c0) * NB, e->packed.p + (size_t)r * chunk + off[k], 0);
+    }
   BAE_HIP(hipGetLastError());
   BAE_HIP(hipStreamSynchronize(e->stream));
-  if (e->coll(e->coll_ctx, 2, e->packed.p, d.chunk, 0) != 0) return e->fail_msg("reduce-scatter hook failed");
-  for (uint32_t p = rank; p < d.npanels; p += N) {
-    const uint32_t J = p * d.kout, Jend = std::min(J + d.kout, nblk);
-    const uint32_t ntl = e->dist_srows_off[p + 1] - e->dist_srows_off[p];
+  e->cstats.reduce_scatter_bytes += 8.0 * (double)chunk * N;
+  if (e->coll(e->coll_ctx, 2, e->packed.p, chunk, 0) != 0) return e->fail_msg("reduce-scatter hook failed");
+  for (uint32_t p = 0; p < npanels; ++p) {
+    const size_t k = (size_t)p * N + rank;
+    const uint32_t ntl = e->dist_srows_off[k + 1] - e->dist_srows_off[k];
     if (ntl == 0) continue;
     hipLaunchKernelGGL(k_copy_panel_rows, dim3(ntl * NB), dim3(256), 0, e->stream, e->A.p, ld,
-                       (const uint32_t*)(e->dist_srows.p + e->dist_srows_off[p]), ntl, nblk * NB, J * NB,
-                       (Jend - J) * NB, e->packed.p + (size_t)rank * d.chunk + d.off[p], 1);
+                       (const uint32_t*)(e->dist_srows.p + e->dist_srows_off[k]), ntl, nblk * NB, pl.panels[p].c0 * NB,
+                       (pl.panels[p].c1 - pl.panels[p].c0) * NB, e->packed.p + (size_t)rank * chunk + off[k], 1);
   }
   BAE_HIP(hipGetLastError());
   return 0;
@@ -1355,132 +1391,303 @@ static int setup_status_block(Engine* e, const double* dA, uint32_t ld, hipStrea
   return 0;
 }
 
+// Backward substitution of the distributed solve, panel [c0, c1): partial sums over the row tiles this rank
+// owns below the square,  part[g][col] = sum over its tiles t = g, g + NG, ... of  L[t-rows, col]^T x[t-rows].
+__global__ void __launch_bounds__(256)
+k_back_partial(const double* __restrict__ A, uint32_t ld, uint32_t nblk, const uint32_t* __restrict__ tiles,
+               uint32_t ntiles, uint32_t c0, uint32_t w, const double* __restrict__ x,
+               const uint8_t* __restrict__ nz, double* __restrict__ part) {
+  __shared__ double xs[NB];
+  const uint32_t col = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, ng = gridDim.y;
+  double s = 0.0;
+  for (uint32_t t = g; t < ntiles; t += ng) {
+    const uint32_t i = tiles[t];
+    __syncthreads();
+    if (threadIdx.x < NB) xs[threadIdx.x] = x[(size_t)i * NB + threadIdx.x];
+    __syncthreads();
+    if (col < w && (!nz || nz[(size_t)i * nblk + c0 + (col >> 6)])) {
+      const double* L = A + ((size_t)i * NB) * ld + (size_t)c0 * NB + col;
+#pragma unroll 16
+      for (int r = 0; r < NB; ++r) s += L[(size_t)r * ld] * xs[r];
+    }
+  }
+  if (col < w) part[(size_t)g * w + col] = s;
+}
+
+// out[col] = sum over g (fixed order) of part[g][col]
+__global__ void k_back_sum(const double* __restrict__ part, uint32_t ng, uint32_t w, double* __restrict__ out) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= w) return;
+  double s = 0.0;
+  for (uint32_t g = 0; g < ng; ++g) s += part[(size_t)g * w + col];
+  out[col] = s;
+}
+
+// y[c0*64 + col] -= p[col]   (y = the rhs row of A)
+__global__ void k_back_apply(double* __restrict__ yrow, const double* __restrict__ p, uint32_t w) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col < w) yrow[col] -= p[col];
+}
+
 int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* status, const uint8_t* nz) {
-  const uint32_t nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
-  const uint32_t KOUT = choose_kout(nblk);
+  const uint32_t nblk = ld / NB, rank = (uint32_t)e->rank;
   BAE_HIP(e->invdiag.alloc((size_t)nblk * NB + (size_t)nblk * NB * NB + (size_t)nblk * NOPV * 64 +
                            (nblk + 1) / 2));
   double* dsgn = e->invdiag.p;
   double* linvT = dsgn + (size_t)nblk * NB;
   double* opbuf = linvT + (size_t)nblk * NB * NB;
   int* colneg = reinterpret_cast<int*>(opbuf + (size_t)nblk * NOPV * 64);
-  // broadcast message of a panel: factor columns | pivot signs | colneg (ints) | factor packets
-  const size_t wmax = (size_t)KOUT * NB;
-  const size_t msg_cap = (size_t)(ld + 1) * wmax + wmax + KOUT + (size_t)KOUT * NOPV * 64;
-  BAE_HIP(e->dist_msg.alloc(msg_cap));
-  double* msg = e->dist_msg.p;
-  hipStream_t s0 = e->stream, s1 = e->stream2;
-  const uint32_t npanels = (nblk + KOUT - 1) / KOUT;
-  // message rows of every panel: the row tiles at or below the panel with a structurally
-  // nonzero tile in one of its columns (all of them when there is no pattern)
   const bool pat = nz && e->nzL_host.size() == (size_t)nblk * nblk;
-  const uint64_t want = pat ? e->nzL_version * 64 + KOUT : ~1ull;
-  if (e->dist_rows_version != want || e->dist_rows_off.size() != npanels + 1) {
-    std::vector<uint32_t> list;
-    e->dist_rows_off.assign(npanels + 1, 0);
-    for (uint32_t p = 0; p < npanels; ++p) {
-      const uint32_t J = p * KOUT, Jend = std::min(J + KOUT, nblk);
-      for (uint32_t i = J; i < nblk; ++i) {
-        bool on = !pat || i < Jend;
-        for (uint32_t kb = J; kb < Jend && !on; ++kb) on = e->nzL_host[(size_t)i * nblk + kb] != 0;
-        if (on) list.push_back(i);
-      }
-      e->dist_rows_off[p + 1] = (uint32_t)list.size();
+  { const int prc = ensure_dist_plan(e, nblk, pat); if (prc) return prc; }
+  const DistPlan& pl = e->dist_plan;
+  const OwnMap& own = pl.map;
+  const uint32_t KOUT = own.G, npanels = pl.nb, n_pad = nblk * NB;
+  const uint32_t* dtiles = e->dist_tiles.p;
+  // streams: chain, panel, bulk, side
+  if (!e->stream3) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    BAE_HIP(hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, lo));
+    BAE_HIP(hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, hi));
+  }
+  hipStream_t s0 = e->stream, s1 = e->stream2, s2 = e->stream3, s3 = e->stream4;
+  // staging buffers: the square message; urgent / side messages of the busiest panel
+  const size_t wmax = (size_t)KOUT * NB;
+  BAE_HIP(e->dist_msg.alloc(dist_square_doubles(KOUT)));
+  size_t cap_us = 1, cap_ur = 1, cap_ss = 1, cap_sr = 1;
+  for (const DistPanel& pn : pl.panels) {
+    size_t us = 0, ur = 0, ss = 0, sr = 0;
+    const size_t w = (size_t)(pn.c1 - pn.c0) * NB;
+    for (uint32_t mi : pn.msgs) {
+      const DistMsg& m = pl.msgs[mi];
+      const size_t cnt = (size_t)m.count * NB * w;
+      const bool recv = std::find(m.dst.begin(), m.dst.end(), rank) != m.dst.end();
+      if (m.src == rank) (m.urgent ? us : ss) += cnt;
+      if (recv) (m.urgent ? ur : sr) += cnt;
     }
-    BAE_HIP(e->dist_rows.alloc(std::max<size_t>(list.size(), 1)));
-    if (!list.empty())
-      BAE_HIP(hipMemcpy(e->dist_rows.p, list.data(), list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    e->dist_rows_version = want;
+    cap_us = std::max(cap_us, us); cap_ur = std::max(cap_ur, ur);
+    cap_ss = std::max(cap_ss, ss); cap_sr = std::max(cap_sr, sr);
   }
-  while (e->ev_panel.size() < npanels) {
-    hipEvent_t a, b;
+  BAE_HIP(e->dist_usend.alloc(cap_us)); BAE_HIP(e->dist_urecv.alloc(cap_ur));
+  BAE_HIP(e->dist_ssend.alloc(cap_ss)); BAE_HIP(e->dist_srecv.alloc(cap_sr));
+  const uint32_t NG = 32;
+  BAE_HIP(e->dist_back.alloc((size_t)(NG + 1) * wmax));
+  while (e->ev_dist.size() < (size_t)npanels * 5) {
+    hipEvent_t a;
     BAE_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-    BAE_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-    e->ev_panel.push_back(a);
-    e->ev_bulk.push_back(b);
+    e->ev_dist.push_back(a);
   }
+  auto EV = [&](uint32_t J, int k) { return e->ev_dist[(size_t)J * 5 + k]; };  // 0 urgent 1 packed 2 side 3 next 4 bulk
+  e->cstats.factorisations++;
   { const int src = setup_status_block(e, dA, ld, s0); if (src) return src; }
-  if (rank == 0)  // factor packet of tile 0
+  // everything queued on the chain stream so far (assembly, reduce-scatter unpack) precedes the other streams' work
+  BAE_HIP(hipEventRecord(e->ev_dist[1], s0));
+  BAE_HIP(hipStreamWaitEvent(s1, e->ev_dist[1], 0));
+  BAE_HIP(hipStreamWaitEvent(s2, e->ev_dist[1], 0));
+  BAE_HIP(hipStreamWaitEvent(s3, e->ev_dist[1], 0));
+  if (rank == pl.panels[0].diag_owner)  // factor packet of tile 0
     hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
-                       colneg, e->flags.p, nz, nblk + 1u);
-  int prev_bulk = -1;
-  uint32_t pj = 0;
-  for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
-    const uint32_t Jend = std::min(J + KOUT, nblk), owner = pj % N;
-    const uint32_t ntl = e->dist_rows_off[pj + 1] - e->dist_rows_off[pj];
-    const uint32_t* tl = e->dist_rows.p + e->dist_rows_off[pj];
-    const uint32_t w = (Jend - J) * NB, nrows = ntl * NB + 1;  // active row tiles + the rhs row
-    const size_t n_cols = (size_t)nrows * w;
+                       colneg, e->flags.p, nz, nblk + 1u, (const uint32_t*)nullptr);
+  // row list of a square: its tiles, then the rhs row — built per panel in a small device array
+  DBuf<uint32_t> sq_list;
+  {
+    std::vector<uint32_t> h;
+    for (const DistPanel& pn : pl.panels) {
+      for (uint32_t t = pn.c0; t < pn.c1; ++t) h.push_back(t);
+      h.push_back(nblk);
+    }
+    BAE_HIP(sq_list.alloc(h.size()));
+    BAE_HIP(hipMemcpyAsync(sq_list.p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s0));
+    BAE_HIP(hipStreamSynchronize(s0));  // (h is a local)
+  }
+  static const bool no128 = getenv("BA_HIP_NO128") != nullptr;
+  int rc = 0;
+  size_t sq_off = 0;
+  for (uint32_t J = 0; J < npanels && !rc; ++J) {
+    const DistPanel& pn = pl.panels[J];
+    const uint32_t c0 = pn.c0, c1 = pn.c1, wt = c1 - c0, w = wt * NB;
+    const uint32_t* sq = sq_list.p + sq_off;
+    sq_off += wt + 1;
+    const bool last = c1 >= nblk;
+    // ---- chain stream: the square ----------------------------------------------------------------------
+    double* msg = e->dist_msg.p;
+    const size_t n_cols = (size_t)(w + 1) * w;
     double* m_sgn = msg + n_cols;
     double* m_neg = m_sgn + w;
-    double* m_op = m_neg + KOUT;
-    const size_t msg_len = n_cols + w + KOUT + (size_t)(Jend - J) * NOPV * 64;
-    if (rank == owner) {
-      launch_panel_chain(s0, dA, ld, nblk, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
-      hipLaunchKernelGGL(k_copy_panel_rows, dim3(nrows), dim3(256), 0, s0, dA, ld, tl, ntl, nblk * NB, J * NB, w,
-                         msg, 0);
-      BAE_HIP(hipMemcpyAsync(m_sgn, dsgn + (size_t)J * NB, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
-      BAE_HIP(hipMemcpyAsync(m_neg, colneg + J, (Jend - J) * sizeof(int), hipMemcpyDeviceToDevice, s0));
-      BAE_HIP(hipMemcpyAsync(m_op, opbuf + (size_t)J * NOPV * 64, (size_t)(Jend - J) * NOPV * 64 * sizeof(double),
+    double* m_op = m_neg + wt;
+    const size_t msg_len = n_cols + w + wt + (size_t)wt * NOPV * 64;
+    if (rank == pn.diag_owner) {
+      // (its updates by the earlier panels: bulk of steps <= J-2 and the chain-stream update of step J-1,
+      // both ordered before this point by the waits of step J-1)
+      launch_panel_chain(s0, dA, ld, nblk, c0, c1, dsgn, opbuf, colneg, e->flags.p, nz, sq, wt + 1, true);
+      hipLaunchKernelGGL(k_copy_panel_rows, dim3(w + 1), dim3(256), 0, s0, dA, ld, sq, wt, n_pad, c0 * NB, w, msg, 0);
+      BAE_HIP(hipMemcpyAsync(m_sgn, dsgn + (size_t)c0 * NB, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(m_neg, colneg + c0, wt * sizeof(int), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(m_op, opbuf + (size_t)c0 * NOPV * 64, (size_t)wt * NOPV * 64 * sizeof(double),
                              hipMemcpyDeviceToDevice, s0));
     }
     BAE_HIP(hipGetLastError());
-    // the message is complete / the previous unpack done in stream order; a native communicator
-    // enqueues the broadcast behind them, a hook gets a drained stream
-    {
-      const int brc = dist_broadcast(e, msg, msg_len, (int)owner, s0);
-      if (brc) return brc;
-    }
-    if (rank != owner) {
-      hipLaunchKernelGGL(k_copy_panel_rows, dim3(nrows), dim3(256), 0, s0, dA, ld, tl, ntl, nblk * NB, J * NB, w,
-                         msg, 1);
-      BAE_HIP(hipMemcpyAsync(dsgn + (size_t)J * NB, m_sgn, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
-      BAE_HIP(hipMemcpyAsync(colneg + J, m_neg, (Jend - J) * sizeof(int), hipMemcpyDeviceToDevice, s0));
-      BAE_HIP(hipMemcpyAsync(opbuf + (size_t)J * NOPV * 64, m_op, (size_t)(Jend - J) * NOPV * 64 * sizeof(double),
+    if ((rc = dist_broadcast(e, msg, msg_len, (int)pn.diag_owner, s0))) break;
+    if (rank != pn.diag_owner) {
+      hipLaunchKernelGGL(k_copy_panel_rows, dim3(w + 1), dim3(256), 0, s0, dA, ld, sq, wt, n_pad, c0 * NB, w, msg, 1);
+      BAE_HIP(hipMemcpyAsync(dsgn + (size_t)c0 * NB, m_sgn, w * sizeof(double), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(colneg + c0, m_neg, wt * sizeof(int), hipMemcpyDeviceToDevice, s0));
+      BAE_HIP(hipMemcpyAsync(opbuf + (size_t)c0 * NOPV * 64, m_op, (size_t)wt * NOPV * 64 * sizeof(double),
                              hipMemcpyDeviceToDevice, s0));
     }
-    if (Jend >= nblk) break;
-    BAE_HIP(hipEventRecord(e->ev_panel[pj], s0));
-    const uint32_t a_end = std::min(Jend + KOUT, nblk);
-    if (rank == (pj + 1) % N) {
-      // next panel's columns (owned here): update + factor packet of its first diagonal tile
-      if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
-      launch_next_panel_update(s0, dA, ld, nblk, Jend, a_end - Jend, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
+    if (last) break;
+    // ---- chain stream: the urgent block row (block J+1 of panel J) -------------------------------------
+    // its tiles took the updates of the panels < J on the panel stream (step J-1: column block J)
+    if (pn.own_u_count[rank]) {
+      if (J > 0) BAE_HIP(hipStreamWaitEvent(s0, EV(J - 1, 3), 0));
+      launch_panel_chain(s0, dA, ld, nblk, c0, c1, dsgn, opbuf, colneg, e->flags.p, nz, dtiles + pn.own_u_first[rank],
+                         pn.own_u_count[rank], false);
     }
-    if (a_end < nblk) {
-      BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
-      launch_bulk_update(e, s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz, true, rank, N, KOUT);
-      BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
-      prev_bulk = (int)pj;
+    auto run_messages = [&](bool urgent, hipStream_t sp, hipStream_t sc, double* sendbuf, double* recvbuf,
+                            hipEvent_t packed_ev) -> int {
+      // pack on `sp` (the stream that computed the rows), transfer + unpack on `sc`
+      std::vector<DistXfer> xf;
+      struct Unp { const uint32_t* tl; uint32_t n; double* buf; };
+      std::vector<Unp> unp;
+      size_t so = 0, ro = 0;
+      for (uint32_t mi : pn.msgs) {
+        const DistMsg& m = pl.msgs[mi];
+        if (m.urgent != urgent) continue;
+        const size_t cnt = (size_t)m.count * NB * w;
+        if (m.src == rank) {
+          hipLaunchKernelGGL(k_copy_panel_rows, dim3(m.count * NB), dim3(256), 0, sp, dA, ld, dtiles + m.first, m.count,
+                             n_pad, c0 * NB, w, sendbuf + so, 0);
+          for (uint32_t q : m.dst) xf.push_back({sendbuf + so, cnt, (int)q, true});
+          so += cnt;
+        }
+        if (std::find(m.dst.begin(), m.dst.end(), rank) != m.dst.end()) {
+          xf.push_back({recvbuf + ro, cnt, (int)m.src, false});
+          unp.push_back({dtiles + m.first, m.count, recvbuf + ro});
+          ro += cnt;
+        }
+      }
+      BAE_HIP(hipGetLastError());
+      if (sp != sc) {
+        BAE_HIP(hipEventRecord(packed_ev, sp));
+        BAE_HIP(hipStreamWaitEvent(sc, packed_ev, 0));
+      }
+      const int xrc = dist_exchange(e, xf, !urgent, sc);
+      if (xrc) return xrc;
+      for (const Unp& u : unp)
+        hipLaunchKernelGGL(k_copy_panel_rows, dim3(u.n * NB), dim3(256), 0, sc, dA, ld, u.tl, u.n, n_pad, c0 * NB, w,
+                           u.buf, 1);
+      BAE_HIP(hipGetLastError());
+      return 0;
+    };
+    if ((rc = run_messages(true, s0, s0, e->dist_usend.p, e->dist_urecv.p, nullptr))) break;
+    BAE_HIP(hipEventRecord(EV(J, 0), s0));
+    // ---- chain stream: panel J applied to the next square (and its rhs segment) + its first diagonal tile
+    const uint32_t n1 = std::min(c1 + KOUT, nblk);  // end of column block J+1
+    if (rank == pl.panels[J + 1].diag_owner) {
+      if (J > 0) BAE_HIP(hipStreamWaitEvent(s0, EV(J - 1, 4), 0));  // the bulk updates of its tiles by the panels < J
+      hipLaunchKernelGGL(k_step_update, dim3(n1 - c1 + 1, n1 - c1), dim3(256), 0, s0, dA, ld, nblk, c1, c0, c1, dsgn, opbuf,
+                         colneg, e->flags.p, nz, nblk + 1u, (const uint32_t*)(sq_list.p + sq_off));
+    }
+    // ---- panel stream: the other own rows of panel J, their messages -----------------------------------
+    BAE_HIP(hipStreamWaitEvent(s1, EV(J, 0), 0));
+    if (J > 0) BAE_HIP(hipStreamWaitEvent(s1, EV(J - 1, 2), 0));  // the side staging buffers are free again
+    if (pn.own_r_count[rank])
+      launch_panel_chain(s1, dA, ld, nblk, c0, c1, dsgn, opbuf, colneg, e->flags.p, nz, dtiles + pn.own_r_first[rank],
+                         pn.own_r_count[rank], false);
+    if ((rc = run_messages(false, s1, s3, e->dist_ssend.p, e->dist_srecv.p, EV(J, 1)))) break;
+    BAE_HIP(hipEventRecord(EV(J, 2), s3));
+    // ---- panel stream: panel J applied to the own tiles of column block J+1 below its square ------------
+    BAE_HIP(hipStreamWaitEvent(s1, EV(J, 2), 0));
+    if (J > 0) BAE_HIP(hipStreamWaitEvent(s1, EV(J - 1, 4), 0));
+    if (n1 < nblk) {
+      const uint32_t ncols = n1 - c1, m = nblk - n1;
+      OwnMap o1 = own;
+      o1.skip_rhs = 1;  // the rhs segment of column block J+1 went with the square's update on the chain stream
+      if (!no128 && m >= 16 && ncols % 2u == 0 && c1 % 2u == 0 && own.G % 2u == 0) {
+        const uint32_t m2 = m / 2, rect_cols = ncols / 2;
+        const uint32_t nrow64 = (ncols * (1 + (m & 1u)) + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_update128<true>, dim3(nrow64 + m2 * rect_cols), dim3(256), 0, s1, dA, ld, nblk, c1, m2, c0, c1,
+                           (const double*)dsgn, (const int*)colneg, 0u, nz, o1, nrow64, n1, rect_cols);
+      } else {
+        // 64-tiles: exactly the row tiles this rank owns below the square of panel J+1 (its two row lists are
+        // adjacent) — a structurally zero tile of L takes no update, so the lists are complete
+        const DistPanel& pq = pl.panels[J + 1];
+        const uint32_t cnt = pq.own_u_count[rank] + pq.own_r_count[rank];
+        if (cnt)
+          hipLaunchKernelGGL(k_step_update, dim3(cnt, ncols), dim3(256), 0, s1, dA, ld, nblk, c1, c0, c1, dsgn, opbuf,
+                             colneg, e->flags.p, nz, nblk + 1u, dtiles + pq.own_u_first[rank]);
+      }
+    }
+    BAE_HIP(hipEventRecord(EV(J, 3), s1));
+    // ---- bulk stream: panel J applied to the own tiles right of column block J+1 -----------------------
+    if (n1 < nblk) {
+      BAE_HIP(hipStreamWaitEvent(s2, EV(J, 2), 0));
+      BAE_HIP(hipStreamWaitEvent(s2, EV(J, 0), 0));
+      launch_bulk_update(e, s2, dA, ld, nblk, n1, c0, c1, dsgn, colneg, nz, true, own);
       if (e->profiling) {
-        // tile products formed by THIS rank: columns c it owns, rows i >= c (+ the rhs row), both
-        // operand tiles structurally nonzero
-        const bool pat = nz && e->nzL_host.size() == (size_t)nblk * nblk;
+        // tile products formed by THIS rank: tiles (i, c), i >= c >= n1, it owns, both operand tiles of the
+        // panel column structurally nonzero; per row class a suffix count of the nonzero tiles of the column
         double tiles = 0.0;
-        std::vector<double> suffix(nblk + 1);
-        for (uint32_t kb = J; kb < Jend; ++kb) {
-          suffix[nblk] = 0.0;
-          for (uint32_t r = nblk; r-- > a_end;)
-            suffix[r] = suffix[r + 1] + (pat ? (double)e->nzL_host[(size_t)r * nblk + kb] : 1.0);
-          for (uint32_t c = a_end; c < nblk; ++c)
-            if ((c / KOUT) % N == rank && (!pat || e->nzL_host[(size_t)c * nblk + kb])) tiles += suffix[c] + 1.0;
+        std::vector<double> suffix((size_t)own.T * (nblk + 1));
+        for (uint32_t kb = c0; kb < c1; ++kb) {
+          for (uint32_t a = 0; a < own.T; ++a) suffix[(size_t)a * (nblk + 1) + nblk] = 0.0;
+          for (uint32_t r = nblk; r-- > n1;)
+            for (uint32_t a = 0; a < own.T; ++a)
+              suffix[(size_t)a * (nblk + 1) + r] = suffix[(size_t)a * (nblk + 1) + r + 1] +
+                  (((r / own.G) % own.T == a && (!pat || e->nzL_host[(size_t)r * nblk + kb])) ? 1.0 : 0.0);
+          for (uint32_t c = n1; c < nblk; ++c) {
+            if (pat && !e->nzL_host[(size_t)c * nblk + kb]) continue;
+            const uint32_t cc = (c / own.G) % own.T;
+            for (uint32_t a = 0; a < own.T; ++a)
+              if (own.n <= 1 || own.tbl[a][cc] == rank) tiles += suffix[(size_t)a * (nblk + 1) + c];
+            if (own.n <= 1 || own.tbl[cc][cc] == rank) tiles += 1.0;  // the rhs row
+          }
         }
         e->kstats.syrk_flops += tiles * 2.0 * NB * NB * NB;
       }
     }
+    BAE_HIP(hipEventRecord(EV(J, 4), s2));
   }
+  if (rc) { sq_list.release(); return rc; }
   BAE_HIP(hipGetLastError());
+  // every stream has drained into the chain stream's view before the backward substitution
   BAE_HIP(hipStreamSynchronize(s1));
+  BAE_HIP(hipStreamSynchronize(s2));
+  BAE_HIP(hipStreamSynchronize(s3));
   hipLaunchKernelGGL(k_linvT, dim3(nblk), dim3(256), 0, s0, (const double*)opbuf, (const double*)dsgn, linvT);
-  launch_backward(s0, dA, ld, nblk, (const double*)linvT, dx, nz);
+  // ---- backward substitution, panels from the last -------------------------------------------------------
+  double* yrow = dA + (size_t)n_pad * ld;
+  double* part = e->dist_back.p;
+  double* psum = part + (size_t)NG * wmax;
+  for (uint32_t J = npanels; J-- > 0 && !rc;) {
+    const DistPanel& pn = pl.panels[J];
+    const uint32_t c0 = pn.c0, c1 = pn.c1, w = (c1 - c0) * NB;
+    if (c1 < nblk) {
+      const uint32_t nt = pn.own_u_count[rank] + pn.own_r_count[rank];  // (the two lists are adjacent)
+      const uint32_t ng = std::min(NG, std::max(nt, 1u));
+      if (nt) {
+        hipLaunchKernelGGL(k_back_partial, dim3((w + 255) / 256, ng), dim3(256), 0, s0, (const double*)dA, ld, nblk,
+                           dtiles + pn.own_u_first[rank], nt, c0, w, (const double*)dx, nz, part);
+        hipLaunchKernelGGL(k_back_sum, dim3((w + 255) / 256), dim3(256), 0, s0, (const double*)part, ng, w, psum);
+      } else {
+        BAE_HIP(hipMemsetAsync(psum, 0, (size_t)w * sizeof(double), s0));
+      }
+      BAE_HIP(hipGetLastError());
+      if ((rc = dist_allreduce_stream(e, psum, w, s0))) break;
+      hipLaunchKernelGGL(k_back_apply, dim3((w + 255) / 256), dim3(256), 0, s0, yrow + (size_t)c0 * NB, (const double*)psum, w);
+    }
+    launch_backward(s0, dA, ld, nblk, (const double*)linvT, dx, nz, c0, c1);
+  }
+  sq_list.release();
+  if (rc) return rc;
   BAE_HIP(hipGetLastError());
-  // the pivot status of every owner
+  // the pivot status of every diagonal owner
   int st = 0;
   BAE_HIP(hipMemcpyAsync(&st, e->flags.p, sizeof(int), hipMemcpyDeviceToHost, s0));
   BAE_HIP(hipStreamSynchronize(s0));
   double sd = (double)st;
   BAE_HIP(hipMemcpy(e->scalars_out.p, &sd, sizeof(double), hipMemcpyHostToDevice));
-  if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
+  if (shard_allreduce(e, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
   BAE_HIP(hipMemcpy(&sd, e->scalars_out.p, sizeof(double), hipMemcpyDeviceToHost));
   *status = sd > 0.5 ? 1 : 0;
   return 0;
@@ -1562,7 +1769,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   { const int src = setup_status_block(e, dA, ld, s0); if (src) return src; }
   // factor packet of tile 0 (nothing to update: one workgroup)
   hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
-                       colneg, e->flags.p, nz, nblk + 1u);
+                       colneg, e->flags.p, nz, nblk + 1u, (const uint32_t*)nullptr);
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
   // overlapping the serial factorisation of the next panel.
@@ -1584,7 +1791,7 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
       // otherwise the capped variant leaves the chain room
       const uint32_t m = nblk - a_end;
       launch_bulk_update(e, s1, dA, ld, nblk, a_end, J, Jend, dsgn, colneg, nz,
-                         no_lookahead || bulk_full || m >= bulk_full_m, 0u, 1u, 1u);
+                         no_lookahead || bulk_full || m >= bulk_full_m, own_map_single());
       BAE_HIP(hipEventRecord(e->ev_bulk[pj], s1));
       prev_bulk = (int)pj;
       if (e->profiling) {

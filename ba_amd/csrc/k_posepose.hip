@@ -329,7 +329,7 @@ static int sum_small(Engine* e, int n, const double* d_v, double* host) {
   }
   if (e->sharded()) {
     BAE_HIP(hipMemcpy(e->scalars_out.p + 8, host, sizeof(double), hipMemcpyHostToDevice));
-    if (e->allreduce(e->allreduce_ctx, e->scalars_out.p + 8, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
+    if (shard_allreduce(e, e->scalars_out.p + 8, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpy(host, e->scalars_out.p + 8, sizeof(double), hipMemcpyDeviceToHost));
   }
   return 0;
@@ -371,7 +371,9 @@ int launch_imu_early(Engine* e, double c_huber_proj) {
   const uint32_t nu = pb.num_unary, nb = pb.num_binary, ni = pb.num_imu;
   if (ni == 0) return 0;
   const double* state = e->pose_state[e->cur].p;
-  hipStream_t s2 = e->stream2;
+  // BA_HIP_IMU_SERIAL=1 (A/B switch): the inertial kernels on the main stream, ahead of the projection linearisation
+  static const bool serial_env = getenv("BA_HIP_IMU_SERIAL") != nullptr;
+  hipStream_t s2 = serial_env ? e->stream : e->stream2;
   if (!e->ev_imu_done) {
     BAE_HIP(hipEventCreateWithFlags(&e->ev_imu_done, hipEventDisableTiming));
     BAE_HIP(hipEventCreateWithFlags(&e->ev_imu_start, hipEventDisableTiming));
@@ -465,7 +467,7 @@ int launch_posepose_build(Engine* e, double c_huber_proj, double* h3) {  // h3: 
   if (e->sharded()) {
     double cnt = (double)nu;
     BAE_HIP(hipMemcpy(e->scalars_out.p, &cnt, sizeof(double), hipMemcpyHostToDevice));
-    if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
+    if (shard_allreduce(e, e->scalars_out.p, 1, 0) != 0) return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpy(&cnt, e->scalars_out.p, sizeof(double), hipMemcpyDeviceToHost));
     n_un_total = (uint64_t)(cnt + 0.5);
   }

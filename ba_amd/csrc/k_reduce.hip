@@ -706,7 +706,7 @@ int sum_partials(Engine* e, uint32_t nparts, uint32_t ncomp, double* host_out, b
     BAE_HIP(hipMemcpyAsync(e->scalars_out.p, host_out, ncomp * sizeof(double),
                            hipMemcpyHostToDevice, e->stream));
     BAE_HIP(hipStreamSynchronize(e->stream));
-    if (e->allreduce(e->allreduce_ctx, e->scalars_out.p, ncomp, 0) != 0)
+    if (shard_allreduce(e, e->scalars_out.p, ncomp, 0) != 0)
       return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpy(host_out, e->scalars_out.p, ncomp * sizeof(double), hipMemcpyDeviceToHost));
   }
@@ -894,7 +894,7 @@ int select_kth(Engine* e, const double* d_values, uint32_t n_local, uint64_t k, 
     }
     BAE_HIP(hipStreamSynchronize(e->stream));
     if (e->sharded())
-      if (e->allreduce(e->allreduce_ctx, e->hist.p, 2048, 1) != 0)
+      if (shard_allreduce(e, e->hist.p, 2048, 1) != 0)
         return e->fail_msg("allreduce hook failed");
     BAE_HIP(hipMemcpy(hh.data(), e->hist.p, 2048 * sizeof(unsigned long long),
                       hipMemcpyDeviceToHost));

@@ -66,6 +66,34 @@ class StructureStats(C.Structure):
                                           "tiles_S", "tiles_L", "tile_refs", "pose_entries", "linearize_waves")]
 
 
+class CommStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("chain_bytes_sent", "chain_bytes_recv", "side_bytes_sent", "side_bytes_recv",
+                                          "reduce_scatter_bytes", "allreduce_bytes")] + \
+               [(n, C.c_uint64) for n in ("chain_messages", "side_messages", "factorisations")]
+
+
+class DistPlanStats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("factor_bytes", "chain_recv_max", "chain_recv_total", "side_recv_max",
+                                          "side_recv_total", "chain_sent_total", "side_sent_total", "recv_max",
+                                          "backward_allreduce_bytes")] + \
+               [(n, C.c_uint32) for n in ("messages_chain", "messages_side", "panels", "ranks", "classes", "kout")]
+
+
+def dist_plan_stats(nblk, nz_lower, nranks, layout="auto", kout=0):
+    """Byte accounting of the distributed solve's message plan (pure host: no device needed).
+    nz_lower: (nblk, nblk) uint8 tile pattern of the factor, or None for a dense one."""
+    out = DistPlanStats()
+    ptr = None
+    if nz_lower is not None:
+        nz = np.ascontiguousarray(nz_lower, dtype=np.uint8)
+        assert nz.shape == (nblk, nblk)
+        ptr = nz.ctypes.data_as(C.POINTER(C.c_uint8))
+    rc = lib().ba_hip_dist_plan_stats(int(nblk), ptr, int(nranks), layout.encode(), int(kout), C.byref(out))
+    if rc != 0:
+        raise ValueError("layout %r does not exist for %d ranks" % (layout, nranks))
+    return {k: getattr(out, k) for k, _ in DistPlanStats._fields_}
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 COLLECTIVE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int)
 
@@ -87,6 +115,7 @@ SYMBOLS = [
     "ba_hip_set_calibration", "ba_hip_num_calib_params", "ba_hip_get_cameras", "ba_hip_get_calib_jacobians", "ba_hip_get_calibration_marginals", "ba_hip_set_landmark_ref_pixels", "ba_hip_get_camera_params",
     "ba_hip_set_camera_models", "ba_hip_get_camera_fov",
     "ba_hip_integrate_imu_jacobians", "ba_hip_imu_pose_derivative", "ba_hip_imu_integrate_pose", "ba_hip_lie",
+    "ba_hip_get_comm_stats", "ba_hip_reset_comm_stats", "ba_hip_dist_plan_stats", "ba_hip_get_factor_tile_pattern",
 ]
 
 
@@ -428,6 +457,22 @@ class Engine:
 
     def solve_is_distributed(self):
         return bool(self.L.ba_hip_solve_is_distributed(self.h))
+
+    def comm_stats(self, reset=False):
+        """Bytes this rank moved per stream of the communicator(s) since the last reset (ba_hip_comm_stats)."""
+        out = CommStats()
+        self._chk(self.L.ba_hip_get_comm_stats(self.h, C.byref(out)))
+        if reset:
+            self._chk(self.L.ba_hip_reset_comm_stats(self.h))
+        return {k: getattr(out, k) for k, _ in CommStats._fields_}
+
+    def factor_tile_pattern(self):
+        """(nblk, nblk) uint8 lower tile pattern of the factor of the reduced system."""
+        nblk = (self.num_pose_params() + self.num_calib_params() + 63) // 64
+        nblk = max(nblk, 1)
+        out = np.zeros((nblk, nblk), dtype=np.uint8)
+        self._chk(self.L.ba_hip_get_factor_tile_pattern(self.h, nblk, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
 
     def dense_solve(self, a_lower, b):
         a, b = _d(a_lower), _d(b)

@@ -75,19 +75,28 @@ def torch_allreduce_hook(dist, device="cuda"):
 def torch_collectives_hook(dist, device="cuda"):
     """Hook (op, ptr, count, root) -> 0 for ba_hip_set_collectives over the torch.distributed
     default group (RCCL): op 1 = broadcast `count` doubles from `root`; op 2 = reduce-scatter
-    (sum) of world_size chunks of `count` doubles, the result lands in this rank's chunk."""
+    (sum) of world_size chunks of `count` doubles, the result lands in this rank's chunk; op 3 / 4 =
+    send to / receive from rank `root` (point-to-point messages of the distributed solve)."""
     import torch
+    pending = []   # (work, buffer) of the sends in flight
 
     def fn(op, ptr, count, root):
         try:
             world, rank = dist.get_world_size(), dist.get_rank()
-            n = count if op == 1 else count * world
+            n = count * world if op == 2 else count
             if device == "cuda":
                 t = torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
             else:  # host buffers (gloo; CPU tests)
                 t = torch.from_numpy(_host_view(ptr, n, 0))
             if op == 1:
                 dist.broadcast(t, src=root)
+            elif op == 3:   # send to `root`: must not block on the receiver
+                buf = t.clone()
+                pending.append((dist.isend(buf, dst=root), buf))
+                return 0
+            elif op == 4:   # receive from `root`
+                dist.recv(t, src=root)
+                pending[:] = [(w, b) for (w, b) in pending if not w.is_completed()]
             elif op == 2:
                 if device == "cuda" and dist.get_backend() != "gloo":
                     out = torch.empty(count, dtype=torch.float64, device="cuda")
@@ -119,6 +128,8 @@ class ThreadAllReduce:
         self.barrier = threading.Barrier(nranks)
         self.slots = [None] * nranks
         self.failed = False
+        import queue
+        self.mail = {(a, b): queue.Queue() for a in range(nranks) for b in range(nranks)}
 
     def hook(self, rank):
         torch = self.torch
@@ -156,8 +167,19 @@ class ThreadAllReduce:
 
         def fn(op, ptr, count, root):
             try:
-                n = count if op == 1 else count * self.n
+                n = count * self.n if op == 2 else count
                 t = torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
+                if op == 3:      # send: a private copy goes into the receiver's mailbox, no waiting
+                    buf = t.clone()
+                    torch.cuda.synchronize()
+                    self.mail[(rank, root)].put(buf)
+                    return 0
+                if op == 4:      # receive: blocks until the sender's copy is there
+                    buf = self.mail[(root, rank)].get(timeout=120)
+                    assert buf.numel() == count
+                    t.copy_(buf)
+                    torch.cuda.synchronize()
+                    return 0
                 self.slots[rank] = t
                 self.barrier.wait()
                 if op == 1:

@@ -143,11 +143,15 @@ def api_options(mod, cfg):
     return o
 
 
-def build_adjuster(cfg, sc, lm_dim):
-    """C++ API driver: ba::BundleAdjuster<double, LmSize, PoseSize> through include/ba_capi.h."""
+def build_adjuster(cfg, sc, lm_dim, lm_range=None, pose_pose=True, device=0):
+    """C++ API driver: ba::BundleAdjuster<double, LmSize, PoseSize> through include/ba_capi.h.
+    lm_range / pose_pose: this rank's landmark shard; inertial / unary / binary residuals on rank 0 only."""
     h = adjuster.BundleAdjuster(lm_dim, cfg["D"])
-    h.Init(api_options(adjuster, cfg))
-    scene.populate(h, sc, active=active_mask(cfg, sc), imu=cfg["imu"], priors=cfg["priors"])
+    o = api_options(adjuster, cfg)
+    o.device = device
+    h.Init(o)
+    scene.populate(h, sc, active=active_mask(cfg, sc), imu=cfg["imu"], priors=cfg["priors"], lm_range=lm_range,
+                   pose_pose=pose_pose)
     return h
 
 
@@ -264,8 +268,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world != 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if world > 1 and api_driver:
-        raise SystemExit("configs 2 / 4 are single-GPU benchmarks (pose-pose residuals live on one rank)")
     dist = torch = None
     # BA_BENCH_COMM=native (default): the engine's own RCCL communicator (ba_hip_comm_init) carries
     # every collective; torch.distributed (gloo) is only the launcher's control plane (unique-id
@@ -354,8 +356,20 @@ def main():
             log("C++ API path: first Solve(1) %.2f s, warm Solve(1) %.1f ms" % (first_solve_s, api_ms))
             del h
     else:
-        h = build_adjuster(cfg, sc, lm_dim)
+        # configs 2 / 4 through ba::BundleAdjuster.  N > 1: every rank holds all poses and its landmark shard,
+        # the pose-pose residuals (inertial, unary, binary) live on rank 0, the gauge masks follow from
+        # GLOBAL residual counts, and the class joins the engine-owned RCCL communicator (SetCommunicator)
+        if world > 1:
+            nsel = K + (1 if lm_dim == 1 else 0)
+            lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
+            h = build_adjuster(cfg, sc, lm_dim, lm_range=(lo, hi), pose_pose=(rank == 0), device=local_rank)
+            ids = [hipapi.Engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            h.set_communicator(ids[0], rank, world, distributed_solve=not os.environ.get("BA_BENCH_REPLICATED_SOLVE"))
+        else:
+            h = build_adjuster(cfg, sc, lm_dim)
         log("graph built on the host")
+        barrier()
         t_setup = time.perf_counter()
         h.Solve(1)       # upload + structure build + the first iteration
         t_setup = time.perf_counter() - t_setup
@@ -365,17 +379,23 @@ def main():
             h.Solve(1)
         ev = h.engine()
         ev.set_profiling(True)
+        barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             h.Solve(1)
             s = h.summary()
             accepted += int(adjuster.RESULT_NAMES[s.result] == "Success")
             err = s.post_solve_norm if cfg["dogleg"] else s.proj_error + s.inertial_error + s.unary_error + s.binary_error
+        barrier()
         elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         log("timed region done: %.1f ms / step" % (1e3 * elapsed / args.steps))
         ks = ev.kernel_stats()
         timers = ev.get_timers()
-        stats = ev.structure_stats()
+        stats = ev.structure_stats() if world == 1 else {}
         ev.set_profiling(False)
         n = ev.num_pose_params()
         api_ms = 1e3 * elapsed / args.steps

@@ -461,6 +461,29 @@ class BundleAdjuster {
     allreduce_ = fn; allreduce_ctx_ = ctx; rank_ = rank; nranks_ = nranks;
     mask_counts_dirty_ = true;
   }
+  // multi-GPU without hooks: the engine's own RCCL communicator over xGMI (include/ba_hip.h: ba_hip_comm_*).
+  // One process per GPU; rank 0 creates the 128-byte id with CreateCommunicatorId and hands it to the other
+  // ranks out of band (a file, MPI, a socket); every rank then calls SetCommunicator before Solve().  The
+  // next Solve() joins the communicator (collective over all ranks: they must all call Solve()).  Every
+  // rank holds all poses and its landmark shard, pose-pose residuals live on rank 0, and
+  //   distributed_solve = true   the reduced system is reduce-scattered onto the owners of its tile blocks
+  //                              and factorised by all GPUs (ba_amd/csrc/dist_plan.h);
+  //   distributed_solve = false  it is all-reduced and factorised by every rank (replicated).
+  // The reference (single process) has no counterpart; replaces the loop body of BundleAdjuster.cpp:298-663
+  // across the GPUs of a node.
+  static bool CreateCommunicatorId(void* id128) { return ba_hip_comm_unique_id(id128) == 0; }
+  void SetCommunicator(const void* id128, int rank, int nranks, bool distributed_solve = true) {
+    std::memcpy(comm_id_, id128, sizeof(comm_id_));
+    comm_set_ = true; comm_dirty_ = true; comm_dist_ = distributed_solve;
+    allreduce_ = nullptr; allreduce_ctx_ = nullptr; rank_ = rank; nranks_ = nranks;
+    mask_counts_dirty_ = true;
+  }
+  void ClearCommunicator() {
+    if (comm_set_ && engine_) ba_hip_comm_destroy(engine_);
+    comm_set_ = false; comm_dirty_ = false; rank_ = 0; nranks_ = 1;
+    mask_counts_dirty_ = true;
+  }
+  bool SolveIsDistributed() const { return engine_ && ba_hip_solve_is_distributed(engine_) != 0; }
 
  private:
   uint32_t GetGravityRegularizationDimension(uint32_t pose_id) {  // reference :634-652
@@ -553,6 +576,8 @@ class BundleAdjuster {
   ba_hip_allreduce_fn engine_allreduce_ = nullptr;  // what the engine currently has installed
   void* engine_allreduce_ctx_ = nullptr;
   bool engine_per_pose_cam_ = false;
+  unsigned char comm_id_[128] = {};     // SetCommunicator: the RCCL unique id
+  bool comm_set_ = false, comm_dirty_ = false, comm_dist_ = true;
 };
 
 template <typename Scalar>
@@ -583,6 +608,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
     if (kCalibDim > 0 && !Check(ba_hip_set_calibration(engine_, CalibSize, DoTvs ? 1 : 0), "ba_hip_set_calibration")) return false;
     engine_device_ = options_.device;
     structure_dirty_ = true;
+    if (comm_set_) comm_dirty_ = true;  // a new engine joins the communicator again
   }
   ba_hip_options o;
   std::memset(&o, 0, sizeof(o));
@@ -595,7 +621,15 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
   o.gyro_bias_sigma = options_.gyro_bias_sigma; o.accel_bias_sigma = options_.accel_bias_sigma;
   o.pivot_rel_tolerance = options_.factorization_pivot_tolerance;
   if (!Check(ba_hip_set_options(engine_, &o), "ba_hip_set_options")) return false;
-  if (structure_dirty_ || allreduce_ != engine_allreduce_ || allreduce_ctx_ != engine_allreduce_ctx_) {
+  if (comm_set_) {
+    // native communicator: joined once per engine (a collective), the solve switch refreshed with it
+    if (comm_dirty_) {
+      if (!Check(ba_hip_comm_init(engine_, comm_id_, rank_, nranks_), "ba_hip_comm_init")) return false;
+      if (!comm_dist_) ba_hip_set_collectives(engine_, nullptr, nullptr);  // replicated solve: all-reduce of S only
+      comm_dirty_ = false;
+      engine_allreduce_ = nullptr; engine_allreduce_ctx_ = nullptr;
+    }
+  } else if (structure_dirty_ || allreduce_ != engine_allreduce_ || allreduce_ctx_ != engine_allreduce_ctx_) {
     ba_hip_set_allreduce(engine_, allreduce_, allreduce_ctx_, rank_, nranks_);
     engine_allreduce_ = allreduce_; engine_allreduce_ctx_ = allreduce_ctx_;
   }

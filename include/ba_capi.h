@@ -121,6 +121,10 @@ uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[
 /* GetLastStep().delta_k (zeros without do_tvs) */
 void ba_adjuster_get_last_calib_step(const ba_adjuster* a, double delta_k[6]);
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks);
+/* ba::BundleAdjuster::SetCommunicator / ClearCommunicator (id128 = NULL): the engine-owned RCCL communicator;
+ * the next Solve() joins it (collective).  distributed_solve 1 = distributed reduced solve, 0 = replicated. */
+void ba_adjuster_set_communicator(ba_adjuster* a, const void* id128, int rank, int nranks, int distributed_solve);
+int ba_adjuster_solve_is_distributed(ba_adjuster* a);
 
 #ifdef __cplusplus
 }

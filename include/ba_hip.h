@@ -373,6 +373,8 @@ int ba_hip_allreduce_host(ba_hip_engine* e, void* host, size_t count, int dtype)
  *          return chunk `rank` (at dev_ptr + rank * count) holds the sum over ranks of that chunk.
  * Same calling conventions as the all-reduce hook.  NULL = replicated solve. */
 typedef int (*ba_hip_collective_fn)(void* ctx, int op, void* dev_ptr, size_t count, int root);
+/* (ops 3 / 4 of the hook, used by the distributed solve since round 3: op 3 = send `count` doubles at
+ * dev_ptr to rank `root`, must not block on the receiver; op 4 = receive `count` doubles from rank `root`.) */
 int ba_hip_set_collectives(ba_hip_engine* e, ba_hip_collective_fn fn, void* ctx);
 /* Native communicator: the engine loads librccl itself (one process per GPU, RCCL over xGMI) and
  * runs every cross-shard sum and the collectives of the distributed reduced solve on an
@@ -388,6 +390,35 @@ int ba_hip_set_collectives(ba_hip_engine* e, ba_hip_collective_fn fn, void* ctx)
 int ba_hip_comm_unique_id(void* id128);
 int ba_hip_comm_init(ba_hip_engine* e, const void* id128, int rank, int nranks);
 int ba_hip_comm_destroy(ba_hip_engine* e);
+/* Bytes this rank moved through the communicator(s) since the last reset: the chain stream carries what
+ * the next panel waits for (factorised squares, the block row under them, the backward substitution's
+ * partial sums), the side stream the rest of every panel (consumed by the bulk trailing updates). */
+typedef struct {
+  double chain_bytes_sent, chain_bytes_recv;   /* square broadcasts (root: sent, others: received) + urgent rows */
+  double side_bytes_sent, side_bytes_recv;     /* the remaining rows of every panel, point to point */
+  double reduce_scatter_bytes;                 /* partial S onto the tile owners (send buffer size per call) */
+  double allreduce_bytes;                      /* every all-reduced buffer (rhs, scalars, histograms, patterns) */
+  uint64_t chain_messages, side_messages, factorisations;
+} ba_hip_comm_stats;
+int ba_hip_get_comm_stats(ba_hip_engine* e, ba_hip_comm_stats* out);
+int ba_hip_reset_comm_stats(ba_hip_engine* e);
+/* Byte accounting of the distributed solve's message plan WITHOUT a device (pure host): nz_lower is the
+ * nblk x nblk row-major byte pattern of the factor's 64x64 tiles (NULL = dense), layout one of "auto",
+ * "tri", "grid", "col", "row" (ba_amd/csrc/dist_plan.h), kout the panel width in tiles (0 = the engine's
+ * choice for nblk).  Returns 0, or -1 if the layout does not exist for nranks. */
+typedef struct {
+  double factor_bytes;                         /* the whole factor: what a 1-D panel broadcast hands to every rank */
+  double chain_recv_max, chain_recv_total;     /* per factorisation: busiest receiver / sum over ranks */
+  double side_recv_max, side_recv_total;
+  double chain_sent_total, side_sent_total;
+  double recv_max;                             /* chain + side of the busiest receiver */
+  double backward_allreduce_bytes;
+  uint32_t messages_chain, messages_side, panels, ranks, classes, kout;
+} ba_hip_dist_plan_stats_t;
+int ba_hip_dist_plan_stats(uint32_t nblk, const uint8_t* nz_lower, int nranks, const char* layout, uint32_t kout,
+                           ba_hip_dist_plan_stats_t* out);
+/* Tile pattern of the factor as the engine holds it (nblk x nblk bytes, lower): for the accounting above. */
+int ba_hip_get_factor_tile_pattern(ba_hip_engine* e, uint32_t nblk, uint8_t* nz_lower);
 /* 1 if the next ba_hip_solve_gn will run the distributed solve, 0 if replicated / single. */
 int ba_hip_solve_is_distributed(ba_hip_engine* e);
 

@@ -608,15 +608,27 @@ def test_two_shards_equal_one(oracle_lib, lm_dim):
     assert rel_err(lms, single.get_landmarks(L)) < 1e-9
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_distributed_solve_matches_single(oracle_lib, nranks):
-    """Distributed reduced solve (ba_hip_set_collectives): 300 poses -> 28 tiles = 7 column
-    panels dealt round-robin to 2 / 3 engines that hold a landmark shard each; reduce-scatter of
-    S, per-panel factorisation + broadcast, owner-filtered trailing updates.  Errors, step
-    norms and the final state must agree with ONE engine solving the whole scene."""
+@pytest.mark.parametrize("nranks,layout", [(2, "auto"), (3, "auto"), (4, "auto"), (8, "auto"), (8, "row"), (4, "tri_refused")],
+                         ids=["2_tri", "3_col", "4_grid", "8_tri", "8_row", "4_tri_refused"])
+def test_distributed_solve_matches_single(oracle_lib, monkeypatch, nranks, layout):
+    """Distributed reduced solve (ba_hip_set_collectives; ba_amd/csrc/dist_plan.h): 300 poses -> 28 tiles
+    = 7 x 7 blocks of 4 x 4 tiles owned by 2 / 3 / 4 / 8 engines (thread-emulated ranks on one GPU) that
+    hold a landmark shard each; reduce-scatter of S onto the block owners, per-panel square broadcast,
+    urgent + side point-to-point rows, owner-filtered trailing updates, distributed backward
+    substitution.  Errors, step norms and the final state must agree with ONE engine solving the whole
+    scene and with the oracle; the step is bitwise equal across the ranks; the bytes every rank moved equal
+    what the message plan says (ba_hip_get_comm_stats against ba_hip_dist_plan_stats)."""
     import threading
 
     from ba_amd import sharding
+    if layout == "tri_refused":
+        # a layout that does not exist for this rank count is an error, not a silent fallback
+        monkeypatch.setenv("BA_HIP_DIST_LAYOUT", "tri")
+        with pytest.raises(ValueError):
+            hipapi.dist_plan_stats(28, None, nranks, "tri")
+        return
+    if layout != "auto":
+        monkeypatch.setenv("BA_HIP_DIST_LAYOUT", layout)
     lm_dim = 1
     sc = scene.make_scene(300, 3000, 6, lm_dim=lm_dim, seed=67)
     pa = np.ones(sc.num_poses, dtype=np.uint8)
@@ -640,7 +652,8 @@ def test_distributed_solve_matches_single(oracle_lib, nranks):
     L = sc.num_landmarks
     single = make(0, L)
     out = {}
-    _run_engine_steps(single, 3, out, "single")
+    iters = 3
+    _run_engine_steps(single, iters, out, "single")
     shards = sharding.landmark_shards(np.full(L, sc.obs_per_landmark), nranks)
     engs = [make(*shards[r]) for r in range(nranks)]
     ar = sharding.ThreadAllReduce(nranks)
@@ -649,15 +662,15 @@ def test_distributed_solve_matches_single(oracle_lib, nranks):
         engs[r].set_collectives(ar.collectives(r))
         assert engs[r].solve_is_distributed()
     assert not single.solve_is_distributed()
-    th = [threading.Thread(target=_run_engine_steps, args=(engs[r], 3, out, r)) for r in range(nranks)]
+    th = [threading.Thread(target=_run_engine_steps, args=(engs[r], iters, out, r)) for r in range(nranks)]
     for t in th:
         t.start()
     for t in th:
-        t.join(timeout=180)
+        t.join(timeout=300)
     assert not ar.failed
     for k in ["single"] + list(range(nranks)):
         assert not isinstance(out[k], Exception), out[k]
-    for it in range(3):
+    for it in range(iters):
         a = out["single"][it]
         for r in range(nranks):
             b = out[r][it]
@@ -665,19 +678,31 @@ def test_distributed_solve_matches_single(oracle_lib, nranks):
             for x, y in zip(a[1:], b[1:]):
                 assert abs(x - y) <= 1e-8 * max(abs(x), 1e-12)
     ps, _, _ = single.get_poses(sc.num_poses)
+    p0, _, _ = engs[0].get_poses(sc.num_poses)
     for r in range(nranks):
         pr, _, _ = engs[r].get_poses(sc.num_poses)
         assert rel_err(pr, ps) < 1e-9
-    p0, _, _ = engs[0].get_poses(sc.num_poses)
-    p1, _, _ = engs[1].get_poses(sc.num_poses)
-    assert np.array_equal(p0, p1)  # every rank computes the same step bit for bit
+        assert np.array_equal(pr, p0)  # every rank computes the same step bit for bit
+        assert np.array_equal(out[(r, "delta_p")], out[(0, "delta_p")])
     # the distributed factorisation against the ORACLE's dense LDL^T on the whole scene
-    ref = _oracle_gn_run(oracle_lib, sc, lm_dim, pa, 3)
+    ref = _oracle_gn_run(oracle_lib, sc, lm_dim, pa, iters)
     _check_against_oracle(ref, out, "single", ps)
     for r in range(nranks):
         _check_against_oracle(ref, out, r, engs[r].get_poses(sc.num_poses)[0])
+    # byte accounting: what the ranks received, summed, is what the plan says for this pattern
+    nzL = single.factor_tile_pattern()
+    plan = hipapi.dist_plan_stats(nzL.shape[0], nzL, nranks, layout)
+    cs = [engs[r].comm_stats() for r in range(nranks)]
+    assert all(c["factorisations"] == iters for c in cs)
+    chain_recv = sum(c["chain_bytes_recv"] for c in cs)
+    side_recv = sum(c["side_bytes_recv"] for c in cs)
+    assert chain_recv == pytest.approx(iters * plan["chain_recv_total"], rel=1e-12)
+    assert side_recv == pytest.approx(iters * plan["side_recv_total"], rel=1e-12)
+    assert max(c["chain_bytes_recv"] + c["side_bytes_recv"] for c in cs) == pytest.approx(iters * plan["recv_max"], rel=1e-12)
+    assert sum(c["side_bytes_sent"] for c in cs) == pytest.approx(iters * plan["side_sent_total"], rel=1e-12)
     for e_ in engs + [single]:
         e_.end_solve()
+        e_.close()
 
 
 def test_tile_sparse_factorisation_matches_oracle(oracle_lib):
@@ -1593,6 +1618,14 @@ def test_native_rccl_communicator_single_rank(oracle_lib, keep_s):
     assert rel_err(pn, pp) < 1e-9
     ref = _oracle_gn_run(oracle_lib, sc, lm_dim, pa, 3)
     _check_against_oracle(ref, out, "native", pn)
+    cs = native.comm_stats()
+    if keep_s == 0:
+        # one rank: the rows travel to the rank itself — through ncclSend / ncclRecv on BOTH communicators
+        # (chain: square broadcasts + urgent rows; side: ncclCommSplit duplicate, the rest of every panel)
+        assert cs["factorisations"] == 3 and cs["chain_messages"] > 0 and cs["side_messages"] > 0
+        assert cs["chain_bytes_sent"] > 0 and cs["side_bytes_sent"] > 0 and cs["side_bytes_recv"] == cs["side_bytes_sent"]
+        assert cs["reduce_scatter_bytes"] > 0
+    assert cs["allreduce_bytes"] > 0
     native.comm_destroy()
     assert not native.solve_is_distributed()
     for e_ in (plain, native):
