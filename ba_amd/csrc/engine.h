@@ -109,6 +109,7 @@ struct Engine {
   DBuf<uint32_t> tile_ptr;               // [tiles_lower+1]
   DBuf<uint2> tile_ref;                  // (first term, count << 14 | offsets) per block overlapping a tile
   DBuf<uint32_t> tile_order;             // launch order of the tile assembly (build_tile_order)
+  DBuf<uint4> tile_desc;                 // per launch entry: (tile, first ref, end ref, row << 16 | column) (k_tile_desc)
   uint32_t n_tile_order = 0;
   uint64_t tile_order_version = ~0ull;
   int dbg_assemble_variant = 5;          // k_assemble_tiles<VAR> (ba_hip_debug_set key 1)
@@ -275,6 +276,7 @@ bool dist_solve_enabled(const Engine* e);
 int dist_reduce_scatter_S(Engine* e);
 int launch_imu_residual_vectors(Engine* e, double* d_r15);
 int build_tile_order(Engine* e);
+int build_tile_desc(Engine* e);   // k_reduce.hip
 // the static lists built on the device (structure_dev.hip); same contents as structure.h's host builder
 int build_lists_device(Engine* e, const std::function<void(const char*)>& stage);
 // broadcast of `count` doubles from `root`, ordered into `s`: native RCCL enqueues without a host

@@ -369,6 +369,7 @@ int build_tile_order(Engine* e) {
   e->n_tile_order = (uint32_t)(8 * longest);
   int rc = upload(e, e->tile_order, order);
   if (rc) return rc;
+  if ((rc = build_tile_desc(e))) return rc;
   e->tile_order_version = e->nzL_version;
   return 0;
 }
@@ -479,7 +480,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
 #define REL(b) e->b.release()
   REL(cam); REL(cam_eval); REL(lm_zref); REL(crow); REL(border_blocks); REL(calib_partials); REL(pose_opt); REL(lm_opt); REL(pose_mask); REL(lm_ref_pose); REL(lm_ref_cam);
   REL(lm_ptr); REL(obs_z); REL(obs_pose); REL(obs_cam); REL(obs_lm); REL(obs_rid); REL(obs_w0); REL(obs_cond);
-  REL(wave_rng); REL(tile_order); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
+  REL(wave_rng); REL(tile_order); REL(tile_desc); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
   REL(imu_frozen); REL(imu_steps); REL(imu_cov_done); REL(pose_cam);
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
   REL(dist_tiles); REL(dist_usend); REL(dist_urecv); REL(dist_ssend); REL(dist_srecv); REL(dist_back);

@@ -29,28 +29,95 @@ namespace bae {
 // VAR 2: six threads per block, terms four at a time — the four (rowA, rowB) index pairs are loaded
 //        first, then the eight row pieces, so that a block's dependent-load chain is
 //        2 x ceil(terms / 4) memory latencies instead of 2 x terms
+// VAR 6 (round-3 experiment, ba_hip_debug_set key 1; VAR 5 is what runs): a test of the hypothesis that the kernel
+//        is bound by the LATENCY of its dependent loads (a tile lives ~20 us in a workgroup, at most 4.7 tiles fit
+//        a CU's LDS): half the threads (a tile has at most ~145 blocks), the launch entry carries the tile's list
+//        range and coordinates (tile_desc: one load instead of tile_order -> tile_ptr), a block's terms go four at
+//        a time with the index pairs of the NEXT four loaded beside the eight rows of the current four — four
+//        dependent round trips instead of eight.  Bitwise the S of VAR 5, and NOT faster: 6.81 against 6.66 ms at
+//        configs[3], 0.54 against 0.55 ms at configs[1] (profiles/r03_assemble_variants.log).  The kernel moves
+//        ~33 GB (PMC) at ~5 TB/s: it is bound by the 64-byte sectors its 48-byte row gathers drag in, not by the
+//        length of the dependency chain.
 template <int VAR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(VAR == 6 ? 128 : 256)
 k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_ptr,
                  const uint2* __restrict__ tile_ref, const uint2* __restrict__ pair_ent,
-                 const double* __restrict__ frow, uint32_t ld, double* __restrict__ A) {
+                 const double* __restrict__ frow, uint32_t ld, double* __restrict__ A,
+                 const uint4* __restrict__ tile_desc) {
   constexpr int TS = 66;  // LDS row stride (doubles): even, so that rows can be read 16 bytes at a time
+  constexpr int NT = VAR == 6 ? 128 : 256;
   __shared__ __attribute__((aligned(16))) double T[64 * TS];
   // launch order: see build_tile_order (engine.hip); padding entries are 0xffffffff
-  const uint32_t t = tile_order[blockIdx.x];
-  if (t == 0xffffffffu) return;
-  uint32_t tr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((uint64_t)(tr + 1) * (tr + 2) / 2 <= t) ++tr;
-  while ((uint64_t)tr * (tr + 1) / 2 > t) --tr;
-  const uint32_t tc = t - (uint32_t)((uint64_t)tr * (tr + 1) / 2);
+  uint32_t t, tr, tc, q0, q1;
+  if constexpr (VAR == 6) {
+    const uint4 d = tile_desc[blockIdx.x];
+    t = d.x;
+    if (t == 0xffffffffu) return;
+    q0 = d.y; q1 = d.z; tr = d.w >> 16; tc = d.w & 0xffffu;
+  } else {
+    t = tile_order[blockIdx.x];
+    if (t == 0xffffffffu) return;
+    tr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)(tr + 1) * (tr + 2) / 2 <= t) ++tr;
+    while ((uint64_t)tr * (tr + 1) / 2 > t) --tr;
+    tc = t - (uint32_t)((uint64_t)tr * (tr + 1) / 2);
+    q0 = tile_ptr[t]; q1 = tile_ptr[t + 1];
+  }
   if (tr >= nt) return;
   const int tid = threadIdx.x;
-  const uint32_t q0 = tile_ptr[t], q1 = tile_ptr[t + 1];
   if (q1 > q0) {
-    for (int i = tid; i < 64 * TS / 2; i += 256) reinterpret_cast<double2*>(T)[i] = make_double2(0.0, 0.0);
+    for (int i = tid; i < 64 * TS / 2; i += NT) reinterpret_cast<double2*>(T)[i] = make_double2(0.0, 0.0);
     __syncthreads();
     if constexpr (VAR == 3) {
       // experiment: no gather at all (floor of the write phase)
+    } else if constexpr (VAR == 6) {
+      for (uint32_t q = q0 + tid; q < q1; q += NT) {
+        const uint2 ref = tile_ref[q];
+        const uint32_t cnt = ref.y >> 14;
+        const int ro = (int)((ref.y >> 7) & 127u) - kRefBias, co = (int)(ref.y & 127u) - kRefBias;
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+        const uint32_t e1 = ref.x + cnt;
+        uint2 en[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = pair_ent[min(ref.x + (uint32_t)u, e1 - 1)];
+        for (uint32_t e = ref.x; e < e1; e += 4) {
+          double2 ra[4][3], rb[4][3];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double2* pa = reinterpret_cast<const double2*>(frow + (size_t)en[u].x * kRow);
+            const double2* pb = reinterpret_cast<const double2*>(frow + (size_t)en[u].y * kRow);
+            ra[u][0] = pa[0]; ra[u][1] = pa[1]; ra[u][2] = pa[2];
+            rb[u][0] = pb[0]; rb[u][1] = pb[1]; rb[u][2] = pb[2];
+          }
+          if (e + 4 < e1) {  // the next four index pairs travel beside these rows
+#pragma unroll
+            for (int u = 0; u < 4; ++u) en[u] = pair_ent[min(e + 4 + (uint32_t)u, e1 - 1)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (e + (uint32_t)u < e1) {
+              const double a[6] = {ra[u][0].x, ra[u][0].y, ra[u][1].x, ra[u][1].y, ra[u][2].x, ra[u][2].y};
+              const double b[6] = {rb[u][0].x, rb[u][0].y, rb[u][1].x, rb[u][1].y, rb[u][2].x, rb[u][2].y};
+#pragma unroll
+              for (int x = 0; x < 6; ++x)
+#pragma unroll
+                for (int y = 0; y < 6; ++y) acc[x * 6 + y] += a[x] * b[y];
+            }
+          }
+        }
+#pragma unroll
+        for (int y = 0; y < 6; ++y) {
+          const int rr = ro + y;
+          if (rr < 0 || rr >= 64) continue;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) {
+            const int cc = co + x;
+            if (cc >= 0 && cc < 64) T[rr * TS + cc] = acc[x * 6 + y];
+          }
+        }
+      }
     } else if constexpr (VAR == 0 || VAR == 4 || VAR == 5) {
       for (uint32_t q = q0 + tid; q < q1; q += 256) {
         const uint2 ref = tile_ref[q];
@@ -112,7 +179,7 @@ k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_order, const uin
       // work item = (block, x): the six threads of a block each form one row x of a (x) b — they read
       // the same rowB (one request) and consecutive doubles of rowA
       const uint32_t items = (q1 - q0) * 6;
-      for (uint32_t it = tid; it < items; it += 256) {
+      for (uint32_t it = tid; it < items; it += NT) {
         const uint32_t q = q0 + it / 6, x = it - (it / 6) * 6;
         const uint2 ref = tile_ref[q];
         const uint32_t cnt = ref.y >> 14;
@@ -190,7 +257,7 @@ k_assemble_tiles(uint32_t nt, const uint32_t* __restrict__ tile_order, const uin
   double* base = A + ((size_t)tr * 64) * ld + (size_t)tc * 64;
   const int c2 = tid & 31;
 #pragma unroll
-  for (int r = tid >> 5; r < 64; r += 8) {
+  for (int r = tid >> 5; r < 64; r += NT / 32) {
     const double2 v = q1 > q0 ? *reinterpret_cast<const double2*>(T + r * TS + 2 * c2) : make_double2(0.0, 0.0);
     if (VAR == 4 && r >= 8) break;  // experiment: gather only (the tile is NOT written in full: wrong results)
     // 14 GB of tiles nobody re-reads before the factorisation reaches them: streaming stores (-2 %)
@@ -238,6 +305,7 @@ k_pose_blocks(const uint32_t* __restrict__ pose_ptr, const uint32_t* __restrict_
       acc[42 + x] += a[x] * s2;
     }
   }
+  // (two terms per step with all index loads up front measured 3.55 against 3.41 ms at configs[3]: not kept)
 #pragma unroll
   for (int k = 0; k < 48; ++k) {
     double v = acc[k];
@@ -444,6 +512,29 @@ int launch_pack_lower(Engine* e, int unpack) {
   return 0;
 }
 
+// launch entry of the tile assembly: (tile id, first / end block reference, tile row << 16 | tile column)
+__global__ void k_tile_desc(uint32_t n, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_ptr,
+                            uint4* __restrict__ desc) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const uint32_t t = tile_order[b];
+  if (t == 0xffffffffu) { desc[b] = make_uint4(t, 0u, 0u, 0u); return; }
+  uint32_t tr = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((uint64_t)(tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  while ((uint64_t)tr * (tr + 1) / 2 > t) --tr;
+  const uint32_t tc = t - (uint32_t)((uint64_t)tr * (tr + 1) / 2);
+  desc[b] = make_uint4(t, tile_ptr[t], tile_ptr[t + 1], (tr << 16) | tc);
+}
+
+int build_tile_desc(Engine* e) {
+  BAE_HIP(e->tile_desc.alloc(std::max<uint32_t>(e->n_tile_order, 1)));
+  if (e->n_tile_order == 0) return 0;
+  hipLaunchKernelGGL(k_tile_desc, dim3((e->n_tile_order + 255) / 256), dim3(256), 0, e->stream, e->n_tile_order,
+                     (const uint32_t*)e->tile_order.p, (const uint32_t*)e->tile_ptr.p, e->tile_desc.p);
+  BAE_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_gather_S(Engine* e) {
   const Structure& st = e->st;
   const uint32_t n = st.n, ld = st.ld, n_pad = ld;
@@ -484,11 +575,11 @@ int launch_gather_S(Engine* e) {
   }
   e->prof_begin(e->ev_gather);
 #define BAE_ASM(V)                                                                                       \
-  hipLaunchKernelGGL(k_assemble_tiles<V>, dim3(e->n_tile_order), dim3(256), 0, e->stream, nt, e->tile_order.p, \
-                     e->tile_ptr.p, e->tile_ref.p, e->pair_ent.p, e->frow.p, ld, e->A.p)
+  hipLaunchKernelGGL(k_assemble_tiles<V>, dim3(e->n_tile_order), dim3(V == 6 ? 128 : 256), 0, e->stream, nt, e->tile_order.p, \
+                     e->tile_ptr.p, e->tile_ref.p, e->pair_ent.p, e->frow.p, ld, e->A.p, (const uint4*)e->tile_desc.p)
   switch (e->dbg_assemble_variant) {
     case 0: BAE_ASM(0); break; case 1: BAE_ASM(1); break; case 2: BAE_ASM(2); break;
-    case 3: BAE_ASM(3); break; case 4: BAE_ASM(4); break; default: BAE_ASM(5); break;
+    case 3: BAE_ASM(3); break; case 4: BAE_ASM(4); break; case 5: BAE_ASM(5); break; default: BAE_ASM(6); break;
   }
 #undef BAE_ASM
   e->prof_end(e->ev_gather);

@@ -12,6 +12,8 @@ po.build()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 worst = 0.0
+worst_c = 0.0
+n_bad = 0
 ONLY = set(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 and sys.argv[3] not in ("", "all") else None
 for trial in range(N):
     P = int(rng.integers(6, 60)); L = int(rng.integers(10, 200)); K = int(rng.integers(3, min(P - 1, 8)))
@@ -94,5 +96,15 @@ for trial in range(N):
     flag = "" if (ok and d < tol and dl < tol) else ("  (singular S: not comparable)" if cond > 1e14 else "  <-- CHECK")
     if cond <= 1e14:
         worst = max(worst, d, dl)
+    # the bound the parity claim rests on:  state difference <= max(1e-9, C * eps * cond),
+    # cond = max(cond(S), cond(V)), C = 4.5 (tol = 1e-15 cond); c_obs is the constant this trial needed
+    if np.isfinite(cond) and cond <= 1e16 and so.result == sh.result:
+        c_obs = max(d, dl) / (2.220446049250313e-16 * max(cond, cond_v))
+        worst_c = max(worst_c, c_obs)
+        if "CHECK" in flag:
+            n_bad += 1
     print("trial %2d P=%2d L=%3d K=%d lm=%d D=%2d dogleg=%d %s result=%d cond %.1e condV %.1e pose %.1e lm %.1e%s" % (trial, P, L, K, lm_dim, pose_dim, dog, "fov" if fov else "pin", so.result, cond, cond_v, d, dl, flag), flush=True)
 print("worst rel diff %.2e" % worst)
+print("conditioning bound: worst observed constant c = diff / (eps * cond) = %.3g (asserted: <= 4.5 wherever diff > 1e-9); trials outside the bound: %d" % (worst_c, n_bad))
+if n_bad:
+    sys.exit(1)
