@@ -1,6 +1,7 @@
 // Flat C wrapper (include/ba_capi.h) over the C++ host class ba::BundleAdjuster<>.
 #include "../../include/ba_capi.h"
 
+#include <cmath>
 #include <vector>
 
 #include "../../include/ba/BundleAdjuster.h"
@@ -82,7 +83,7 @@ struct Impl : Iface {
   uint32_t add_camera_fov(const double* p, const double* t) override {
     return ba.AddCamera(std::make_shared<ba::FovCamera<double>>(p[0], p[1], p[2], p[3], p[4], ba::SE3::from7(t)));
   }
-  double camera_fov(uint32_t cam) const override { return ba.rig()->cameras_[cam]->Param(4); }
+  double camera_fov(uint32_t cam) const override { return cam < ba.rig()->NumCams() ? ba.rig()->cameras_[cam]->Param(4) : std::nan(""); }
   void set_imu_noise(const double* r6, const double* rb6) override {
     auto calib = ba.GetImuCalibration();
     for (int i = 0; i < 6; ++i) { calib.r[i] = r6[i]; calib.r_b[i] = rb6[i]; }
@@ -189,8 +190,13 @@ struct Impl : Iface {
   void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) override {
     ba.SetAllReduce(fn, ctx, rank, nranks);
   }
-  void camera_pose(uint32_t cam, double* t7) const override { ba.rig()->cameras_[cam]->Pose().to7(t7); }
+  // (an out-of-range camera id writes NaN, not whatever lies behind the rig's vector)
+  void camera_pose(uint32_t cam, double* t7) const override {
+    if (cam >= ba.rig()->NumCams()) { for (int i = 0; i < 7; ++i) t7[i] = std::nan(""); return; }
+    ba.rig()->cameras_[cam]->Pose().to7(t7);
+  }
   void camera_params(uint32_t cam, double* p4) const override {
+    if (cam >= ba.rig()->NumCams()) { for (int i = 0; i < 4; ++i) p4[i] = std::nan(""); return; }
     const ba::Vector4t p = ba.rig()->cameras_[cam]->GetParams();
     for (int i = 0; i < 4; ++i) p4[i] = p[i];
   }

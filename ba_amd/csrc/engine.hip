@@ -544,8 +544,9 @@ int ba_hip_set_camera_models(ba_hip_engine* h, uint32_t n, const int32_t* model,
   e->finalized = false;
   return 0;
 }
-int ba_hip_get_camera_fov(ba_hip_engine* h, double* w) {
+int ba_hip_get_camera_fov(ba_hip_engine* h, uint32_t n, double* w) {
   ENG(h);
+  if (!w || n != e->prob.cam_w.size()) return e->fail_msg("ba_hip_get_camera_fov: camera count mismatch");
   for (size_t c = 0; c < e->prob.cam_w.size(); ++c) w[c] = e->prob.cam_w[c];
   return 0;
 }
@@ -1235,15 +1236,17 @@ int ba_hip_set_landmark_ref_pixels(ba_hip_engine* h, uint32_t n, const double* z
   e->finalized = false;
   return 0;
 }
-int ba_hip_get_camera_params(ba_hip_engine* h, double* params4) {
+int ba_hip_get_camera_params(ba_hip_engine* h, uint32_t n, double* params4) {
   ENG(h);
   const std::vector<double>& p = e->prob.cam_params;
+  if (!params4 || (size_t)n * 4 != p.size()) return e->fail_msg("ba_hip_get_camera_params: camera count mismatch");
   for (size_t i = 0; i < p.size(); ++i) params4[i] = p[i];
   return 0;
 }
-int ba_hip_get_cameras(ba_hip_engine* h, double* t_vs7) {
+int ba_hip_get_cameras(ba_hip_engine* h, uint32_t n, double* t_vs7) {
   ENG(h);
   const std::vector<double>& t = e->prob.cam_tvs;
+  if (!t_vs7 || (size_t)n * 7 != t.size()) return e->fail_msg("ba_hip_get_cameras: camera count mismatch");
   for (size_t i = 0; i < t.size(); ++i) t_vs7[i] = t[i];
   return 0;
 }

@@ -1108,7 +1108,8 @@ int factor_tile_pattern(Engine* e) {
 }
 
 uint32_t choose_kout(uint32_t nblk) {
-  static const uint32_t kout_env = getenv("BA_HIP_KOUT") ? (uint32_t)atoi(getenv("BA_HIP_KOUT")) : 0;
+  const char* ke = getenv("BA_HIP_KOUT");  // (read on every call: tests vary it inside one process)
+  const uint32_t kout_env = ke ? (uint32_t)atoi(ke) : 0;
   return kout_env ? kout_env : (nblk >= 400 ? 16u : nblk >= 256 ? 8u : 4u);  // measured at 94 / 282 / 469 / 938 tiles
 }
 

@@ -287,15 +287,53 @@ int bits_for(unsigned long long maxval) {
   while ((1ull << b) <= maxval) ++b;
   return b;
 }
-// last element of an exclusive scan + the last count = total
-int total_of(Engine* e, const uint32_t* off, const uint32_t* cnt, size_t n, uint32_t* out) {
+// temporary of build_lists_device: released on every exit path (early error returns included)
+template <typename T>
+struct TBuf : DBuf<T> {
+  TBuf() = default;
+  TBuf(const TBuf&) = delete;
+  TBuf& operator=(const TBuf&) = delete;
+  ~TBuf() { this->release(); }
+};
+
+// 64-bit sum of 32-bit counts (block partials, one 64-bit atomic per block)
+__global__ void __launch_bounds__(256) k_sum_counts64(const uint32_t* __restrict__ cnt, size_t n,
+                                                       unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[4];
+  unsigned long long s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += cnt[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// Total of a count array whose 32-bit exclusive scan is `off`.  The counts grow quadratically with the track
+// length, so the total is summed in 64 bits FIRST: a total of 2^32 or more wraps the scan silently, and then the
+// lists would be built truncated — that is an error here, before anything indexes with the wrapped offsets.
+int total_of(Engine* e, const uint32_t* off, const uint32_t* cnt, size_t n, uint32_t* out, const char* what) {
   *out = 0;
+  (void)off;
   if (n == 0) return 0;
-  uint32_t a = 0, b = 0;
-  BAE_HIP(hipMemcpyAsync(&a, off + n - 1, 4, hipMemcpyDeviceToHost, e->stream));
-  BAE_HIP(hipMemcpyAsync(&b, cnt + n - 1, 4, hipMemcpyDeviceToHost, e->stream));
-  BAE_HIP(hipStreamSynchronize(e->stream));
-  *out = a + b;
+  DBuf<unsigned long long> acc;
+  BAE_HIP(acc.alloc(1));
+  unsigned long long tot = 0;
+  hipError_t err = hipMemsetAsync(acc.p, 0, sizeof(unsigned long long), e->stream);
+  if (err == hipSuccess) {
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_sum_counts64, dim3(grid), dim3(256), 0, e->stream, cnt, n, acc.p);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipMemcpyAsync(&tot, acc.p, sizeof(tot), hipMemcpyDeviceToHost, e->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  acc.release();
+  if (err != hipSuccess) return e->fail(err, "total_of");
+  if (tot >= 0xFFFFFFFFull) {
+    e->err = std::string(what) + " exceeds 2^32 entries";
+    return -1;
+  }
+  *out = (uint32_t)tot;
   return 0;
 }
 
@@ -340,10 +378,10 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
   const size_t O1 = std::max<size_t>(O, 1), L1 = std::max<size_t>(L, 1);
 
   // ---- raw arrays to the device -----------------------------------------------------------------------
-  DBuf<double> r_z, r_w;
-  DBuf<uint32_t> r_pose, r_lm, r_cam, perm_in, key_tmp;
-  DBuf<uint8_t> r_cond;
-  DBuf<char> tmp;
+  TBuf<double> r_z, r_w;
+  TBuf<uint32_t> r_pose, r_lm, r_cam, perm_in, key_tmp;
+  TBuf<uint8_t> r_cond;
+  TBuf<char> tmp;
   int rc = 0;
 #define UPV(buf, vec) { BAE_HIP(buf.alloc(std::max<size_t>((vec).size(), 1))); \
     if (!(vec).empty()) BAE_HIP(hipMemcpyAsync(buf.p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, e->stream)); }
@@ -363,7 +401,7 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
   BAE_HIP(e->obs_z.alloc(2 * O1)); BAE_HIP(e->obs_w0.alloc(O1)); BAE_HIP(e->obs_w.alloc(O1));
   BAE_HIP(e->obs_pose.alloc(O1)); BAE_HIP(e->obs_cam.alloc(O1)); BAE_HIP(e->obs_lm.alloc(O1));
   BAE_HIP(e->obs_cond.alloc(O1));
-  DBuf<uint32_t> lm_cnt;
+  TBuf<uint32_t> lm_cnt;
   BAE_HIP(lm_cnt.alloc((size_t)L + 1));
   BAE_HIP(hipMemsetAsync(lm_cnt.p, 0, ((size_t)L + 1) * 4, e->stream));
   if (O) {
@@ -414,7 +452,7 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
   DevGraph g = {LM, D, O, L, R, WO, st.lrow_base, e->obs_pose.p, e->obs_lm.p, e->lm_ptr.p,
                 e->lm_ref_pose.p, e->pose_opt.p, e->lm_opt.p};
   // ---- incidences -----------------------------------------------------------------------------------------
-  DBuf<uint32_t> linc_cnt, linc_ptr, inc_pose, inc_wrow;
+  TBuf<uint32_t> linc_cnt, linc_ptr, inc_pose, inc_wrow;
   BAE_HIP(linc_cnt.alloc((size_t)L + 1)); BAE_HIP(linc_ptr.alloc((size_t)L + 1));
   BAE_HIP(hipMemsetAsync(linc_cnt.p, 0, ((size_t)L + 1) * 4, e->stream));
   if (L) hipLaunchKernelGGL(k_inc_count, GRID(L), g, linc_cnt.p);
@@ -425,7 +463,7 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
   if (L) hipLaunchKernelGGL(k_inc_fill, GRID(L), g, (const uint32_t*)linc_ptr.p, inc_pose.p, inc_wrow.p);
 
   // ---- rank-1 terms of the off-diagonal blocks -----------------------------------------------------------
-  DBuf<uint32_t> lrec_cnt, lrec_off, orec_cnt, orec_off, schur_cnt, schur_off, jt_cnt, jt_off;
+  TBuf<uint32_t> lrec_cnt, lrec_off, orec_cnt, orec_off, schur_cnt, schur_off, jt_cnt, jt_off;
   BAE_HIP(lrec_cnt.alloc(L1)); BAE_HIP(lrec_off.alloc(L1)); BAE_HIP(schur_cnt.alloc(L1)); BAE_HIP(schur_off.alloc(L1));
   BAE_HIP(orec_cnt.alloc(O1)); BAE_HIP(orec_off.alloc(O1)); BAE_HIP(jt_cnt.alloc(O1)); BAE_HIP(jt_off.alloc(O1));
   uint32_t n_lm_recs = 0, n_obs_recs = 0, n_schur = 0, n_jterms = 0;
@@ -434,15 +472,15 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
                        schur_cnt.p);
     if ((rc = scan_exclusive(e, tmp, (const uint32_t*)lrec_cnt.p, lrec_off.p, L))) return rc;
     if ((rc = scan_exclusive(e, tmp, (const uint32_t*)schur_cnt.p, schur_off.p, L))) return rc;
-    if ((rc = total_of(e, lrec_off.p, lrec_cnt.p, L, &n_lm_recs))) return rc;
-    if ((rc = total_of(e, schur_off.p, schur_cnt.p, L, &n_schur))) return rc;
+    if ((rc = total_of(e, lrec_off.p, lrec_cnt.p, L, &n_lm_recs, "gather list (landmark records)"))) return rc;
+    if ((rc = total_of(e, schur_off.p, schur_cnt.p, L, &n_schur, "per-pose term list (Schur terms)"))) return rc;
   }
   if (O) {
     hipLaunchKernelGGL(k_obs_counts, GRID(O), g, orec_cnt.p, jt_cnt.p);
     if ((rc = scan_exclusive(e, tmp, (const uint32_t*)orec_cnt.p, orec_off.p, O))) return rc;
     if ((rc = scan_exclusive(e, tmp, (const uint32_t*)jt_cnt.p, jt_off.p, O))) return rc;
-    if ((rc = total_of(e, orec_off.p, orec_cnt.p, O, &n_obs_recs))) return rc;
-    if ((rc = total_of(e, jt_off.p, jt_cnt.p, O, &n_jterms))) return rc;
+    if ((rc = total_of(e, orec_off.p, orec_cnt.p, O, &n_obs_recs, "gather list (observation records)"))) return rc;
+    if ((rc = total_of(e, jt_off.p, jt_cnt.p, O, &n_jterms, "per-pose term list (J terms)"))) return rc;
   }
   const uint64_t n_recs64 = (uint64_t)n_lm_recs + n_obs_recs;
   if (n_recs64 >= 0xFFFFFFFFull) return e->fail_msg("gather list exceeds 2^32 entries");
@@ -453,7 +491,7 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
   BAE_HIP(hipMemsetAsync(e->tile_ptr.p, 0, (tiles_lower + 1) * 4, e->stream));
   st.tile_nz.assign((size_t)nt * nt, 0);
   if (n_recs) {
-    DBuf<unsigned long long> k0, k1, v0;
+    TBuf<unsigned long long> k0, k1, v0;
     BAE_HIP(k0.alloc(n_recs)); BAE_HIP(k1.alloc(n_recs)); BAE_HIP(v0.alloc(n_recs));
     if (L) hipLaunchKernelGGL(k_lm_records, GRID(L), g, (const uint32_t*)linc_ptr.p, (const uint32_t*)inc_pose.p,
                               (const uint32_t*)inc_wrow.p, (const uint32_t*)lrec_off.p, k0.p, v0.p);
@@ -467,13 +505,13 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
     k0.release(); v0.release();
     if (stage) { BAE_HIP(hipStreamSynchronize(e->stream)); stage("pair terms sorted"); }
     // blocks, tile references
-    DBuf<uint32_t> flag, fidx, starts, cursor;
-    DBuf<int> ovf;
+    TBuf<uint32_t> flag, fidx, starts, cursor;
+    TBuf<int> ovf;
     BAE_HIP(flag.alloc(n_recs)); BAE_HIP(fidx.alloc(n_recs)); BAE_HIP(ovf.alloc(1));
     BAE_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int), e->stream));
     hipLaunchKernelGGL(k_block_flags, GRID(n_recs), n_recs, (const unsigned long long*)k1.p, flag.p);
     if ((rc = scan_exclusive(e, tmp, (const uint32_t*)flag.p, fidx.p, n_recs))) return rc;
-    if ((rc = total_of(e, fidx.p, flag.p, n_recs, &st.n_pairs))) return rc;
+    if ((rc = total_of(e, fidx.p, flag.p, n_recs, &st.n_pairs, "pose-pair block list"))) return rc;
     BAE_HIP(starts.alloc((size_t)st.n_pairs + 1));
     hipLaunchKernelGGL(k_block_starts, GRID(n_recs), n_recs, (const uint32_t*)flag.p, (const uint32_t*)fidx.p, starts.p,
                        st.n_pairs);
@@ -493,7 +531,7 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
     BAE_HIP(hipMemcpyAsync(cursor.p, e->tile_ptr.p, (tiles_lower + 1) * 4, hipMemcpyDeviceToDevice, e->stream));
     hipLaunchKernelGGL(k_tile_refs<1>, GRID(st.n_pairs), st.n_pairs, nt, (const uint32_t*)starts.p,
                        (const unsigned long long*)k1.p, cursor.p, e->tile_ref.p, ovf.p);
-    DBuf<uint8_t> nz;
+    TBuf<uint8_t> nz;
     BAE_HIP(nz.alloc((size_t)nt * nt));
     BAE_HIP(hipMemsetAsync(nz.p, 0, (size_t)nt * nt, e->stream));
     hipLaunchKernelGGL(k_tile_pattern, GRID(tiles_lower), nt, (const uint32_t*)e->tile_ptr.p, nz.p);
@@ -515,8 +553,8 @@ int build_lists_device(Engine* e, const std::function<void(const char*)>& stage)
   BAE_HIP(e->pose_ent.alloc(std::max<size_t>(3 * (size_t)n_pe, 1)));
   static_assert(sizeof(PoseEnt) == sizeof(U3), "per-pose term = three words");
   {
-    DBuf<uint32_t> pk0, pk1;
-    DBuf<PoseEnt> pe0;
+    TBuf<uint32_t> pk0, pk1;
+    TBuf<PoseEnt> pe0;
     BAE_HIP(pk0.alloc(std::max<size_t>(n_pe, 1))); BAE_HIP(pk1.alloc(std::max<size_t>(n_pe, 1)));
     BAE_HIP(pe0.alloc(std::max<size_t>(n_pe, 1)));
     if (O) hipLaunchKernelGGL(k_pose_jterms, GRID(O), g, (const uint32_t*)jt_off.p, pk0.p, pe0.p);

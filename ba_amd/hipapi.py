@@ -220,7 +220,7 @@ class Engine:
 
     def get_camera_fov(self, n):
         w = np.empty(n)
-        self._chk(self.L.ba_hip_get_camera_fov(self.h, _p(w, dp)))
+        self._chk(self.L.ba_hip_get_camera_fov(self.h, int(n), _p(w, dp)))
         return w
 
     def set_pose_cam_params(self, params):
@@ -342,12 +342,12 @@ class Engine:
 
     def get_camera_params(self, n):
         p = np.empty((n, 4))
-        self._chk(self.L.ba_hip_get_camera_params(self.h, _p(p, dp)))
+        self._chk(self.L.ba_hip_get_camera_params(self.h, int(n), _p(p, dp)))
         return p
 
     def get_cameras(self, n):
         t = np.empty((n, 7))
-        self._chk(self.L.ba_hip_get_cameras(self.h, _p(t, dp)))
+        self._chk(self.L.ba_hip_get_cameras(self.h, int(n), _p(t, dp)))
         return t
 
     def get_calib_jacobians(self, n):

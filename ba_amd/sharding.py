@@ -91,11 +91,17 @@ def torch_collectives_hook(dist, device="cuda"):
             if op == 1:
                 dist.broadcast(t, src=root)
             elif op == 3:   # send to `root`: must not block on the receiver
-                buf = t.clone()
+                # (gloo moves host memory: device buffers are staged through the host for it)
+                buf = t.cpu() if (device == "cuda" and dist.get_backend() == "gloo") else t.clone()
                 pending.append((dist.isend(buf, dst=root), buf))
                 return 0
             elif op == 4:   # receive from `root`
-                dist.recv(t, src=root)
+                if device == "cuda" and dist.get_backend() == "gloo":
+                    tmp = torch.empty(count, dtype=torch.float64)
+                    dist.recv(tmp, src=root)
+                    t.copy_(tmp)
+                else:
+                    dist.recv(t, src=root)
                 pending[:] = [(w, b) for (w, b) in pending if not w.is_completed()]
             elif op == 2:
                 if device == "cuda" and dist.get_backend() != "gloo":

@@ -363,9 +363,12 @@ def main():
             nsel = K + (1 if lm_dim == 1 else 0)
             lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
             h = build_adjuster(cfg, sc, lm_dim, lm_range=(lo, hi), pose_pose=(rank == 0), device=local_rank)
-            ids = [hipapi.Engine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            h.set_communicator(ids[0], rank, world, distributed_solve=not os.environ.get("BA_BENCH_REPLICATED_SOLVE"))
+            if comm_mode == "native":
+                ids = [hipapi.Engine.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                h.set_communicator(ids[0], rank, world, distributed_solve=not os.environ.get("BA_BENCH_REPLICATED_SOLVE"))
+            else:  # rehearsal on a box with fewer GPUs than ranks: the class's all-reduce hook (replicated solve)
+                h.set_allreduce(sharding.torch_allreduce_hook(dist, "cuda"), rank, world)
         else:
             h = build_adjuster(cfg, sc, lm_dim)
         log("graph built on the host")
@@ -432,7 +435,7 @@ def main():
         if args.live_pmc and world == 1 and not api_driver:
             # this process has released its engine; the passes are separate processes under rocprofv3
             import subprocess
-            live = os.path.join(ROOT, "gpurun_out", "r02_pmc_traffic_cfg%d.json" % args.config)
+            live = os.path.join(ROOT, "gpurun_out", "r03_pmc_traffic_cfg%d.json" % args.config)
             if os.path.exists(live):
                 os.remove(live)
             os.makedirs(os.path.dirname(live), exist_ok=True)
@@ -454,6 +457,13 @@ def main():
                 return pmc[name]
             hits = [k for k in pmc if k.startswith(name.rstrip(">"))]
             return pmc[hits[0]] if len(hits) == 1 else None
+
+        def pmc_iterations(tab):
+            # the PMC passes profile one iteration: launches of the linearisation kernel = iterations covered
+            for k, v in tab.items():
+                if k.startswith("bae::k_linearize"):
+                    return v.get("launches", 1)
+            return 1
 
         def pmc_bytes(name):
             e = pmc_entry(name)
@@ -534,6 +544,37 @@ def main():
                                            "achieved_GBs": b_imu / (us * 1e-6) / 1e9,
                                            "frac_of_8TBs": b_imu / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                            "pmc_traffic_bytes": pmc_bytes("bae::k_imu")}
+        # SURVEY.md §8d group figure for the Jacobian / Schur kernels (phases j_evaluation + robust_weights +
+        # jtj_schur of the last step): COMPULSORY bytes — every input read once, every output written once, no
+        # materialised Jacobians — over the time those phases took, against 8 TB/s; with and without the one
+        # write of the upper triangle of S (14.4 GB at configs[3], the dominant term).  pmc_bytes: what the
+        # group's kernels really moved (committed rocprofv3 --pmc summary), null if none.
+        Dp = cfg["D"]
+        b_lin = Ow * 32 + Lw * 36 + P * (56 + (72 if Dp == 15 else 0)) + Ow * 16
+        b_out_noS = 8.0 * n + Lw * 8 * (ell * ell + ell)
+        b_S = 8.0 * n * (n + 1) / 2
+        g_ms = sum(timers.get(k, 0.0) for k in ("j_evaluation", "robust_weights", "jtj_schur"))
+        g_pmc = None
+        if pmc:
+            # launches per iteration that belong to the group (k_residuals: the error pass of the median only — the
+            # two evaluation passes of an iteration are the EvaluateResiduals phase)
+            names = {"bae::k_linearize<%d, 2, false, true>" % lm_dim: 1, "bae::k_assemble_tiles<5>": 1, "bae::k_pose_blocks": 1,
+                     "bae::k_residuals": 1, "bae::k_write_diag": 1, "bae::k_select_hist": None}
+            tot = 0.0
+            for nm, per_it in names.items():
+                en = pmc_entry(nm)
+                if en:
+                    cnt = per_it if per_it is not None else en.get("launches", 1) / max(pmc_iterations(pmc), 1)
+                    tot += en["traffic_bytes_per_launch_corrected"] * cnt
+            g_pmc = tot if tot > 0 else None
+        out["hbm_group"] = {
+            "kernels": "j_evaluation + robust_weights + jtj_schur (k_residuals, k_select_*, k_linearize, k_assemble_tiles, k_pose_blocks, k_write_diag)",
+            "bytes_8d": b_lin + b_out_noS + b_S, "bytes_8d_without_S": b_lin + b_out_noS,
+            "ms": g_ms,
+            "frac_with_S": (b_lin + b_out_noS + b_S) / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if g_ms > 0 else None,
+            "frac_without_S": (b_lin + b_out_noS) / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if g_ms > 0 else None,
+            "pmc_bytes": g_pmc,
+            "pmc_frac": g_pmc / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if (g_pmc and g_ms > 0) else None}
         if api_ms is not None:
             # wall time of adjuster.Solve(1) on a warm object (graph unchanged since the last call)
             out["api_solve_ms"] = api_ms

@@ -1078,12 +1078,12 @@ void BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::Solve(
   if (DoTvs && rig_->NumCams() > 0) {
     // :72-83 moved the rig's camera 0 on every applied step (host-side copy in the engine: no transfer)
     std::vector<double> tv(7 * (size_t)rig_->NumCams());
-    if (Check(ba_hip_get_cameras(engine_, tv.data()), "ba_hip_get_cameras")) rig_->cameras_[0]->SetPose(SE3::from7(tv.data()));
+    if (Check(ba_hip_get_cameras(engine_, rig_->NumCams(), tv.data()), "ba_hip_get_cameras")) rig_->cameras_[0]->SetPose(SE3::from7(tv.data()));
   }
   if (kCamParamsInCalib && rig_->NumCams() > 0) {  // :46-53
     std::vector<double> cp(4 * (size_t)rig_->NumCams()), cw(rig_->NumCams());
-    if (Check(ba_hip_get_camera_params(engine_, cp.data()), "ba_hip_get_camera_params") &&
-        Check(ba_hip_get_camera_fov(engine_, cw.data()), "ba_hip_get_camera_fov"))
+    if (Check(ba_hip_get_camera_params(engine_, rig_->NumCams(), cp.data()), "ba_hip_get_camera_params") &&
+        Check(ba_hip_get_camera_fov(engine_, rig_->NumCams(), cw.data()), "ba_hip_get_camera_fov"))
       rig_->cameras_[0]->SetParams(std::vector<double>({cp[0], cp[1], cp[2], cp[3], cw[0]}));
   }
   last_step_stale_ = true;

@@ -123,8 +123,9 @@ int ba_hip_set_calibration(ba_hip_engine* e, int calib_size, int do_tvs);
 /* LandmarkT::z_ref (BundleAdjuster.h:476-483): the pixel of every landmark in its reference
  * camera, two doubles per landmark id.  Only the intrinsics calibration reads it. */
 int ba_hip_set_landmark_ref_pixels(ba_hip_engine* e, uint32_t n, const double* z_ref2);
-/* [fx, fy, u0, v0] of every camera as the engine currently holds them */
-int ba_hip_get_camera_params(ba_hip_engine* e, double* params4);
+/* [fx, fy, u0, v0] of every camera as the engine currently holds them; n = the camera count of
+ * ba_hip_set_cameras (a mismatch is an error, nothing is written) */
+int ba_hip_get_camera_params(ba_hip_engine* e, uint32_t n, double* params4);
 
 /* ---- problem upload (replaces the AoS graph of Types.h:41-321) -------------------- */
 /* calibu::Rig cameras: pinhole params [fx,fy,u0,v0] and T_vs (BundleAdjuster.h:259-263) */
@@ -134,8 +135,8 @@ int ba_hip_set_cameras(ba_hip_engine* e, uint32_t n, const double* params4, cons
  * (pix = K (f(r) p), p = P.xy / P.z, f(r) = atan(2 r tan(w/2)) / (r w) — Devernay & Faugeras 2001; Calibu is
  * not in the reference tree, see oracle/outils.h).  w is read for model 1 only. */
 int ba_hip_set_camera_models(ba_hip_engine* e, uint32_t n, const int32_t* model, const double* w);
-/* w of every camera (0 for a LinearCamera) as the engine currently holds it */
-int ba_hip_get_camera_fov(ba_hip_engine* e, double* w);
+/* w of every camera (0 for a LinearCamera) as the engine currently holds it; n as above */
+int ba_hip_get_camera_fov(ba_hip_engine* e, uint32_t n, double* w);
 /* Options::use_per_pose_cam_params (BundleAdjuster.h:96; parallel_algos.h:54-57,
  * BundleAdjuster.cpp:162-176): every projection residual is evaluated with the pinhole
  * intrinsics [fx,fy,u0,v0] of its MEASUREMENT pose (PoseT::cam_params, Types.h:46) instead of the
@@ -268,7 +269,7 @@ uint32_t ba_hip_num_calib_params(const ba_hip_engine* e);  /* 0, or 6 with ba_hi
 int ba_hip_get_calibration_marginals(ba_hip_engine* e, double* cov_kxk);
 /* T_vs of every camera (7 doubles each) as the engine currently holds them: the values of
  * ba_hip_set_cameras, moved by the calibration steps applied since. */
-int ba_hip_get_cameras(ba_hip_engine* e, double* t_vs7);
+int ba_hip_get_cameras(ba_hip_engine* e, uint32_t n, double* t_vs7);  /* n = camera count, checked */
 uint32_t ba_hip_num_lm_params(const ba_hip_engine* e);
 /* s_ as the reference leaves it (BundleAdjuster.cpp:473-477,587-598): dense n x n
  * row-major (n = pose + calibration unknowns); block (i,j) kept only for i <= j when

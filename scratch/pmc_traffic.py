@@ -1,5 +1,5 @@
 """Per-kernel HBM-side traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one
-bench.py iteration; writes gpurun_out/r02_pmc_traffic_cfg<N>.json (copy it to profiles/).
+bench.py iteration; writes gpurun_out/r03_pmc_traffic_cfg<N>.json (copy it to profiles/).
 
 Run on the GPU box (one pass per counter: the TCC block cannot hold both, MI355X_MICROARCH.md):
     python scratch/pmc_traffic.py <config>
@@ -61,7 +61,7 @@ res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separat
                   "python3 bench.py --no-cpu-baseline --no-api --steps 1 --warmup 0 --config %d" % cfg,
        "corrections": "KB -> bytes; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)",
        "kernels": dict(sorted(out.items()))}
-path = os.path.join(root, "gpurun_out", "r02_pmc_traffic_cfg%d.json" % cfg)
+path = os.path.join(root, "gpurun_out", "r03_pmc_traffic_cfg%d.json" % cfg)
 json.dump(res, open(path, "w"), indent=1)
 print("wrote", path)
 for k in sorted(out, key=lambda k: -out[k]["traffic_bytes_per_launch_corrected"] * out[k]["launches"])[:8]:

@@ -9,7 +9,7 @@ import pytest
 
 from helpers import gn_options, rel_err
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1_*.npz")))
 
 
 def load_into(ba, g):

@@ -16,7 +16,7 @@ from helpers import accepted_obs, fill, gn_options, rel_err
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1_*.npz")))
 
 
 def hip_options(**kw):
@@ -608,9 +608,10 @@ def test_two_shards_equal_one(oracle_lib, lm_dim):
     assert rel_err(lms, single.get_landmarks(L)) < 1e-9
 
 
-@pytest.mark.parametrize("nranks,layout", [(2, "auto"), (3, "auto"), (4, "auto"), (8, "auto"), (8, "row"), (4, "tri_refused")],
-                         ids=["2_tri", "3_col", "4_grid", "8_tri", "8_row", "4_tri_refused"])
-def test_distributed_solve_matches_single(oracle_lib, monkeypatch, nranks, layout):
+@pytest.mark.parametrize("nranks,layout,kout", [(2, "auto", 4), (3, "auto", 4), (4, "auto", 4), (8, "auto", 4), (8, "row", 4),
+                                               (8, "auto", 3), (4, "auto", 5), (4, "tri_refused", 4)],
+                         ids=["2_tri", "3_col", "4_grid", "8_tri", "8_row", "8_tri_odd_blocks", "4_grid_ragged", "4_tri_refused"])
+def test_distributed_solve_matches_single(oracle_lib, monkeypatch, nranks, layout, kout):
     """Distributed reduced solve (ba_hip_set_collectives; ba_amd/csrc/dist_plan.h): 300 poses -> 28 tiles
     = 7 x 7 blocks of 4 x 4 tiles owned by 2 / 3 / 4 / 8 engines (thread-emulated ranks on one GPU) that
     hold a landmark shard each; reduce-scatter of S onto the block owners, per-panel square broadcast,
@@ -629,6 +630,9 @@ def test_distributed_solve_matches_single(oracle_lib, monkeypatch, nranks, layou
         return
     if layout != "auto":
         monkeypatch.setenv("BA_HIP_DIST_LAYOUT", layout)
+    # blocks of 4 tiles (the engine's choice at this size: 7 x 7 blocks), 3 (odd: no 128-blocks, 10 block rows,
+    # the last one ragged) or 5 (6 block rows, the last one of 3 tiles)
+    monkeypatch.setenv("BA_HIP_KOUT", str(kout))
     lm_dim = 1
     sc = scene.make_scene(300, 3000, 6, lm_dim=lm_dim, seed=67)
     pa = np.ones(sc.num_poses, dtype=np.uint8)
@@ -691,7 +695,7 @@ def test_distributed_solve_matches_single(oracle_lib, monkeypatch, nranks, layou
         _check_against_oracle(ref, out, r, engs[r].get_poses(sc.num_poses)[0])
     # byte accounting: what the ranks received, summed, is what the plan says for this pattern
     nzL = single.factor_tile_pattern()
-    plan = hipapi.dist_plan_stats(nzL.shape[0], nzL, nranks, layout)
+    plan = hipapi.dist_plan_stats(nzL.shape[0], nzL, nranks, layout, kout)
     cs = [engs[r].comm_stats() for r in range(nranks)]
     assert all(c["factorisations"] == iters for c in cs)
     chain_recv = sum(c["chain_bytes_recv"] for c in cs)
@@ -1631,6 +1635,56 @@ def test_native_rccl_communicator_single_rank(oracle_lib, keep_s):
     for e_ in (plain, native):
         e_.end_solve()
         e_.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("distributed", [1, 0], ids=["distributed_solve", "replicated_solve"])
+def test_class_level_native_communicator_single_rank(oracle_lib, distributed):
+    """ba::BundleAdjuster::SetCommunicator (round 3): the C++ class joins the engine-owned RCCL communicator by
+    itself — no hook, no poking the engine — and switches between the distributed and the replicated reduced
+    solve.  One rank (all this box has): every collective and both communicators run through RCCL; three
+    Solve(1) calls must agree with a plain adjuster and with the oracle (visual + unary priors, 300 poses)."""
+    po = oracle_lib
+    lm_dim = 1
+    sc = scene.make_scene(300, 3000, 6, lm_dim=lm_dim, seed=67)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+
+    def make(cls, opts):
+        b = cls(lm_dim, 6)
+        b.Init(opts)
+        fill(b, sc, active=pa)
+        for i in range(0, sc.num_poses, 25):
+            b.AddUnaryConstraint(i, sc.gt_poses[i], np.diag([1e-2] * 3 + [1e-3] * 3), True)
+        return b
+
+    o = make(po.OracleBundleAdjuster, gn_options(po))
+    plain = make(adjuster.BundleAdjuster, hip_options(write_reduced_camera_matrix=0))
+    native = make(adjuster.BundleAdjuster, hip_options(write_reduced_camera_matrix=0))
+    native.set_communicator(hipapi.Engine.comm_unique_id(), 0, 1, distributed_solve=bool(distributed))
+    for it in range(3):
+        o.Solve(1); plain.Solve(1); native.Solve(1)
+        so, sp, sn = o.summary(), plain.summary(), native.summary()
+        assert so.result == sp.result == sn.result
+        assert native.solve_is_distributed() == bool(distributed) and not plain.solve_is_distributed()
+        for a, b in ((sn.proj_error, sp.proj_error), (sn.unary_error, sp.unary_error), (sn.delta_norm, sp.delta_norm)):
+            assert abs(a - b) <= 1e-9 * max(abs(b), 1e-12)
+        assert abs(sn.proj_error - so.proj_error) <= 1e-8 * so.proj_error
+        if it == 0:
+            assert rel_err(native.delta_p(), o.delta_p()) < 1e-8      # north_star: 1e-6 on delta_x
+    assert rel_err(native.poses()[0], plain.poses()[0]) < 1e-9
+    assert rel_err(native.poses()[0], o.poses()[0]) < 1e-8
+    assert rel_err(native.landmarks(), o.landmarks()) < 1e-8
+    cs = native.engine().comm_stats()
+    assert cs["allreduce_bytes"] > 0
+    if distributed:
+        assert cs["factorisations"] == 3 and cs["chain_messages"] > 0 and cs["side_messages"] > 0
+    else:
+        assert cs["factorisations"] == 0
+    native.set_communicator(None, 0, 1)   # ClearCommunicator: back to a plain single engine
+    native.Solve(1); plain.Solve(1)
+    assert not native.solve_is_distributed()
+    assert rel_err(native.poses()[0], plain.poses()[0]) < 1e-9
 
 
 @pytest.mark.gpu
