@@ -495,9 +495,12 @@ def main():
                        "poses": P, "landmarks": L, "residuals": O, "reduced_system_n": n,
                        "driver": ("ba::BundleAdjuster::Solve(1) per step on a warm object (C++ API path, include/ba_capi.h)"
                                   if api_driver else "phase calls of the C-ABI (include/ba_hip.h)"),
-                       "parallelism": ("landmark-sharded x%d, reduce-scatter of S to panel owners, distributed LDL^T "
-                                       "(panel broadcast); collectives: %s" % (world, "engine-owned RCCL communicator"
-                                                                               if comm_mode == "native" else "torch.distributed hooks (%s)" % backend))
+                       "parallelism": ("landmark-sharded x%d (all poses on every rank%s), %s; collectives: %s"
+                                       % (world, ", pose-pose residuals on rank 0" if api_driver else "",
+                                          "replicated LDL^T (all-reduce of S)" if (os.environ.get("BA_BENCH_REPLICATED_SOLVE") or (api_driver and comm_mode != "native"))
+                                          else "reduce-scatter of S onto tile-block owners, distributed LDL^T (square broadcast + point-to-point block rows, DESIGN.md 6a)",
+                                          "engine-owned RCCL communicator" + (" (ba::BundleAdjuster::SetCommunicator)" if api_driver else "")
+                                          if comm_mode == "native" else "torch.distributed hooks (%s)" % backend))
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": "%s (dense LDL^T trailing update, v_mfma_f64_16x16x4_f64; the look-ahead's bulk launches)" % bulk_kernel,
                          "achieved": syrk_tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",

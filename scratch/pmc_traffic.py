@@ -30,14 +30,24 @@ out = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join("/tmp", "pmc_%s_cfg%d" % (ctr, cfg))  # raw pass output: large, not worth copying back
     shutil.rmtree(d, ignore_errors=True)
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--",
+    # PMC_KERNEL_REGEX: instrument only the matching kernels (configs[4]: a full pass over the 2344-tile
+    # factorisation's ~10^5 launches does not finish in 18 minutes; the HBM-bound kernels are what is wanted)
+    flt = ["--kernel-include-regex", os.environ["PMC_KERNEL_REGEX"]] if os.environ.get("PMC_KERNEL_REGEX") else []
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr] + flt + ["-d", d, "-o", "p", "--",
            "python3", os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-api", "--steps", "1", "--warmup", "0",
            "--config", str(cfg)]
     env = dict(os.environ, TMPDIR="/tmp")
     print("pass", ctr, flush=True)
-    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
-    if r.returncode != 0:
-        print(r.stdout[-2000:], r.stderr[-2000:]); sys.exit(1)
+    # (a pass of the large configs runs for minutes without output: print a heartbeat, the GPU box kills silent runs)
+    import time
+    with open(os.path.join("/tmp", "pmc_%s_cfg%d.out" % (ctr, cfg)), "w") as fo:
+        pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=fo, stderr=subprocess.STDOUT)
+        t0 = time.time()
+        while pr.poll() is None:
+            time.sleep(30)
+            print("  ... %s pass running, %d s" % (ctr, time.time() - t0), flush=True)
+    if pr.returncode != 0:
+        print(open(fo.name).read()[-3000:]); sys.exit(1)
     db = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)[0]
     c = sqlite3.connect(db)
     tabs = [x[0] for x in c.execute("select name from sqlite_master where type='table'")]
