@@ -1451,7 +1451,9 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     BAE_HIP(hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, lo));
     BAE_HIP(hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, hi));
   }
-  hipStream_t s0 = e->stream, s1 = e->stream2, s2 = e->stream3, s3 = e->stream4;
+  // (a native communicator without its duplicate — librccl lacks ncclCommSplit, or BA_HIP_ONE_COMM — carries the
+  // side transfers too: they are then ordered into the chain stream, one communicator is never used on two streams)
+  hipStream_t s0 = e->stream, s1 = e->stream2, s2 = e->stream3, s3 = (e->comm && !e->comm2) ? e->stream : e->stream4;
   // staging buffers: the square message; urgent / side messages of the busiest panel
   const size_t wmax = (size_t)KOUT * NB;
   BAE_HIP(e->dist_msg.alloc(dist_square_doubles(KOUT)));

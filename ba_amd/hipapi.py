@@ -11,6 +11,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libba_hip.so")
+if os.environ.get("BA_AMD_LIB"):   # A/B measurements of library builds (scratch/): another libba_hip.so
+    LIB_PATH = os.path.abspath(os.environ["BA_AMD_LIB"])
 
 dp = C.POINTER(C.c_double)
 u32p = C.POINTER(C.c_uint32)

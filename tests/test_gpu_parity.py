@@ -1469,6 +1469,82 @@ def test_config3_full_size_properties():
 
 
 @pytest.mark.gpu
+def test_config3_full_size_distributed_solve_on_two_emulated_ranks():
+    """The distributed reduced solve at the size bench.py runs it (configs[3]: 938 tiles, blocks of 16 tiles, 59
+    panels, k_update128 with the ownership map, 0.5 GB messages): two engines on the one GPU hold half of the
+    landmarks each (threads + in-process hooks) and factorise n = 59 988 together; ONE engine on the whole scene is
+    the reference (it is itself gated against the oracle at every size the oracle can follow).  The Gauss-Newton
+    step must be bitwise equal on both ranks, agree with the single engine to 1e-9, and the bytes moved must be
+    the bytes ba_hip_dist_plan_stats predicts for this pattern (the committed fixture of tests/test_dist_plan.py)."""
+    import threading
+
+    from ba_amd import sharding
+    P, L, K = 10000, 1000000, 10
+    sc, single = _bench_scene_engine(P, L, K)
+    single.linearize()
+    assert single.solve_gn() == 0
+    d_single, _ = single.get_delta_gn()
+    nzL = single.factor_tile_pattern()
+    single.end_solve()
+    single.close()
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    keep[::K + 1] = False
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    shards = sharding.landmark_shards(np.full(L, K), 2)
+
+    def make(lo, hi):
+        sel = keep & (sc.obs_lm >= lo) & (sc.obs_lm < hi)
+        eng = hipapi.Engine(1, 6)
+        eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+        eng.set_poses(sc.poses, is_active=pa)
+        eng.set_landmarks(sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi])
+        eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], sc.obs_lm[sel] - lo)
+        eng.finalize()
+        eng.begin_solve()
+        eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+        return eng
+
+    engs = [make(*shards[r]) for r in range(2)]
+    ar = sharding.ThreadAllReduce(2)
+    for r in range(2):
+        engs[r].set_allreduce(ar.hook(r), r, 2)
+        engs[r].set_collectives(ar.collectives(r))
+        assert engs[r].solve_is_distributed()
+    out = {}
+
+    def run(r):
+        try:
+            engs[r].linearize()
+            rc = engs[r].solve_gn()
+            out[r] = (rc, engs[r].get_delta_gn()[0])
+        except Exception as exc:  # surfaced below
+            out[r] = exc
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not ar.failed
+    for r in range(2):
+        assert not isinstance(out[r], Exception), out[r]
+        assert out[r][0] == 0
+    assert np.array_equal(out[0][1], out[1][1])
+    assert rel_err(out[0][1], d_single) < 1e-9
+    plan = hipapi.dist_plan_stats(nzL.shape[0], nzL, 2, "auto")
+    cs = [engs[r].comm_stats() for r in range(2)]
+    assert sum(c["chain_bytes_recv"] for c in cs) == pytest.approx(plan["chain_recv_total"], rel=1e-12)
+    assert sum(c["side_bytes_recv"] for c in cs) == pytest.approx(plan["side_recv_total"], rel=1e-12)
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config3_factor_tile_pattern.npz")
+    d = np.load(golden)
+    assert np.array_equal(np.unpackbits(d["bits"])[:nzL.size].reshape(nzL.shape), nzL)   # the fixture IS this pattern
+    for e_ in engs:
+        e_.end_solve()
+        e_.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["tvs", "intrinsics"])
 def test_config3_full_size_with_calibration_unknowns(kind):
     """The configs[3] scene (10k poses / 1M landmarks / 10M residuals) with the self-calibration
@@ -1574,13 +1650,16 @@ def test_config4_full_size_all_residual_kinds(oracle_lib):
 
 # ---- multi-rank paths: native RCCL, class-level sharding ------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("keep_s", [0, 1], ids=["distributed_solve", "replicated_solve"])
-def test_native_rccl_communicator_single_rank(oracle_lib, keep_s):
+@pytest.mark.parametrize("keep_s,one_comm", [(0, 0), (1, 0), (0, 1)],
+                         ids=["distributed_solve", "replicated_solve", "distributed_one_communicator"])
+def test_native_rccl_communicator_single_rank(oracle_lib, monkeypatch, keep_s, one_comm):
     """ba_hip_comm_init: the engine loads librccl itself and runs the cross-shard sums and the
     collectives of the distributed reduced solve on its own ncclComm.  One rank (all this box has):
     the sharded code paths are forced on, every all-reduce / reduce-scatter / broadcast goes through
     RCCL, and the results must equal the plain single engine and the oracle."""
     lm_dim = 1
+    if one_comm:   # no ncclCommSplit duplicate: the side transfers are ordered into the chain stream
+        monkeypatch.setenv("BA_HIP_ONE_COMM", "1")
     sc = scene.make_scene(300, 3000, 6, lm_dim=lm_dim, seed=67)
     pa = np.ones(sc.num_poses, dtype=np.uint8)
     pa[sc.anchor_poses] = 0

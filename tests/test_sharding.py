@@ -56,8 +56,16 @@ def _worker(rank, world, port, out):
     chunks = np.arange(8, dtype=np.float64) + 100.0 * rank      # 2 chunks of 4
     rc4 = coll(2, chunks.ctypes.data_as(ctypes.c_void_p).value, 4, 0)
     mine = chunks[4 * rank:4 * rank + 4]
+    # the point-to-point block rows (ops 3 / 4): both ranks send first (a send never blocks on the receiver),
+    # then receive — the order the engine uses inside one exchange group
+    p2p_out = np.full(6, 1000.0 + rank)
+    p2p_in = np.zeros(6)
+    rc5 = coll(3, p2p_out.ctypes.data_as(ctypes.c_void_p).value, p2p_out.size, 1 - rank)
+    p2p_out[:] = -1.0     # the hook copied the message: the caller may reuse its staging buffer
+    rc6 = coll(4, p2p_in.ctypes.data_as(ctypes.c_void_p).value, p2p_in.size, 1 - rank)
     if rank == 0:
-        np.save(out, np.concatenate([[rc1, rc2], s_part, hist.astype(np.float64), cnt, [rc3, rc4], msg, mine]))
+        np.save(out, np.concatenate([[rc1, rc2], s_part, hist.astype(np.float64), cnt, [rc3, rc4], msg, mine,
+                                     [rc5, rc6], p2p_in]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,3 +82,5 @@ def test_gloo_allreduce_hook_world_size_2(tmp_path):
     assert r[18] == 0 and r[19] == 0
     assert np.array_equal(r[20:25], np.full(5, 11.0))       # broadcast from rank 1
     assert np.array_equal(r[25:29], 2 * np.arange(4) + 100.0)  # rank 0's chunk, summed over ranks
+    assert r[29] == 0 and r[30] == 0
+    assert np.array_equal(r[31:37], np.full(6, 1001.0))     # rank 1's message, as it was when it was sent
