@@ -65,7 +65,7 @@ SYMBOLS = [
     "ba_adjuster_is_landmark_reliable", "ba_adjuster_landmark_outlier_ratio",
     "ba_adjuster_get_projection_residual", "ba_adjuster_get_imu_residual",
     "ba_adjuster_get_summary", "ba_adjuster_get_cond_errors", "ba_adjuster_get_timers", "ba_adjuster_engine",
-    "ba_adjuster_set_allreduce", "ba_adjuster_set_communicator", "ba_adjuster_solve_is_distributed", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
+    "ba_adjuster_set_allreduce", "ba_adjuster_set_communicator", "ba_adjuster_solve_is_distributed", "ba_adjuster_set_collectives", "ba_adjuster_create_calib", "ba_adjuster_get_camera_pose",
     "ba_adjuster_get_last_calib_step", "ba_adjuster_get_calibration_marginals", "ba_adjuster_get_camera_params",
     "ba_adjuster_add_camera_fov", "ba_adjuster_get_camera_fov",
 ]
@@ -403,3 +403,12 @@ class BundleAdjuster:
 
     def solve_is_distributed(self):
         return bool(self.L.ba_adjuster_solve_is_distributed(self.h))
+
+    def set_collectives(self, fn):
+        """ba::BundleAdjuster::SetCollectives: fn(op, dev_ptr, count, root) -> int, on top of set_allreduce."""
+        if fn is None:
+            self._cb2 = None
+            self.L.ba_adjuster_set_collectives(self.h, None, None)
+            return
+        self._cb2 = hipapi.COLLECTIVE_FN(lambda ctx, op, ptr, count, root: int(fn(op, ptr, count, root)))
+        self.L.ba_adjuster_set_collectives(self.h, self._cb2, None)

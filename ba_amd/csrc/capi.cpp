@@ -42,6 +42,7 @@ struct Iface {
   virtual ba_hip_engine* engine() = 0;
   virtual void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) = 0;
   virtual void set_communicator(const void* id128, int rank, int nranks, int distributed) = 0;
+  virtual void set_collectives(ba_hip_collective_fn fn, void* ctx) = 0;
   virtual int solve_is_distributed() = 0;
   virtual void camera_pose(uint32_t cam, double* t7) const = 0;
   virtual void camera_params(uint32_t cam, double* p4) const = 0;
@@ -187,6 +188,7 @@ struct Impl : Iface {
     else ba.ClearCommunicator();
   }
   int solve_is_distributed() override { return ba.SolveIsDistributed() ? 1 : 0; }
+  void set_collectives(ba_hip_collective_fn fn, void* ctx) override { ba.SetCollectives(fn, ctx); }
   void set_allreduce(ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) override {
     ba.SetAllReduce(fn, ctx, rank, nranks);
   }
@@ -337,5 +339,6 @@ uint32_t ba_adjuster_get_calibration_marginals(const ba_adjuster* a, double cov[
 void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx, int rank, int nranks) { a->p->set_allreduce(fn, ctx, rank, nranks); }
 void ba_adjuster_set_communicator(ba_adjuster* a, const void* id128, int rank, int nranks, int distributed_solve) { a->p->set_communicator(id128, rank, nranks, distributed_solve); }
 int ba_adjuster_solve_is_distributed(ba_adjuster* a) { return a->p->solve_is_distributed(); }
+void ba_adjuster_set_collectives(ba_adjuster* a, ba_hip_collective_fn fn, void* ctx) { a->p->set_collectives(fn, ctx); }
 
 }  // extern "C"

@@ -461,6 +461,10 @@ class BundleAdjuster {
     allreduce_ = fn; allreduce_ctx_ = ctx; rank_ = rank; nranks_ = nranks;
     mask_counts_dirty_ = true;
   }
+  // ... and, on top of SetAllReduce, the collectives hook (broadcast / reduce-scatter / send / receive,
+  // include/ba_hip.h: ba_hip_set_collectives): the reduced solve is then distributed instead of replicated.
+  // For foreign communicators and the thread-emulated tests; with SetCommunicator neither hook is needed.
+  void SetCollectives(ba_hip_collective_fn fn, void* ctx) { collectives_ = fn; collectives_ctx_ = ctx; collectives_dirty_ = true; }
   // multi-GPU without hooks: the engine's own RCCL communicator over xGMI (include/ba_hip.h: ba_hip_comm_*).
   // One process per GPU; rank 0 creates the 128-byte id with CreateCommunicatorId and hands it to the other
   // ranks out of band (a file, MPI, a socket); every rank then calls SetCommunicator before Solve().  The
@@ -576,6 +580,9 @@ class BundleAdjuster {
   ba_hip_allreduce_fn engine_allreduce_ = nullptr;  // what the engine currently has installed
   void* engine_allreduce_ctx_ = nullptr;
   bool engine_per_pose_cam_ = false;
+  ba_hip_collective_fn collectives_ = nullptr;   // SetCollectives
+  void* collectives_ctx_ = nullptr;
+  bool collectives_dirty_ = false;
   unsigned char comm_id_[128] = {};     // SetCommunicator: the RCCL unique id
   bool comm_set_ = false, comm_dirty_ = false, comm_dist_ = true;
 };
@@ -609,6 +616,7 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
     engine_device_ = options_.device;
     structure_dirty_ = true;
     if (comm_set_) comm_dirty_ = true;  // a new engine joins the communicator again
+    collectives_dirty_ = true;
   }
   ba_hip_options o;
   std::memset(&o, 0, sizeof(o));
@@ -629,9 +637,16 @@ bool BundleAdjuster<Scalar, LmSize, PoseSize, CalibSize, DoTvs>::SyncEngine() {
       comm_dirty_ = false;
       engine_allreduce_ = nullptr; engine_allreduce_ctx_ = nullptr;
     }
-  } else if (structure_dirty_ || allreduce_ != engine_allreduce_ || allreduce_ctx_ != engine_allreduce_ctx_) {
-    ba_hip_set_allreduce(engine_, allreduce_, allreduce_ctx_, rank_, nranks_);
-    engine_allreduce_ = allreduce_; engine_allreduce_ctx_ = allreduce_ctx_;
+  } else {
+    if (structure_dirty_ || allreduce_ != engine_allreduce_ || allreduce_ctx_ != engine_allreduce_ctx_) {
+      ba_hip_set_allreduce(engine_, allreduce_, allreduce_ctx_, rank_, nranks_);
+      engine_allreduce_ = allreduce_; engine_allreduce_ctx_ = allreduce_ctx_;
+      collectives_dirty_ = true;
+    }
+    if (collectives_dirty_) {
+      ba_hip_set_collectives(engine_, collectives_, collectives_ctx_);
+      collectives_dirty_ = false;
+    }
   }
   if (structure_dirty_) {
     EnsureHostState();  // the graph is re-marshalled from poses_ / landmarks_: they must be current

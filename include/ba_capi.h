@@ -125,6 +125,8 @@ void ba_adjuster_set_allreduce(ba_adjuster* a, ba_hip_allreduce_fn fn, void* ctx
  * the next Solve() joins it (collective).  distributed_solve 1 = distributed reduced solve, 0 = replicated. */
 void ba_adjuster_set_communicator(ba_adjuster* a, const void* id128, int rank, int nranks, int distributed_solve);
 int ba_adjuster_solve_is_distributed(ba_adjuster* a);
+/* ba::BundleAdjuster::SetCollectives: the collectives hook on top of the all-reduce hook (distributed reduced solve) */
+void ba_adjuster_set_collectives(ba_adjuster* a, ba_hip_collective_fn fn, void* ctx);
 
 #ifdef __cplusplus
 }

@@ -1338,6 +1338,96 @@ def test_landmarks_only_solve_with_all_poses_fixed(oracle_lib, lm_dim, use_dogle
 
 
 # ---- BASELINE.json configs at full size / all residual kinds ------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_config4_miniature_on_landmark_shards_with_distributed_solve(oracle_lib, monkeypatch, nranks):
+    """The 8-GPU form of BASELINE.json configs[4], in miniature and on emulated ranks: reprojection residuals
+    sharded by landmark, IMU + unary priors + binary odometry on rank 0 only, PoseSize 15, dogleg trust region,
+    gauge masks from GLOBAL counts, and the reduced solve DISTRIBUTED over the ranks (SetAllReduce +
+    SetCollectives: what bench.py --gpus N --config 4 does through SetCommunicator).  n = 80 x 15 = 1200 -> 19 tiles,
+    blocks of 2 tiles.  Three Solve(1) calls per rank against the oracle on the whole scene: result codes, every
+    error sum, the trust region, the state; the ranks agree bit for bit on the poses."""
+    import threading
+    import types
+
+    from ba_amd import sharding
+    po = oracle_lib
+    monkeypatch.setenv("BA_HIP_KOUT", "2")
+    lm_dim, P = 1, 80
+    sc = scene.make_scene(P, 400, 6, lm_dim=lm_dim, seed=79)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    nsel = sc.obs_per_landmark + 1
+    L = sc.num_landmarks
+    shards = sharding.landmark_shards(np.full(L, sc.obs_per_landmark), nranks)
+
+    def sub(lo, hi):
+        m = (sc.obs_lm >= lo) & (sc.obs_lm < hi)
+        s = types.SimpleNamespace(**vars(sc))
+        s.landmarks, s.lm_ref_pose = sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi]
+        s.obs_z, s.obs_pose, s.obs_lm = sc.obs_z[m], sc.obs_pose[m], sc.obs_lm[m] - lo
+        s.num_landmarks = hi - lo
+        return s
+
+    def make(cls, opts, s, pose_pose):
+        b = cls(lm_dim, 15)
+        b.Init(opts)
+        b.SetGravity(sc.gravity)
+        fill(b, s)
+        if pose_pose:
+            _add_all_residual_kinds(b, sc, po, P, unary_every=8)
+        return b
+
+    o = make(po.OracleBundleAdjuster, gn_options(po, use_dogleg=1), sc, True)
+    ranks = [make(adjuster.BundleAdjuster, hip_options(use_dogleg=1, write_reduced_camera_matrix=0), sub(*shards[r]), r == 0)
+             for r in range(nranks)]
+    ar = sharding.ThreadAllReduce(nranks)
+    for r in range(nranks):
+        ranks[r].set_allreduce(ar.hook(r), r, nranks)
+        ranks[r].set_collectives(ar.collectives(r))
+    names = ("proj_error", "inertial_error", "unary_error", "binary_error", "pre_solve_norm", "post_solve_norm",
+             "trust_region_size", "delta_norm")
+    res = {}
+
+    def run(r):
+        try:
+            rows = []
+            for _ in range(3):
+                ranks[r].Solve(1)
+                s = ranks[r].summary()
+                rows.append((s.result,) + tuple(getattr(s, n) for n in names) + (ranks[r].solve_is_distributed(),))
+            res[r] = rows
+        except Exception as exc:  # surfaced below
+            res[r] = exc
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not ar.failed
+    for r in range(nranks):
+        assert not isinstance(res[r], Exception), res[r]
+    for it in range(3):
+        o.Solve(1)
+        so = o.summary()
+        for r in range(nranks):
+            row = res[r][it]
+            assert row[0] == so.result and row[-1] is True
+            for n, v in zip(names, row[1:-1]):
+                a = getattr(so, n)
+                tol = 1e-5 if n == "delta_norm" else 1e-6
+                assert abs(a - v) <= tol * max(abs(a), 1e-9), (it, r, n, a, v)
+    p0 = ranks[0].poses()
+    for r in range(nranks):
+        pr = ranks[r].poses()
+        for a, b in zip(pr, p0):
+            assert np.array_equal(a, b)                      # pose, velocity, bias states: bit for bit across ranks
+        for a, b in zip(pr, o.poses()):
+            assert rel_err(a, b) < 1e-6
+    lms = np.concatenate([ranks[r].landmarks() for r in range(nranks)])
+    assert rel_err(lms, o.landmarks()) < 1e-6
+
+
 def _add_all_residual_kinds(b, sc, po_math, P, rng_seed=4, unary_every=10):
     """projection (already filled) + IMU between neighbours + unary prior on every k-th pose +
     binary odometry between neighbours: the shape of BASELINE.json configs[4]."""
