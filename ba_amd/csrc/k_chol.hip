@@ -474,10 +474,15 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   double2 px[4], py[4];
   double FA0[4], FB0[4], FA1[4], FB1[4];
 #define BAE_SB __builtin_amdgcn_sched_barrier(0)
+// (BAE_KMASK: measurement builds only — 63 makes every operand chunk come from tile column 0, i.e. from the L2 /
+// Infinity Cache: wrong numbers, the kernel's rate without HBM misses; scratch/gpu_r03_ceiling.sh)
+#ifndef BAE_KMASK
+#define BAE_KMASK 0xffffffffu
+#endif
 #define BAE_GLOAD(K0)                                                                \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                    \
-    px[u] = *reinterpret_cast<const double2*>(Xg + u * ld32 + (K0));                 \
-    py[u] = *reinterpret_cast<const double2*>(Yg + u * ld32 + (K0));                 \
+    px[u] = *reinterpret_cast<const double2*>(Xg + u * ld32 + ((K0) & BAE_KMASK));   \
+    py[u] = *reinterpret_cast<const double2*>(Yg + u * ld32 + ((K0) & BAE_KMASK));   \
   }
 #define BAE_SSTORE(B)                                                                \
   _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                    \
