@@ -349,7 +349,10 @@ def test_fov_camera_matches_oracle(oracle_lib, lm_dim, rig):
     """calibu::FovCamera (fx, fy, u0, v0, w — the camera of the reference's CalibSize = 5 instantiations)
     in the ordinary adjuster: residuals, reduced system and step of the first iteration, then three
     iterations of the whole solver against the oracle.  fov_and_pinhole: a rig of a FovCamera and a
-    LinearCamera, half of the non-reference observations made by the second one."""
+    LinearCamera, half of the non-reference observations made by the second one.
+    PARITY UNPINNED by reference vectors: Calibu is absent from the reference tree, the oracle restates the FOV
+    model from its publication and pins its derivatives with central differences (tests/test_oracle_fd.py); this test
+    checks the HIP path against that restatement, not against Calibu."""
     po = oracle_lib
     sc = scene.make_scene(40, 120, 6, lm_dim=lm_dim, seed=31, outlier_frac=0.0)
     z_pin = sc.obs_z.copy()
