@@ -40,6 +40,11 @@ static const uint32_t kOwnMaxT = 16;
 struct OwnMap {
   uint32_t n, rank, G, T, skip_rhs;
   uint8_t tbl[kOwnMaxT][kOwnMaxT];
+  // k_update128<false, true> only (distributed bulk updates): the (block row, block column) pairs this rank owns
+  // right of the next panel, G/2 x G/2 128-blocks each — the launch holds just these instead of the whole trailing
+  // triangle with 1 - 1/N of its workgroups leaving at the ownership test.  Two 32-bit halves of the device address
+  // (plain data for the host-only builds of this header).
+  uint32_t pairs_lo, pairs_hi;
 };
 
 // Does this launch touch tile (i, c)?  i == nblk is the rhs row; its segment over block column bc rides

@@ -139,6 +139,10 @@ struct Engine {
   uint64_t dist_plan_version = ~0ull;
   std::string dist_layout_name;
   DBuf<uint32_t> dist_tiles;             // DistPlan::tiles on the device
+  DBuf<uint2> dist_pairs;                // block pairs this rank owns, by block column (k_update128<false, true>)
+  std::vector<uint32_t> dist_pair_first; // per panel J: first pair with block column >= J + 2
+  uint32_t dist_npairs = 0;
+  DBuf<uint32_t> dist_sq_list;           // per panel: the tiles of its square, then the rhs row (row lists of the chain kernels)
   DBuf<double> dist_usend, dist_urecv;   // urgent point-to-point staging (chain stream)
   DBuf<double> dist_ssend, dist_srecv;   // side point-to-point staging (side stream)
   DBuf<double> dist_back;                // backward substitution: partial sums of a panel + their reduction

@@ -391,7 +391,7 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 // The blocks cover the even part of the trailing matrix; the rhs row and an odd last tile row are
 // 64-tiles taken by the first workgroups of the same launch.
 static const int NB2 = 128;
-template <bool RECT>  // RECT: the rectangle variant (separate kernel name in profiles)
+template <bool RECT, bool LIST = false>  // RECT: the rectangle variant (separate kernel name in profiles); LIST: own.pairs
 __global__ void __launch_bounds__(256, 2)
 k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t m2, uint32_t kb0,
             uint32_t kb1, const double* __restrict__ dsgn, const int* __restrict__ colneg, uint32_t sbl,
@@ -416,7 +416,18 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   }
   const uint32_t b = blockIdx.x - nrow64;
   uint32_t R, C;
-  if (RECT) {
+  if constexpr (LIST) {
+    // distributed bulk update: workgroup -> (owned block pair, 128-block inside it); consecutive workgroups (= the
+    // XCDs) take the column blocks of one row of the pair, as in the rectangle mode
+    const uint32_t gb = own.G >> 1, per = gb * gb;
+    const uint32_t pr = b / per, within = b - pr * per;
+    const uint2* pairs = reinterpret_cast<const uint2*>(((unsigned long long)own.pairs_hi << 32) | own.pairs_lo);
+    const uint2 bp = pairs[pr];
+    const uint32_t base = c0 / own.G;
+    R = (bp.x - base) * gb + within / gb;
+    C = (bp.y - base) * gb + within % gb;
+    if (C > R || R >= m2) return;
+  } else if (RECT) {
     // consecutive workgroups (= the XCDs, round-robin) take the column blocks of one row block:
     // an XCD keeps "its" column operands in L2 for all rows
     R = b / rect_cols;
@@ -1245,7 +1256,8 @@ static void launch_next_panel_update(hipStream_t s, double* dA, uint32_t ld, uin
 // One launch, bracketed by the profiling events.
 static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t a_end,
                                    uint32_t J, uint32_t Jend, const double* dsgn, const int* colneg,
-                                   const uint8_t* nz, bool full, const OwnMap& own) {
+                                   const uint8_t* nz, bool full, const OwnMap& own, const uint2* pairs = nullptr,
+                                   uint32_t npairs = 0) {
   static const bool no128 = getenv("BA_HIP_NO128") != nullptr;  // A/B switch
   static const uint32_t sbl = getenv("BA_HIP_SBL") ? (uint32_t)atoi(getenv("BA_HIP_SBL")) : 3u;
   const uint32_t m = nblk - a_end;
@@ -1255,8 +1267,18 @@ static void launch_bulk_update(Engine* e, hipStream_t s, double* dA, uint32_t ld
     // leftover 64-tiles first (a multiple of 8 workgroups keeps the XCD phase of the blocks)
     const uint32_t nrow64 = (m * (1 + (m & 1u)) + 7) / 8 * 8;
     if (e) e->prof_begin(e->ev_syrk, s);
-    hipLaunchKernelGGL(k_update128<false>, dim3(nrow64 + ((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk,
-                       a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own, nrow64, a_end, 0u);
+    if (pairs && own.n > 1 && a_end % own.G == 0) {
+      // only the block pairs this rank owns (distributed solve)
+      OwnMap ol = own;
+      ol.pairs_lo = (uint32_t)(reinterpret_cast<unsigned long long>(pairs) & 0xffffffffull);
+      ol.pairs_hi = (uint32_t)(reinterpret_cast<unsigned long long>(pairs) >> 32);
+      const uint32_t per = (own.G / 2) * (own.G / 2);
+      hipLaunchKernelGGL((k_update128<false, true>), dim3(nrow64 + npairs * per), dim3(256), 0, s, dA, ld, nblk,
+                         a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, ol, nrow64, a_end, 0u);
+    } else {
+      hipLaunchKernelGGL(k_update128<false>, dim3(nrow64 + ((nsb + 7) / 8) * 8 * sbe2 * sbe2), dim3(256), 0, s, dA, ld, nblk,
+                         a_end, m2, J, Jend, dsgn, colneg, sbl2, nz, own, nrow64, a_end, 0u);
+    }
     if (e) e->prof_end(e->ev_syrk, s);
     return;
   }
@@ -1297,6 +1319,32 @@ static int ensure_dist_plan(Engine* e, uint32_t nblk, bool pat) {
   if (!e->dist_plan.tiles.empty())
     BAE_HIP(hipMemcpy(e->dist_tiles.p, e->dist_plan.tiles.data(), e->dist_plan.tiles.size() * sizeof(uint32_t),
                       hipMemcpyHostToDevice));
+  {
+    // block pairs (bi >= bc) this rank owns, by block column then block row; pair_first[J] = first pair with
+    // bc >= J + 2 (what the bulk update of panel J touches)
+    const DistPlan& pl = e->dist_plan;
+    std::vector<uint2> pairs;
+    e->dist_pair_first.assign(pl.nb + 1, 0);
+    for (uint32_t bc = 0; bc < pl.nb; ++bc) {
+      if (bc >= 2) e->dist_pair_first[bc - 2] = (uint32_t)pairs.size();
+      for (uint32_t bi = bc; bi < pl.nb; ++bi)
+        if (map.n <= 1 || map.tbl[bi % map.T][bc % map.T] == map.rank) pairs.push_back(make_uint2(bi, bc));
+    }
+    for (uint32_t J = (pl.nb >= 2 ? pl.nb - 2 : 0); J <= pl.nb; ++J) e->dist_pair_first[J] = (uint32_t)pairs.size();
+    e->dist_npairs = (uint32_t)pairs.size();
+    BAE_HIP(e->dist_pairs.alloc(std::max<size_t>(pairs.size(), 1)));
+    if (!pairs.empty())
+      BAE_HIP(hipMemcpy(e->dist_pairs.p, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice));
+  }
+  {
+    std::vector<uint32_t> h;
+    for (const DistPanel& pn : e->dist_plan.panels) {
+      for (uint32_t t = pn.c0; t < pn.c1; ++t) h.push_back(t);
+      h.push_back(nblk);
+    }
+    BAE_HIP(e->dist_sq_list.alloc(std::max<size_t>(h.size(), 1)));
+    BAE_HIP(hipMemcpy(e->dist_sq_list.p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   e->dist_plan_version = want;
   e->dist_srows_version = ~0ull;
   return 0;
@@ -1496,18 +1544,8 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
   if (rank == pl.panels[0].diag_owner)  // factor packet of tile 0
     hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
                        colneg, e->flags.p, nz, nblk + 1u, (const uint32_t*)nullptr);
-  // row list of a square: its tiles, then the rhs row — built per panel in a small device array
-  DBuf<uint32_t> sq_list;
-  {
-    std::vector<uint32_t> h;
-    for (const DistPanel& pn : pl.panels) {
-      for (uint32_t t = pn.c0; t < pn.c1; ++t) h.push_back(t);
-      h.push_back(nblk);
-    }
-    BAE_HIP(sq_list.alloc(h.size()));
-    BAE_HIP(hipMemcpyAsync(sq_list.p, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s0));
-    BAE_HIP(hipStreamSynchronize(s0));  // (h is a local)
-  }
+  // row list of a square: its tiles, then the rhs row — one small device array per plan (ensure_dist_plan)
+  DBuf<uint32_t>& sq_list = e->dist_sq_list;
   static const bool no128 = getenv("BA_HIP_NO128") != nullptr;
   int rc = 0;
   size_t sq_off = 0;
@@ -1631,7 +1669,8 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     if (n1 < nblk) {
       BAE_HIP(hipStreamWaitEvent(s2, EV(J, 2), 0));
       BAE_HIP(hipStreamWaitEvent(s2, EV(J, 0), 0));
-      launch_bulk_update(e, s2, dA, ld, nblk, n1, c0, c1, dsgn, colneg, nz, true, own);
+      launch_bulk_update(e, s2, dA, ld, nblk, n1, c0, c1, dsgn, colneg, nz, true, own,
+                         e->dist_pairs.p + e->dist_pair_first[J], e->dist_npairs - e->dist_pair_first[J]);
       if (e->profiling) {
         // tile products formed by THIS rank: tiles (i, c), i >= c >= n1, it owns, both operand tiles of the
         // panel column structurally nonzero; per row class a suffix count of the nonzero tiles of the column
@@ -1656,7 +1695,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     }
     BAE_HIP(hipEventRecord(EV(J, 4), s2));
   }
-  if (rc) { sq_list.release(); return rc; }
+  if (rc) return rc;
   BAE_HIP(hipGetLastError());
   // every stream has drained into the chain stream's view before the backward substitution
   BAE_HIP(hipStreamSynchronize(s1));
@@ -1686,7 +1725,6 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     }
     launch_backward(s0, dA, ld, nblk, (const double*)linvT, dx, nz, c0, c1);
   }
-  sq_list.release();
   if (rc) return rc;
   BAE_HIP(hipGetLastError());
   // the pivot status of every diagonal owner
