@@ -139,6 +139,11 @@ struct Engine {
   uint64_t dist_plan_version = ~0ull;
   std::string dist_layout_name;
   DBuf<uint32_t> dist_tiles;             // DistPlan::tiles on the device
+  // sparse exchange of S (dist_scatter_S_sparse): rectangles per peer (prefix offsets [N + 1]) and their staging offsets
+  uint64_t dist_sp_version = ~0ull;
+  std::vector<uint32_t> dist_sp_send, dist_sp_recv;
+  std::vector<size_t> dist_sp_send_off, dist_sp_recv_off;
+  DBuf<uint4> dist_sp_srect, dist_sp_rrect;
   DBuf<uint2> dist_pairs;                // block pairs this rank owns, by block column (k_update128<false, true>)
   std::vector<uint32_t> dist_pair_first; // per panel J: first pair with block column >= J + 2
   uint32_t dist_npairs = 0;

@@ -483,7 +483,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(wave_rng); REL(tile_order); REL(tile_desc); REL(tile_ptr); REL(tile_ref); REL(pair_ent); REL(pose_ptr); REL(pose_mid); REL(pose_ent);
   REL(imu_frozen); REL(imu_steps); REL(imu_cov_done); REL(pose_cam);
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
-  REL(dist_tiles); REL(dist_sq_list); REL(dist_pairs); REL(dist_usend); REL(dist_urecv); REL(dist_ssend); REL(dist_srecv); REL(dist_back);
+  REL(dist_tiles); REL(dist_sq_list); REL(dist_pairs); REL(dist_sp_srect); REL(dist_sp_rrect); REL(dist_usend); REL(dist_urecv); REL(dist_ssend); REL(dist_srecv); REL(dist_back);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
   REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
   REL(frow); REL(diag_blocks); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);

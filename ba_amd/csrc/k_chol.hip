@@ -1347,6 +1347,7 @@ static int ensure_dist_plan(Engine* e, uint32_t nblk, bool pat) {
   }
   e->dist_plan_version = want;
   e->dist_srows_version = ~0ull;
+  e->dist_sp_version = ~0ull;
   return 0;
 }
 
@@ -1354,8 +1355,11 @@ static int ensure_dist_plan(Engine* e, uint32_t nblk, bool pat) {
 // structurally nonzero tile of S on SOME shard travel (the union pattern of factor_tile_pattern, identical
 // on every rank; S itself is half as dense as its factor): the other tiles are zero on every rank already.
 // Chunk of destination rank r: for every panel, the row tiles of that panel whose block r owns.
+int dist_scatter_S_sparse(Engine* e);
 int dist_reduce_scatter_S(Engine* e) {
   const uint32_t ld = e->st.ld, nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
+  // default: the sparse point-to-point exchange (below); BA_HIP_DENSE_SCATTER=1: one reduce-scatter of the union pattern
+  if (!getenv("BA_HIP_DENSE_SCATTER") && e->nranks > 1) return dist_scatter_S_sparse(e);
   const bool pat = e->nzS_host.size() == (size_t)nblk * nblk;
   { const int prc = ensure_dist_plan(e, nblk, pat && e->nzL_host.size() == (size_t)nblk * nblk); if (prc) return prc; }
   const DistPlan& pl = e->dist_plan;
@@ -1418,6 +1422,138 @@ int dist_reduce_scatter_S(Engine* e) {
     hipLaunchKernelGGL(k_copy_panel_rows, dim3(ntl * NB), dim3(256), 0, e->stream, e->A.p, ld,
                        (const uint32_t*)(e->dist_srows.p + e->dist_srows_off[k]), ntl, nblk * NB, pl.panels[p].c0 * NB,
                        (pl.panels[p].c1 - pl.panels[p].c0) * NB, e->packed.p + (size_t)rank * chunk + off[k], 1);
+  }
+  BAE_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- sparse exchange of S: only the tiles a shard really has ------------------------------------------------------
+// rects[b >> 6] = (row tile, first column in doubles, columns, offset of the 64 x columns block in buf);
+// mode 0: buf <- A (pack), mode 1: A += buf (sum at the owner)
+__global__ void __launch_bounds__(256)
+k_copy_rects(double* __restrict__ A, uint32_t ld, const uint4* __restrict__ rects, double* __restrict__ buf, int mode) {
+  const uint4 rc = rects[blockIdx.x >> 6];
+  const uint32_t r = blockIdx.x & 63u;
+  double* row = A + ((size_t)rc.x * NB + r) * ld + rc.y;
+  double* brow = buf + (size_t)rc.w + (size_t)r * rc.z;
+  for (uint32_t cc = threadIdx.x; cc < rc.z; cc += 256) {
+    if (mode) row[cc] += brow[cc];
+    else brow[cc] = row[cc];
+  }
+}
+
+// Every rank holds a partial S over its landmark shard; the owner of a tile block needs the SUM.  The dense
+// reduce-scatter (dist_reduce_scatter_S) moves every tile of the UNION pattern from every rank.  Here a rank sends a
+// (row tile x panel) rectangle to its owner only if its OWN pattern (Structure::tile_nz: the tiles its shard, its
+// pose-pose residuals and the diagonal touch) has a tile in it; the owner adds what arrives in ascending rank order
+// (deterministic).  With shards dealt along the trajectory a shard touches a band of S and sends a fraction of what
+// the dense exchange does; with shards that touch everything the volume is the dense one.  The local patterns are
+// all-gathered once per structure (one u64 all-reduce with every rank's bits in its own slot).
+int dist_scatter_S_sparse(Engine* e) {
+  const uint32_t ld = e->st.ld, nblk = ld / NB, N = (uint32_t)e->nranks, rank = (uint32_t)e->rank;
+  { const int prc = ensure_dist_plan(e, nblk, e->nzL_host.size() == (size_t)nblk * nblk); if (prc) return prc; }
+  const DistPlan& pl = e->dist_plan;
+  if (e->st.tile_nz.size() != (size_t)nblk * nblk) return e->fail_msg("sparse exchange of S: no local tile pattern");
+  if (e->dist_sp_version != e->dist_plan_version) {
+    // --- all-gather of the local patterns (lower triangle, bit per tile)
+    const size_t bits = (size_t)nblk * nblk, words = (bits + 63) / 64;
+    std::vector<unsigned long long> all(words * N, 0ull);
+    for (uint32_t i = 0; i < nblk; ++i)
+      for (uint32_t k = 0; k <= i; ++k)
+        if (e->st.tile_nz[(size_t)i * nblk + k]) {
+          const size_t b = (size_t)i * nblk + k;
+          all[(size_t)rank * words + (b >> 6)] |= 1ull << (b & 63);
+        }
+    {
+      DBuf<unsigned long long> d;
+      BAE_HIP(d.alloc(all.size()));
+      hipError_t err = hipMemcpy(d.p, all.data(), all.size() * 8, hipMemcpyHostToDevice);
+      int rc = 0;
+      if (err != hipSuccess) rc = e->fail(err, "hipMemcpy");
+      if (!rc && shard_allreduce(e, d.p, all.size(), 1) != 0) rc = e->fail_msg("allreduce hook failed");
+      if (!rc && (err = hipMemcpy(all.data(), d.p, all.size() * 8, hipMemcpyDeviceToHost)) != hipSuccess) rc = e->fail(err, "hipMemcpy");
+      d.release();
+      if (rc) return rc;
+    }
+    auto has = [&](uint32_t s_, uint32_t i, uint32_t c0, uint32_t c1) {
+      for (uint32_t kb = c0; kb < c1 && kb <= i; ++kb) {
+        const size_t b = (size_t)i * nblk + kb;
+        if (all[(size_t)s_ * words + (b >> 6)] >> (b & 63) & 1ull) return true;
+      }
+      return false;
+    };
+    // --- rectangles this rank sends (by destination) and receives (by source), enumerated identically on both sides
+    std::vector<uint4> srect, rrect;
+    e->dist_sp_send.assign(N + 1, 0); e->dist_sp_recv.assign(N + 1, 0);
+    e->dist_sp_send_off.assign(N + 1, 0); e->dist_sp_recv_off.assign(N + 1, 0);
+    size_t soff = 0, roff = 0;
+    bool too_big = false;
+    for (uint32_t peer = 0; peer < N; ++peer) {
+      e->dist_sp_send[peer] = (uint32_t)srect.size(); e->dist_sp_recv[peer] = (uint32_t)rrect.size();
+      e->dist_sp_send_off[peer] = soff; e->dist_sp_recv_off[peer] = roff;
+      if (peer == rank) continue;
+      OwnMap mp = pl.map, mr = pl.map;
+      mp.rank = peer; mr.rank = rank;
+      for (uint32_t p = 0; p < pl.nb; ++p) {
+        const uint32_t c0 = pl.panels[p].c0, c1 = pl.panels[p].c1, w = (c1 - c0) * NB;
+        for (uint32_t i = c0; i < nblk; ++i) {
+          if (own_tile(mp, i, c0, nblk) && has(rank, i, c0, c1)) {   // mine -> peer
+            too_big |= soff > 0xffffffffull - (size_t)NB * w;
+            srect.push_back(make_uint4(i, c0 * NB, w, (uint32_t)soff));
+            soff += (size_t)NB * w;
+          }
+          if (own_tile(mr, i, c0, nblk) && has(peer, i, c0, c1)) {   // peer -> me
+            too_big |= roff > 0xffffffffull - (size_t)NB * w;
+            rrect.push_back(make_uint4(i, c0 * NB, w, (uint32_t)roff));
+            roff += (size_t)NB * w;
+          }
+        }
+      }
+    }
+    e->dist_sp_send[N] = (uint32_t)srect.size(); e->dist_sp_recv[N] = (uint32_t)rrect.size();
+    e->dist_sp_send_off[N] = soff; e->dist_sp_recv_off[N] = roff;
+    if (too_big) return e->fail_msg("sparse exchange of S: more than 2^32 doubles to one side (use BA_HIP_DENSE_SCATTER=1)");
+    BAE_HIP(e->dist_sp_srect.alloc(std::max<size_t>(srect.size(), 1)));
+    BAE_HIP(e->dist_sp_rrect.alloc(std::max<size_t>(rrect.size(), 1)));
+    if (!srect.empty()) BAE_HIP(hipMemcpy(e->dist_sp_srect.p, srect.data(), srect.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!rrect.empty()) BAE_HIP(hipMemcpy(e->dist_sp_rrect.p, rrect.data(), rrect.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    e->dist_sp_version = e->dist_plan_version;
+  }
+  const size_t stot = e->dist_sp_send_off[N], rtot = e->dist_sp_recv_off[N];
+  // staging: the send half and the receive half of `packed`
+  BAE_HIP(e->packed.alloc(std::max<size_t>(stot + rtot, 1)));
+  double* sbuf = e->packed.p;
+  double* rbuf = e->packed.p + stot;
+  std::vector<DistXfer> xf;
+  for (uint32_t peer = 0; peer < N; ++peer) {
+    if (peer == rank) continue;
+    const uint32_t ns = e->dist_sp_send[peer + 1] - e->dist_sp_send[peer];
+    const size_t slen = e->dist_sp_send_off[peer + 1] - e->dist_sp_send_off[peer];
+    if (ns) {
+      hipLaunchKernelGGL(k_copy_rects, dim3(ns * 64), dim3(256), 0, e->stream, e->A.p, ld,
+                         (const uint4*)(e->dist_sp_srect.p + e->dist_sp_send[peer]), sbuf, 0);
+      xf.push_back({sbuf + e->dist_sp_send_off[peer], slen, (int)peer, true});
+    }
+    const size_t rlen = e->dist_sp_recv_off[peer + 1] - e->dist_sp_recv_off[peer];
+    if (rlen) xf.push_back({rbuf + e->dist_sp_recv_off[peer], rlen, (int)peer, false});
+  }
+  BAE_HIP(hipGetLastError());
+  e->cstats.reduce_scatter_bytes += 8.0 * (double)stot;
+  {
+    // (counted as the S exchange, not as chain traffic: undo dist_exchange's own bookkeeping)
+    const ba_hip_comm_stats keep = e->cstats;
+    const int xrc = dist_exchange(e, xf, false, e->stream);
+    const double rs = e->cstats.reduce_scatter_bytes;
+    e->cstats = keep;
+    e->cstats.reduce_scatter_bytes = rs;
+    if (xrc) return xrc;
+  }
+  for (uint32_t peer = 0; peer < N; ++peer) {   // ascending rank order: the sums are reproducible
+    if (peer == rank) continue;
+    const uint32_t nr = e->dist_sp_recv[peer + 1] - e->dist_sp_recv[peer];
+    if (nr)
+      hipLaunchKernelGGL(k_copy_rects, dim3(nr * 64), dim3(256), 0, e->stream, e->A.p, ld,
+                         (const uint4*)(e->dist_sp_rrect.p + e->dist_sp_recv[peer]), rbuf, 1);
   }
   BAE_HIP(hipGetLastError());
   return 0;

@@ -391,21 +391,29 @@ def remount_landmarks(sc, t_vs_from, t_vs_to):
     return out
 
 
-def populate(ba, sc, active=None, imu=False, priors=False, unary_every=100, seed=4, lm_range=None, pose_pose=True):
+def populate(ba, sc, active=None, imu=False, priors=False, unary_every=100, seed=4, lm_range=None, pose_pose=True,
+             lm_ids=None):
     """Feed a Scene through a reference-style API object (the oracle's or ba_amd.adjuster's
     BundleAdjuster — same method names): camera, poses, landmarks, projection residuals;
     imu: one inertial residual per consecutive pose pair (needs add_inertial);
     priors: a unary prior on every `unary_every`-th pose (cov diag(1e-2 I3, 1e-3 I3)) and a binary
     odometry constraint between consecutive poses from the ground truth + 1 cm noise, identity
     covariance — the configs[4] recipe of SURVEY.md §8d.
-    lm_range = (lo, hi): only that landmark shard and its observations (multi-GPU: every rank holds all
-    poses); pose_pose = False: no inertial / unary / binary residuals (they live on rank 0)."""
+    lm_range = (lo, hi) or lm_ids = ascending landmark ids: only that landmark shard and its observations (multi-GPU:
+    every rank holds all poses); pose_pose = False: no inertial / unary / binary residuals (they live on rank 0)."""
     if hasattr(sc, "gravity") and imu:
         ba.SetGravity(sc.gravity)
     ba.AddCamera(sc.cam_params)
     ba.add_poses(sc.poses, v_w=getattr(sc, "init_vel", None), b=getattr(sc, "init_bias", None),
                  is_active=active, time=getattr(sc, "pose_time", None))
-    if lm_range is None:
+    if lm_ids is not None:   # an arbitrary (ascending) set of landmark ids: shards dealt along the trajectory
+        ids = np.asarray(lm_ids)
+        new_id = np.full(sc.num_landmarks, -1, dtype=np.int64)
+        new_id[ids] = np.arange(len(ids))
+        sel = new_id[sc.obs_lm] >= 0
+        ba.add_landmarks(sc.landmarks[ids], sc.lm_ref_pose[ids])
+        n = ba.add_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], new_id[sc.obs_lm[sel]].astype(np.uint32))
+    elif lm_range is None:
         ba.add_landmarks(sc.landmarks, sc.lm_ref_pose)
         n = ba.add_projection_residuals(sc.obs_z, sc.obs_pose, sc.obs_lm)
     else:

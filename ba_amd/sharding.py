@@ -30,6 +30,18 @@ def landmark_shards(obs_per_landmark, nranks):
     return [(int(bounds[r]), int(bounds[r + 1])) for r in range(nranks)]
 
 
+def landmark_shards_along_trajectory(lm_ref_pose, obs_per_landmark, nranks):
+    """Landmark id arrays, one per rank: the landmarks in the order of their reference pose, cut into ranges balanced
+    by the Schur work  sum k(k+1)/2  like landmark_shards.  A shard then touches the poses of one stretch of the
+    trajectory (plus the visibility window either side), i.e. a band of the reduced pose system instead of all of it:
+    the sparse exchange of S (ba_amd/csrc/k_chol.hip: dist_scatter_S_sparse) moves a fraction of what shards that are
+    contiguous in a spatially random id do.  Ids inside a shard stay ascending."""
+    ref = np.asarray(lm_ref_pose)
+    order = np.argsort(ref, kind="stable")
+    k = np.broadcast_to(np.asarray(obs_per_landmark, dtype=np.float64), ref.shape)[order]
+    return [np.sort(order[lo:hi]).astype(np.int64) for lo, hi in landmark_shards(k, nranks)]
+
+
 class _DevArray:
     """__cuda_array_interface__ view of a raw device pointer."""
 

@@ -99,12 +99,15 @@ def active_mask(cfg, sc):
     return pa
 
 
-def build_engine(sc, lm_dim, lo, hi, device, stream=None):
-    """C-ABI driver: upload poses (all) and the landmark shard [lo, hi) with its accepted residuals."""
+def build_engine(sc, lm_dim, lo, hi, device, stream=None, ids=None):
+    """C-ABI driver: upload poses (all) and the landmark shard [lo, hi) — or the landmark ids `ids` (ascending) —
+    with its accepted residuals."""
     nsel = sc.obs_per_landmark + (1 if lm_dim == 1 else 0)
     keep = np.ones(len(sc.obs_pose), dtype=bool)
     if lm_dim == 1:
         keep[::nsel] = False  # the reference-frame observation is rejected (BundleAdjuster.h:489-501)
+    if ids is not None:
+        return _build_engine_ids(sc, lm_dim, keep, np.asarray(ids), device, stream)
     sel = keep & (sc.obs_lm >= lo) & (sc.obs_lm < hi)
     pa = np.ones(sc.num_poses, dtype=np.uint8)
     pa[sc.anchor_poses] = 0
@@ -113,6 +116,23 @@ def build_engine(sc, lm_dim, lo, hi, device, stream=None):
     eng.set_poses(sc.poses, is_active=pa)
     eng.set_landmarks(sc.landmarks[lo:hi], sc.lm_ref_pose[lo:hi])
     eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], sc.obs_lm[sel] - lo)
+    eng.finalize()
+    eng.begin_solve()
+    eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+    return eng, int(sel.sum())
+
+
+def _build_engine_ids(sc, lm_dim, keep, ids, device, stream):
+    new_id = np.full(sc.num_landmarks, -1, dtype=np.int64)
+    new_id[ids] = np.arange(len(ids))
+    sel = keep & (new_id[sc.obs_lm] >= 0)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    eng = hipapi.Engine(lm_dim, 6, device=device, stream=stream)
+    eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+    eng.set_poses(sc.poses, is_active=pa)
+    eng.set_landmarks(sc.landmarks[ids], sc.lm_ref_pose[ids])
+    eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], new_id[sc.obs_lm[sel]].astype(np.uint32))
     eng.finalize()
     eng.begin_solve()
     eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
@@ -143,7 +163,7 @@ def api_options(mod, cfg):
     return o
 
 
-def build_adjuster(cfg, sc, lm_dim, lm_range=None, pose_pose=True, device=0):
+def build_adjuster(cfg, sc, lm_dim, lm_range=None, pose_pose=True, device=0, lm_ids=None):
     """C++ API driver: ba::BundleAdjuster<double, LmSize, PoseSize> through include/ba_capi.h.
     lm_range / pose_pose: this rank's landmark shard; inertial / unary / binary residuals on rank 0 only."""
     h = adjuster.BundleAdjuster(lm_dim, cfg["D"])
@@ -151,7 +171,7 @@ def build_adjuster(cfg, sc, lm_dim, lm_range=None, pose_pose=True, device=0):
     o.device = device
     h.Init(o)
     scene.populate(h, sc, active=active_mask(cfg, sc), imu=cfg["imu"], priors=cfg["priors"], lm_range=lm_range,
-                   pose_pose=pose_pose)
+                   pose_pose=pose_pose, lm_ids=lm_ids)
     return h
 
 
@@ -301,8 +321,13 @@ def main():
         # landmark shards: contiguous, equal counts (every landmark has K residuals, so the
         # Schur work  sum k(k+1)/2  is balanced too)
         lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
+        # N > 1: shards dealt ALONG THE TRAJECTORY (landmarks in the order of their reference pose), so that a shard's
+        # partial S is a band and the sparse exchange of S moves a fraction of the matrix (BA_BENCH_SHARDS=id: contiguous ids)
+        ids = None
+        if world > 1 and os.environ.get("BA_BENCH_SHARDS", "trajectory") != "id":
+            ids = sharding.landmark_shards_along_trajectory(sc.lm_ref_pose, np.full(L, K), world)[rank]
         t_setup = time.perf_counter()
-        eng, _ = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0)
+        eng, _ = build_engine(sc, lm_dim, lo, hi, local_rank if world > 1 else 0, ids=ids)
         t_setup = time.perf_counter() - t_setup  # host -> device uploads + structure build (once per graph)
         if world > 1 and comm_mode == "native":
             # native RCCL inside the engine: all-reduce, reduce-scatter of S to the panel owners,
@@ -362,7 +387,10 @@ def main():
         if world > 1:
             nsel = K + (1 if lm_dim == 1 else 0)
             lo, hi = sharding.landmark_shards(np.full(L, K), world)[rank]
-            h = build_adjuster(cfg, sc, lm_dim, lm_range=(lo, hi), pose_pose=(rank == 0), device=local_rank)
+            ids = None
+            if os.environ.get("BA_BENCH_SHARDS", "trajectory") != "id":   # shards along the trajectory (see the C-ABI driver)
+                ids = sharding.landmark_shards_along_trajectory(sc.lm_ref_pose, np.full(L, K), world)[rank]
+            h = build_adjuster(cfg, sc, lm_dim, lm_range=(lo, hi), pose_pose=(rank == 0), device=local_rank, lm_ids=ids)
             if comm_mode == "native":
                 ids = [hipapi.Engine.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)

@@ -712,6 +712,81 @@ def test_distributed_solve_matches_single(oracle_lib, monkeypatch, nranks, layou
         e_.close()
 
 
+def test_sparse_exchange_of_S_moves_less_with_shards_along_the_trajectory(oracle_lib):
+    """The partial S of a landmark shard reaches the owners of its tile blocks point to point, and only the
+    (row tile x panel) rectangles the shard's own pattern touches travel (dist_scatter_S_sparse).  Four emulated
+    ranks, the same scene dealt two ways: shards contiguous in the generator's spatially random landmark id touch
+    every pose pair; shards dealt along the trajectory (landmarks by reference pose) touch a band.  Both must
+    reproduce the single engine; the second must move clearly fewer bytes.  (BA_HIP_DENSE_SCATTER=1, one
+    reduce-scatter of the union pattern, is the fallback path and is run too.)"""
+    import threading
+
+    from ba_amd import sharding
+    lm_dim, nranks = 1, 4
+    sc = scene.make_scene(300, 3000, 6, lm_dim=lm_dim, seed=67)
+    pa = np.ones(sc.num_poses, dtype=np.uint8)
+    pa[sc.anchor_poses] = 0
+    keep = np.ones(len(sc.obs_pose), dtype=bool)
+    keep[::sc.obs_per_landmark + 1] = False
+    L = sc.num_landmarks
+
+    def make(ids):
+        new_id = np.full(L, -1, dtype=np.int64)
+        new_id[ids] = np.arange(len(ids))
+        sel = keep & (new_id[sc.obs_lm] >= 0)
+        eng = hipapi.Engine(lm_dim, 6)
+        eng.set_cameras(sc.cam_params, [0, 0, 0, 0, 0, 0, 1])
+        eng.set_poses(sc.poses, is_active=pa)
+        eng.set_landmarks(sc.landmarks[ids], sc.lm_ref_pose[ids])
+        eng.set_projection_residuals(sc.obs_z[sel], sc.obs_pose[sel], new_id[sc.obs_lm[sel]].astype(np.uint32))
+        eng.finalize()
+        eng.begin_solve()
+        eng.set_pose_masks(np.zeros(sc.num_poses, dtype=np.uint16))
+        return eng
+
+    single = make(np.arange(L))
+    out = {}
+    _run_engine_steps(single, 2, out, "single")
+    ps, _, _ = single.get_poses(sc.num_poses)
+    deals = {"id": [np.arange(lo, hi) for lo, hi in sharding.landmark_shards(np.full(L, sc.obs_per_landmark), nranks)],
+             "trajectory": sharding.landmark_shards_along_trajectory(sc.lm_ref_pose, np.full(L, sc.obs_per_landmark), nranks)}
+    assert sorted(np.concatenate(deals["trajectory"]).tolist()) == list(range(L))
+    moved = {}
+    for name, env in (("id", None), ("trajectory", None), ("trajectory_dense", "1")):
+        if env:
+            os.environ["BA_HIP_DENSE_SCATTER"] = env
+        try:
+            engs = [make(deals[name.split("_")[0]][r]) for r in range(nranks)]
+            ar = sharding.ThreadAllReduce(nranks)
+            for r in range(nranks):
+                engs[r].set_allreduce(ar.hook(r), r, nranks)
+                engs[r].set_collectives(ar.collectives(r))
+            th = [threading.Thread(target=_run_engine_steps, args=(engs[r], 2, out, (name, r))) for r in range(nranks)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(timeout=300)
+            assert not ar.failed
+        finally:
+            os.environ.pop("BA_HIP_DENSE_SCATTER", None)
+        for r in range(nranks):
+            assert not isinstance(out[(name, r)], Exception), out[(name, r)]
+            pr, _, _ = engs[r].get_poses(sc.num_poses)
+            assert rel_err(pr, ps) < 1e-9
+            for a, b in zip(out["single"], out[(name, r)]):
+                assert a[0] == b[0] == 0
+                for x, y in zip(a[1:], b[1:]):
+                    assert abs(x - y) <= 1e-8 * max(abs(x), 1e-12)
+        moved[name] = sum(e_.comm_stats()["reduce_scatter_bytes"] for e_ in engs)
+        for e_ in engs:
+            e_.end_solve()
+            e_.close()
+    assert moved["trajectory"] < 0.7 * moved["id"], moved
+    assert moved["trajectory"] < moved["trajectory_dense"], moved
+    single.end_solve()
+    single.close()
+
+
 def test_tile_sparse_factorisation_matches_oracle(oracle_lib):
     """300 poses (n = 1788, 28 tiles of 64): poses far apart on the loop share no landmark, so S
     has structurally zero 64x64 tiles and the factorisation skips tile products (symbolic
