@@ -112,6 +112,7 @@ struct Engine {
   DBuf<uint4> tile_desc;                 // per launch entry: (tile, first ref, end ref, row << 16 | column) (k_tile_desc)
   uint32_t n_tile_order = 0;
   uint64_t tile_order_version = ~0ull;
+  uint64_t tile_order_plan = ~0ull;      // distributed solve: the launch list holds the owned + sent tiles of plan version ..
   int dbg_assemble_variant = 5;          // k_assemble_tiles<VAR> (ba_hip_debug_set key 1)
   int dbg_host_structure = 0;            // 1: build the static lists on the host (structure.h) (key 5)
   int dbg_linearize_variant = 0;         // 0 LDS-staged factor rows, 1 direct stores (key 4)
@@ -286,6 +287,7 @@ int dist_reduce_scatter_S(Engine* e);
 int launch_imu_residual_vectors(Engine* e, double* d_r15);
 int build_tile_order(Engine* e);
 int build_tile_desc(Engine* e);   // k_reduce.hip
+int dist_assembly_tiles(Engine* e, std::vector<uint8_t>* need);  // k_chol.hip
 // the static lists built on the device (structure_dev.hip); same contents as structure.h's host builder
 int build_lists_device(Engine* e, const std::function<void(const char*)>& stage);
 // broadcast of `count` doubles from `root`, ordered into `s`: native RCCL enqueues without a host

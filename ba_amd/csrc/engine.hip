@@ -343,16 +343,22 @@ int build_tile_order(Engine* e) {
     int rc = factor_tile_pattern(e);
     if (rc) return rc;
   }
-  if (e->tile_order_version == e->nzL_version && e->tile_order.p) return 0;
   const uint32_t nt = st.ld / 64;
+  // distributed solve with the sparse exchange of S: only the tiles this rank owns or sends (k_chol.hip)
+  std::vector<uint8_t> need;
+  const int restricted = e->dbg_all_tiles ? 0 : dist_assembly_tiles(e, &need);
+  if (restricted < 0) return restricted;
+  const uint64_t plan_key = restricted ? e->dist_plan_version : ~0ull;
+  if (e->tile_order_version == e->nzL_version && e->tile_order.p && e->tile_order_plan == plan_key) return 0;
   const bool pat = !e->dbg_all_tiles && e->nzL_host.size() == (size_t)nt * nt;
+  const std::vector<uint8_t>& which = restricted ? need : e->nzL_host;
   std::vector<uint32_t> order;
   size_t longest = 0;
   if (e->dbg_tile_order == 1) {
     std::vector<std::vector<uint32_t>> queue(8);
     for (uint32_t I = 0; I < nt; ++I)
       for (uint32_t J = I; J < nt; ++J)
-        if (!pat || e->nzL_host[(size_t)J * nt + I]) queue[I % 8].push_back((uint32_t)((uint64_t)J * (J + 1) / 2 + I));
+        if (!pat || which[(size_t)J * nt + I]) queue[I % 8].push_back((uint32_t)((uint64_t)J * (J + 1) / 2 + I));
     for (auto& q : queue) longest = std::max(longest, q.size());
     order.assign(std::max<size_t>(8 * longest, 1), 0xffffffffu);
     for (uint32_t x = 0; x < 8; ++x)
@@ -362,7 +368,7 @@ int build_tile_order(Engine* e) {
     // fill-only tiles, so latency-bound and bandwidth-bound workgroups overlap on every CU
     for (uint32_t J = 0; J < nt; ++J)
       for (uint32_t I = 0; I <= J; ++I)
-        if (!pat || e->nzL_host[(size_t)J * nt + I]) order.push_back((uint32_t)((uint64_t)J * (J + 1) / 2 + I));
+        if (!pat || which[(size_t)J * nt + I]) order.push_back((uint32_t)((uint64_t)J * (J + 1) / 2 + I));
     longest = (order.size() + 7) / 8;
     order.resize(std::max<size_t>(8 * longest, 1), 0xffffffffu);
   }
@@ -371,6 +377,7 @@ int build_tile_order(Engine* e) {
   if (rc) return rc;
   if ((rc = build_tile_desc(e))) return rc;
   e->tile_order_version = e->nzL_version;
+  e->tile_order_plan = plan_key;
   return 0;
 }
 

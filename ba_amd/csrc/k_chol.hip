@@ -1559,6 +1559,33 @@ int dist_scatter_S_sparse(Engine* e) {
   return 0;
 }
 
+// Which tiles of the factor's pattern this rank's assembly has to write when S is exchanged sparsely: the tiles it OWNS
+// (they receive the other shards' rectangles and the factorisation's updates: they must start from its own partial or
+// from zero) and the tiles of every rectangle it SENDS (a rectangle travels whole: tiles of it that the shard does not
+// touch must be zeros, not last iteration's leftovers).  Every other tile is neither read nor sent by this rank.  need:
+// nt x nt bytes, lower triangle.  Returns 1 if the restriction applies (distributed solve with the sparse exchange).
+int dist_assembly_tiles(Engine* e, std::vector<uint8_t>* need) {
+  const uint32_t nt = e->st.ld / NB;
+  if (!dist_solve_enabled(e) || e->nranks <= 1 || getenv("BA_HIP_DENSE_SCATTER")) return 0;
+  if (e->nzL_host.size() != (size_t)nt * nt || e->st.tile_nz.size() != (size_t)nt * nt) return 0;
+  if (ensure_dist_plan(e, nt, true)) return -1;
+  const DistPlan& pl = e->dist_plan;
+  OwnMap me = pl.map;
+  me.rank = (uint32_t)e->rank;
+  need->assign((size_t)nt * nt, 0);
+  for (uint32_t p = 0; p < pl.nb; ++p) {
+    const uint32_t c0 = pl.panels[p].c0, c1 = pl.panels[p].c1;
+    for (uint32_t i = c0; i < nt; ++i) {
+      bool touch = own_tile(me, i, c0, nt);
+      for (uint32_t kb = c0; kb < c1 && kb <= i && !touch; ++kb) touch = e->st.tile_nz[(size_t)i * nt + kb] != 0;
+      if (!touch) continue;
+      for (uint32_t kb = c0; kb < c1 && kb <= i; ++kb)
+        if (e->nzL_host[(size_t)i * nt + kb]) (*need)[(size_t)i * nt + kb] = 1;
+    }
+  }
+  return 1;
+}
+
 // pivot floors tol * |A_jj| of the matrix about to be factorised (rank-deficiency guard)
 __global__ void k_pivot_floor(uint32_t n_pad, uint32_t ld, const double* __restrict__ A, double tol,
                               double* __restrict__ out) {
