@@ -526,7 +526,7 @@ def main():
                        "parallelism": ("landmark-sharded x%d (all poses on every rank%s), %s; collectives: %s"
                                        % (world, ", pose-pose residuals on rank 0" if api_driver else "",
                                           "replicated LDL^T (all-reduce of S)" if (os.environ.get("BA_BENCH_REPLICATED_SOLVE") or (api_driver and comm_mode != "native"))
-                                          else "reduce-scatter of S onto tile-block owners, distributed LDL^T (square broadcast + point-to-point block rows, DESIGN.md 6a)",
+                                          else "sparse exchange of S onto tile-block owners (shards along the trajectory), distributed LDL^T (square broadcast + point-to-point block rows, DESIGN.md 6a)",
                                           "engine-owned RCCL communicator" + (" (ba::BundleAdjuster::SetCommunicator)" if api_driver else "")
                                           if comm_mode == "native" else "torch.distributed hooks (%s)" % backend))
                        if world > 1 else "single GPU"},
