@@ -142,6 +142,9 @@ int dist_exchange(Engine* e, const std::vector<DistXfer>& x, bool side, hipStrea
     if (t.send && e->coll(e->coll_ctx, 3, t.buf, t.count, t.peer) != 0) return e->fail_msg("send hook failed");
   for (const DistXfer& t : x)
     if (!t.send && e->coll(e->coll_ctx, 4, t.buf, t.count, t.peer) != 0) return e->fail_msg("receive hook failed");
+  // op 5: end of the exchange — a hook that defers its sends (to batch them with the receives) must have started them
+  // all by the time it returns from this call; hooks that send eagerly ignore it
+  if (e->coll(e->coll_ctx, 5, nullptr, 0, 0) != 0) return e->fail_msg("exchange flush hook failed");
   return 0;
 }
 

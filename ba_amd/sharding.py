@@ -91,10 +91,18 @@ def torch_collectives_hook(dist, device="cuda"):
     send to / receive from rank `root` (point-to-point messages of the distributed solve)."""
     import torch
     pending = []   # (work, buffer) of the sends in flight
+    deferred = []  # nccl backend: (buffer, destination) of the sends waiting for their batch
 
     def fn(op, ptr, count, root):
         try:
             world, rank = dist.get_world_size(), dist.get_rank()
+            nccl = device == "cuda" and dist.get_backend() == "nccl"
+            if op == 5:      # end of an exchange
+                if nccl and deferred:   # sends nobody batched with a receive (this rank receives nothing)
+                    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, b, d) for b, d in deferred]):
+                        w.wait()
+                    deferred.clear()
+                return 0
             n = count * world if op == 2 else count
             if device == "cuda":
                 t = torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
@@ -103,12 +111,22 @@ def torch_collectives_hook(dist, device="cuda"):
             if op == 1:
                 dist.broadcast(t, src=root)
             elif op == 3:   # send to `root`: must not block on the receiver
+                if nccl:
+                    # RCCL point to point outside a group deadlocks when two ranks send to each other first: the
+                    # sends are deferred and launched in ONE batch with the first receive (or at op 5)
+                    deferred.append((t.clone(), root))
+                    return 0
                 # (gloo moves host memory: device buffers are staged through the host for it)
                 buf = t.cpu() if (device == "cuda" and dist.get_backend() == "gloo") else t.clone()
                 pending.append((dist.isend(buf, dst=root), buf))
                 return 0
             elif op == 4:   # receive from `root`
-                if device == "cuda" and dist.get_backend() == "gloo":
+                if nccl:
+                    ops = [dist.P2POp(dist.isend, b, d) for b, d in deferred] + [dist.P2POp(dist.irecv, t, root)]
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                    deferred.clear()
+                elif device == "cuda" and dist.get_backend() == "gloo":
                     tmp = torch.empty(count, dtype=torch.float64)
                     dist.recv(tmp, src=root)
                     t.copy_(tmp)
@@ -185,6 +203,8 @@ class ThreadAllReduce:
 
         def fn(op, ptr, count, root):
             try:
+                if op == 5:      # end of an exchange: sends are eager here
+                    return 0
                 n = count * self.n if op == 2 else count
                 t = torch.as_tensor(_DevArray(ptr, n, "<f8"), device="cuda")
                 if op == 3:      # send: a private copy goes into the receiver's mailbox, no waiting

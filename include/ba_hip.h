@@ -374,8 +374,10 @@ int ba_hip_allreduce_host(ba_hip_engine* e, void* host, size_t count, int dtype)
  *          return chunk `rank` (at dev_ptr + rank * count) holds the sum over ranks of that chunk.
  * Same calling conventions as the all-reduce hook.  NULL = replicated solve. */
 typedef int (*ba_hip_collective_fn)(void* ctx, int op, void* dev_ptr, size_t count, int root);
-/* (ops 3 / 4 of the hook, used by the distributed solve since round 3: op 3 = send `count` doubles at
- * dev_ptr to rank `root`, must not block on the receiver; op 4 = receive `count` doubles from rank `root`.) */
+/* (ops 3 / 4 / 5 of the hook, used by the distributed solve since round 3: op 3 = send `count` doubles at
+ * dev_ptr to rank `root`, must not block on the receiver (copy or defer); op 4 = receive `count` doubles from rank
+ * `root`; op 5 (dev_ptr NULL) = end of one exchange: every send handed over since the last op 5 has been started.
+ * The engine issues all sends of an exchange, then all receives, then op 5.) */
 int ba_hip_set_collectives(ba_hip_engine* e, ba_hip_collective_fn fn, void* ctx);
 /* Native communicator: the engine loads librccl itself (one process per GPU, RCCL over xGMI) and
  * runs every cross-shard sum and the collectives of the distributed reduced solve on an
