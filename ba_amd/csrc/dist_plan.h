@@ -129,6 +129,10 @@ struct DistPanel {
   // per rank: the row tiles it owns below the square — block J+1 (urgent) / the others — as ranges of `tiles`
   std::vector<uint32_t> own_u_first, own_u_count, own_r_first, own_r_count;
   std::vector<uint32_t> msgs;   // indices into DistPlan::msgs; urgent ones first
+  // per rank: does its update of column block J+1 with this panel use a row another rank computed and sent on the side
+  // stream?  (never in the row layout: a block row never changes hands — the panel stream then runs ahead of the side
+  // transfers)
+  std::vector<uint8_t> next_needs_side;
 };
 
 struct DistPlan {
@@ -170,6 +174,12 @@ inline DistPlan build_dist_plan(uint32_t nblk, const OwnMap& map, const uint8_t*
       if (!on) continue;
       const uint32_t r = n > 1 ? map.tbl[(i / G) % T][J % T] : 0;
       (i / G == J + 1 ? own_u[r] : own_r[r]).push_back(i);
+    }
+    pn.next_needs_side.assign(n, 0);
+    for (uint32_t i = std::min(pn.c1 + G, nblk); i < nblk; ++i) {
+      if (n <= 1) break;
+      const uint32_t upd = map.tbl[(i / G) % T][(J + 1) % T], src = map.tbl[(i / G) % T][J % T];
+      if (upd != src) pn.next_needs_side[upd] = 1;
     }
     pn.own_u_first.assign(n, 0); pn.own_u_count.assign(n, 0);
     pn.own_r_first.assign(n, 0); pn.own_r_count.assign(n, 0);

@@ -1806,7 +1806,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     if ((rc = run_messages(false, s1, s3, e->dist_ssend.p, e->dist_srecv.p, EV(J, 1)))) break;
     BAE_HIP(hipEventRecord(EV(J, 2), s3));
     // ---- panel stream: panel J applied to the own tiles of column block J+1 below its square ------------
-    BAE_HIP(hipStreamWaitEvent(s1, EV(J, 2), 0));
+    if (pn.next_needs_side[rank] || own.n <= 1) BAE_HIP(hipStreamWaitEvent(s1, EV(J, 2), 0));  // rows received on the side stream
     if (J > 0) BAE_HIP(hipStreamWaitEvent(s1, EV(J - 1, 4), 0));
     if (n1 < nblk) {
       const uint32_t ncols = n1 - c1, m = nblk - n1;

@@ -108,7 +108,9 @@ def model(layout, N):
             if rows_r:
                 colop = ktiles[c1:n1].astype(np.float64)            # operand tiles of the column block
                 prod = float((ktiles[rows_r].astype(np.float64) @ colop.T).sum())
-            t = max(s1[r], t_side[r], ev_bulk_prev[r]) + prod * 2.0 * NB ** 3 / RECT_RATE
+            # (the wait for the side transfer only where a row of it was computed elsewhere: never in the row layout)
+            side_dep = any(own(blk[i], J) != r for i in rows_r)
+            t = max(s1[r], t_side[r] if side_dep else 0.0, ev_bulk_prev[r]) + prod * 2.0 * NB ** 3 / RECT_RATE
             s1[r] = t; ev_next[r] = t
         # bulk stream
         if n1 < nblk:
