@@ -366,12 +366,15 @@ int ba_hip_set_allreduce(ba_hip_engine* e, ba_hip_allreduce_fn fn, void* ctx, in
 int ba_hip_allreduce_host(ba_hip_engine* e, void* host, size_t count, int dtype);
 /* Collectives hook (optional, on top of the all-reduce hook): with it the dense reduced solve
  * is DISTRIBUTED over the shards instead of replicated:
- * the partial S of every shard is reduce-scattered to the owners of its column panels (256 / 512 / 1024 columns by system size)
- * (panel p belongs to rank p mod nranks), every panel is factorised by its owner and broadcast,
- * and each rank applies the trailing updates to the panels it owns.
+ * S is cut into blocks of G x G 64-tiles (G = 4 / 8 / 16 by system size) owned by the ranks through a small class
+ * table (ba_amd/csrc/dist_plan.h: "tri" / "grid" / "col" / "row" layouts); the partial S of every shard reaches the
+ * block owners point to point (only the rectangles the shard's own pattern touches), the owner of a diagonal block
+ * factorises the panel's square and broadcasts it, the block rows under it travel point to point to the ranks that
+ * multiply them, and each rank applies the trailing updates to the tiles it owns.
  *   op 1 = broadcast `count` doubles at dev_ptr from rank `root`;
  *   op 2 = reduce-scatter (sum), in place: dev_ptr holds nranks chunks of `count` doubles, on
- *          return chunk `rank` (at dev_ptr + rank * count) holds the sum over ranks of that chunk.
+ *          return chunk `rank` (at dev_ptr + rank * count) holds the sum over ranks of that chunk
+ *          (BA_HIP_DENSE_SCATTER=1 and single-rank communicators only);
  * Same calling conventions as the all-reduce hook.  NULL = replicated solve. */
 typedef int (*ba_hip_collective_fn)(void* ctx, int op, void* dev_ptr, size_t count, int root);
 /* (ops 3 / 4 / 5 of the hook, used by the distributed solve since round 3: op 3 = send `count` doubles at
