@@ -1159,15 +1159,17 @@ def test_large_system_properties():
     assert h.summary().proj_error < e0
 
 
-def test_config1_scale_step_matches_oracle(oracle_lib):
+@pytest.mark.parametrize("lm_dim", [1, 3])
+def test_config1_scale_step_matches_oracle(oracle_lib, lm_dim):
     """BASELINE.json configs[1] (1k poses / 100k landmarks / 1M residuals) against the oracle on
     the same scene: the Gauss-Newton step of the first iteration — north_star's parity bar is
-    1e-6 relative on delta_x.  The oracle needs ~7 s for its dense LDL^T."""
+    1e-6 relative on delta_x.  The oracle needs ~7 s for its dense LDL^T.  LmSize 1 (the reference's
+    instantiation: inverse depth in a reference pose) and LmSize 3 (world points, north_star's 6x3 / 3x3 blocks)."""
     po = oracle_lib
-    sc = scene.make_scene(1000, 100000, 10, lm_dim=1, seed=2)
+    sc = scene.make_scene(1000, 100000, 10, lm_dim=lm_dim, seed=2)
     pa = np.ones(sc.num_poses, dtype=np.uint8)
     pa[sc.anchor_poses] = 0
-    o, h = both(po, sc, 1, active=pa, apply_results=0, write_reduced_camera_matrix=0)
+    o, h = both(po, sc, lm_dim, active=pa, apply_results=0, write_reduced_camera_matrix=0)
     o.Solve(1)
     h.Solve(1)
     so, sh = o.summary(), h.summary()
