@@ -1182,6 +1182,41 @@ def test_config1_scale_step_matches_oracle(oracle_lib, lm_dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["config2_gn", "config4_dogleg"])
+def test_visual_inertial_at_the_largest_size_the_oracle_follows(oracle_lib, kind):
+    """BASELINE.json configs[2] / configs[4] at the size of bench.py's CPU-baseline sample and a bit beyond what the
+    miniatures cover: 400 poses / 20k landmarks / 200k residuals + 399 IMU pre-integration residuals, PoseSize 15
+    (n = 6000, 94 tiles: tile-sparse factorisation, look-ahead, k_imu in its wavefront form) — Gauss-Newton, or with
+    unary priors + binary odometry and the dogleg trust region.  One Solve(1) against the oracle: result code, every
+    error sum, the pose step to north_star's 1e-6, the state."""
+    po = oracle_lib
+    P = 400
+    dog = 1 if kind == "config4_dogleg" else 0
+    sc = scene.make_scene(P, 20000, 10, lm_dim=1, seed=2)
+    scene.add_inertial(sc, period=60.0 * P / 100.0)
+    objs = []
+    for cls, opts in ((po.OracleBundleAdjuster, gn_options(po, use_dogleg=dog)),
+                      (adjuster.BundleAdjuster, hip_options(use_dogleg=dog, write_reduced_camera_matrix=0))):
+        b = cls(1, 15)
+        b.Init(opts)
+        scene.populate(b, sc, imu=True, priors=bool(dog), unary_every=20)
+        objs.append(b)
+    o, h = objs
+    o.Solve(1)
+    h.Solve(1)
+    so, sh = o.summary(), h.summary()
+    assert so.result == sh.result
+    for name in ("proj_error", "inertial_error", "unary_error", "binary_error", "delta_norm"):
+        a, b_ = getattr(so, name), getattr(sh, name)
+        assert abs(a - b_) <= 1e-6 * max(abs(a), 1e-9), (name, a, b_)
+    if dog:
+        assert abs(so.trust_region_size - sh.trust_region_size) <= 1e-6 * abs(so.trust_region_size)
+    assert rel_err(h.delta_p(), o.delta_p()) < 1e-6
+    _state_close(o, h, 1e-6)
+    print("%s at n = %d: delta_p rel err %.2e" % (kind, 15 * P, rel_err(h.delta_p(), o.delta_p())))
+
+
+@pytest.mark.gpu
 def test_blocked_128_trailing_update_on_small_systems():
     """k_update128 (the 128x128 trailing-update kernel, its row-mode companion launch, its
     indefinite fallback and the ownership filter of the distributed solve) normally only runs on
