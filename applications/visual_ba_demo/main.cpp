@@ -12,18 +12,56 @@
 //   visual_ba_demo --calibrate-fov          ba::SelfCalBundleAdjuster<double> = <double, 1, 6, 5> (reference
 //                                           BundleAdjuster.h:758-759) on a ba::FovCamera whose five parameters
 //                                           (fx, fy, u0, v0, w) start 2-4 % off
+//   visual_ba_demo --ranks N --rank R --comm-id-file F [--device D]
+//                                           one process per GPU: every process holds all poses and the landmarks
+//                                           l with l mod N == R; the class joins the engine-owned RCCL communicator
+//                                           (SetCommunicator; rank 0 writes the 128-byte id to F, the others wait for
+//                                           it) and the reduced solve is distributed over the GPUs — no torch, no hooks
 #include <ba/BundleAdjuster.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
+#include <thread>
+
+struct Shard { int rank = 0, ranks = 1, device = 0; std::string id_file; };
+
+// rank 0 creates the communicator id and publishes it through a file; the other ranks wait for it
+static bool exchange_id(const Shard& sh, unsigned char* id) {
+  if (sh.rank == 0) {
+    if (!ba::BundleAdjuster<double, 1, 6, 0>::CreateCommunicatorId(id)) return false;
+    const std::string tmp = sh.id_file + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f || std::fwrite(id, 1, 128, f) != 128) return false;
+    std::fclose(f);
+    return std::rename(tmp.c_str(), sh.id_file.c_str()) == 0;
+  }
+  for (int tries = 0; tries < 600; ++tries) {
+    if (FILE* f = std::fopen(sh.id_file.c_str(), "rb")) {
+      const size_t n = std::fread(id, 1, 128, f);
+      std::fclose(f);
+      if (n == 128) return true;
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+  }
+  return false;
+}
 
 template <class BA>
-int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics, 3 the five parameters of a FOV camera
+int run(int calibrate, const Shard& shard = Shard()) {  // 0 none, 1 intrinsics, 2 extrinsics, 3 the five parameters of a FOV camera
   BA adjuster;
   ba::Options<double> options;  // reference defaults: dogleg, robust norm, auto regularisation
   options.error_change_threshold = 1e-5;
+  options.device = shard.device;
+  if (!shard.id_file.empty()) {
+    unsigned char id[128];
+    if (!exchange_id(shard, id)) { std::printf("communicator id exchange failed\n"); return 3; }
+    adjuster.SetCommunicator(id, shard.rank, shard.ranks);
+  }
   const int kPoses = 24, kLandmarks = 300;
   adjuster.Init(options, kPoses, kLandmarks * 6, kLandmarks);
   const double fx = 198.969, fy = 198.1284, u0 = 329.9368, v0 = 240.1017, fov_w = 0.93;
@@ -123,15 +161,20 @@ int run(int calibrate) {  // 0 none, 1 intrinsics, 2 extrinsics, 3 the five para
       apply(gt[ref] * mount0, xs, xw);
       for (int k = 0; k < 3; ++k) Xp[k] = xw[k];
     }
-    const uint32_t lm = adjuster.AddLandmark(ba::Vector4t({Xp[0], Xp[1], Xp[2], Xp[3]}), ref, 0, true);
+    // landmark shards: every rank draws the same scene, a rank keeps the landmarks l with l mod ranks == rank
+    const bool mine = (l % shard.ranks) == shard.rank;
+    const uint32_t lm = mine ? adjuster.AddLandmark(ba::Vector4t({Xp[0], Xp[1], Xp[2], Xp[3]}), ref, 0, true) : 0;
     for (int i = 0; i < kPoses; ++i) {
       if (!project(gt[i], X, uv)) continue;
       const ba::Vector2t z({uv[0] + 0.5 * n01(rng), uv[1] + 0.5 * n01(rng)});
-      if (adjuster.AddProjectionResidual(z, i, lm, 0) != (uint32_t)-1) ++n_res;
+      if (mine && adjuster.AddProjectionResidual(z, i, lm, 0) != (uint32_t)-1) ++n_res;
     }
   }
   std::printf("poses %u landmarks %u residuals %d\n", adjuster.GetNumPoses(), adjuster.GetNumLandmarks(), n_res);
   adjuster.Solve(1);
+  if (!shard.id_file.empty())
+    std::printf("rank %d of %d on device %d: reduced solve %s\n", shard.rank, shard.ranks, shard.device,
+                adjuster.SolveIsDistributed() ? "distributed over the communicator" : "replicated");
   double e0, eu, eb, ei;
   adjuster.GetErrors(e0, eu, eb, ei);
   if (!adjuster.GetSolutionSummary().IsResultGood()) { std::printf("Solve failed\n"); return 2; }
@@ -173,5 +216,13 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::strcmp(argv[1], "--calibrate-intrinsics") == 0) return run<ba::BundleAdjuster<double, 1, 6, 4, false>>(1);
   if (argc > 1 && std::strcmp(argv[1], "--calibrate-extrinsics") == 0) return run<ba::BundleAdjuster<double, 1, 6, 0, true>>(2);
   if (argc > 1 && std::strcmp(argv[1], "--calibrate-fov") == 0) return run<ba::SelfCalBundleAdjuster<double>>(3);
-  return run<ba::BundleAdjuster<double, 1, 6, 0>>(0);  // VisualBundleAdjuster<double>
+  Shard shard;
+  for (int i = 1; i + 1 < argc; i += 2) {
+    if (std::strcmp(argv[i], "--ranks") == 0) shard.ranks = std::atoi(argv[i + 1]);
+    else if (std::strcmp(argv[i], "--rank") == 0) shard.rank = std::atoi(argv[i + 1]);
+    else if (std::strcmp(argv[i], "--device") == 0) shard.device = std::atoi(argv[i + 1]);
+    else if (std::strcmp(argv[i], "--comm-id-file") == 0) shard.id_file = argv[i + 1];
+  }
+  if (shard.ranks < 1 || shard.rank < 0 || shard.rank >= shard.ranks) { std::printf("bad --rank / --ranks\n"); return 3; }
+  return run<ba::BundleAdjuster<double, 1, 6, 0>>(0, shard);  // VisualBundleAdjuster<double>
 }

@@ -435,6 +435,25 @@ def test_cpp_application_runs_on_the_engine(mode):
     assert "proj error" in r.stdout
 
 
+def test_cpp_application_joins_the_native_communicator(tmp_path):
+    """applications/visual_ba_demo --ranks 1 --rank 0 --comm-id-file F: a plain C++ program on the class's
+    SetCommunicator — id created and published by rank 0, the engine-owned RCCL communicator joined inside Solve(),
+    the reduced solve distributed (one rank on this box; on a node: one process per GPU with --rank R --device R)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ba_amd", "lib", "visual_ba_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, "--ranks", "1", "--rank", "0", "--comm-id-file", str(tmp_path / "comm.id")],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "reduced solve distributed over the communicator" in r.stdout and "proj error" in r.stdout
+    plain = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    # the same scene without a communicator ends at the same error
+    last = lambda out: [ln for ln in out.splitlines() if ln.startswith("proj error")][-1]
+    assert last(r.stdout).split("worst")[0] == last(plain.stdout).split("worst")[0] or \
+        abs(float(last(r.stdout).split("after 9 ")[1].split(",")[0]) - float(last(plain.stdout).split("after 9 ")[1].split(",")[0])) < 1e-6
+
+
 def test_pose_graph_application_with_interpolation_buffer(oracle_lib, tmp_path):
     """applications/unary_binary_imu_test — the reference's GPS + IMU pose-graph program
     (BundleAdjuster<double,0,9,0>, `ODO` / `UTM` / `IMU` log parser, gyro dead reckoning, unary
