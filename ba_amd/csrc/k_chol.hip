@@ -60,7 +60,10 @@ static const int LDM = 18;  // LDS row stride of the 16x16 diagonal inverses
 //   * the accumulators start at zero and the C tile is fetched after the loop;
 //   * 37 KB of LDS per workgroup, four workgroups per CU.
 static const int KC2 = 16;
-static const int LDK2 = KC2 + 2;
+#ifndef BAE_LDK2            // (measurement builds: LDS row stride of the operand stages)
+#define BAE_LDK2 (KC2 + 2)
+#endif
+static const int LDK2 = BAE_LDK2;
 
 // Fast path of update_tile — a full 64-row tile and no negative pivot in the K range (every tile
 // of an SPD system except the rhs row).  Hand-scheduled:
@@ -484,7 +487,11 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   const size_t ld32 = (size_t)32 * ld;
   double2 px[4], py[4];
   double FA0[4], FB0[4], FA1[4], FB1[4];
+#ifdef BAE_NO_SCHED_PINS_128   // (measurement builds: the compiler schedules the 128x128 loop freely)
+#define BAE_SB
+#else
 #define BAE_SB __builtin_amdgcn_sched_barrier(0)
+#endif
 // (BAE_KMASK: measurement builds only — 63 makes every operand chunk come from tile column 0, i.e. from the L2 /
 // Infinity Cache: wrong numbers, the kernel's rate without HBM misses; scratch/gpu_r03_ceiling.sh)
 #ifndef BAE_KMASK
