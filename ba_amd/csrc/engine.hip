@@ -1476,6 +1476,15 @@ int ba_hip_get_structure_stats(ba_hip_engine* h, ba_hip_structure_stats* out) {
         out->tiles_S += e->nzS_host[i * nt + k] ? 1 : 0;
         out->tiles_L += e->nzL_host[i * nt + k] ? 1 : 0;
       }
+  if (e->nzL_valid && e->nzL_host.size() == nt * nt) {
+    // column k with m_k structurally nonzero tiles below the diagonal: m_k (m_k + 1) / 2 update products, m_k / 2
+    // substitution products (a triangular 64x64 solve is half a product), + the rhs row (m_k + 1 products)
+    for (uint64_t k = 0; k < nt; ++k) {
+      uint64_t m = 0;
+      for (uint64_t i = k + 1; i < nt; ++i) m += e->nzL_host[i * nt + k] ? 1 : 0;
+      out->factor_tile_products += m * (m + 1) / 2 + (m + 1) / 2 + m + 1;
+    }
+  }
   return 0;
 }
 

@@ -65,7 +65,8 @@ class KernelStats(C.Structure):
 class StructureStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("poses_active", "landmarks_active", "observations", "incidences",
                                           "factor_rows", "pair_blocks", "pair_entries", "tiles_lower",
-                                          "tiles_S", "tiles_L", "tile_refs", "pose_entries", "linearize_waves")]
+                                          "tiles_S", "tiles_L", "tile_refs", "pose_entries", "linearize_waves",
+                                          "factor_tile_products")]
 
 
 class CommStats(C.Structure):

@@ -536,7 +536,13 @@ def main():
                          "traffic_source": ("%s (rocprofv3 --pmc, bytes per launch)" % pmc_file) if pmc_file else None,
                          "flops_per_launch": ks.syrk_flops / max(ks.syrk_launches, 1),
                          "launches": ks.syrk_launches,
-                         "avg_launch_us": 1e3 * ks.syrk_ms / max(ks.syrk_launches, 1)},
+                         "avg_launch_us": 1e3 * ks.syrk_ms / max(ks.syrk_launches, 1),
+                         # the WHOLE reduced solve (bulk updates + the chain they share the matrix pipes with): every
+                         # tile product of the factorisation on the tile pattern over the `solve` phase of the last step
+                         "solve_total": ({"flops": stats["factor_tile_products"] * 2.0 * 64 ** 3, "ms": timers.get("solve", 0.0),
+                                          "achieved": stats["factor_tile_products"] * 2.0 * 64 ** 3 / (timers["solve"] * 1e-3) / 1e12,
+                                          "frac": stats["factor_tile_products"] * 2.0 * 64 ** 3 / (timers["solve"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF}
+                                         if stats and stats.get("factor_tile_products") and timers.get("solve", 0) > 0 else None)},
             "hbm_kernels": {
                 # achieved_GBs: algorithmic bytes / live launch time; pmc_traffic_bytes: what the kernel
                 # really moved, from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE: the guide's

@@ -336,6 +336,8 @@ typedef struct {
   uint64_t tile_refs;         /* (tile, block) references of the tile assembly (straddling blocks count twice) */
   uint64_t pose_entries;      /* terms of the diagonal blocks / right-hand sides (12 bytes each) */
   uint64_t linearize_waves;   /* wavefronts of the linearisation kernel */
+  uint64_t factor_tile_products; /* 64x64x64 tile products of the tile-sparse LDL^T on the factor's pattern (trailing
+                                    updates + substitutions; x 2 * 64^3 flop each): the flops of one reduced solve */
 } ba_hip_structure_stats;
 int ba_hip_get_structure_stats(ba_hip_engine* e, ba_hip_structure_stats* out);
 /* Experiment knobs for scratch/ micro-benchmarks (kernel variants with identical results): key 1 =
