@@ -186,6 +186,15 @@ struct Engine {
 
   // ---- device: per-iteration
   DBuf<double> obs_e, obs_w;             // error for the median, robust weight
+  // err_cache: |r|^2 * original weight per observation at the state held in buffer 0 / 1, left behind by the last
+  // EvaluateResiduals at that state (k_residuals mode 1); ba_hip_linearize takes its Huber median from it instead of
+  // running the error pass again.  Invalidated by everything that changes a state buffer or the cameras; off with
+  // calibration unknowns (the camera moves with the step) and on request (BA_HIP_NO_ERR_CACHE).
+  DBuf<double> obs_e_state[2];
+  bool obs_e_valid[2] = {false, false};
+  bool err_cache_on() const { return calib_dim == 0 && !err_cache_off; }
+  bool err_cache_off = false;
+  void err_cache_clear() { obs_e_valid[0] = obs_e_valid[1] = false; }
   DBuf<double> obs_jl;                   // [O][2*lm] sqrt(w) * dz_dlm (dogleg J_l * rhs_l)
   DBuf<double> diag_blocks;              // [Pact][36] diagonal blocks of S (k_pose_blocks -> k_write_diag)
   DBuf<double> crow;                     // [n_scalars][6] calibration rows, indexed like `scal`: sqrt(w) dz_dtvs

@@ -492,7 +492,7 @@ void ba_hip_destroy(ba_hip_engine* h) {
   REL(packed); REL(nzL); REL(dist_msg); REL(dist_rows); REL(dist_srows);
   REL(dist_tiles); REL(dist_sq_list); REL(dist_pairs); REL(dist_sp_srect); REL(dist_sp_rrect); REL(dist_usend); REL(dist_urecv); REL(dist_ssend); REL(dist_srecv); REL(dist_back);
   for (int b = 0; b < 2; ++b) { REL(pose_state[b]); REL(lm_x[b]); REL(lm_reliable[b]); }
-  REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_jl);
+  REL(lm_xw); REL(tsw); REL(tws); REL(twp); REL(lm_outliers); REL(obs_e); REL(obs_w); REL(obs_e_state[0]); REL(obs_e_state[1]); REL(obs_jl);
   REL(frow); REL(diag_blocks); REL(scal); REL(lm_vinv); REL(lm_bl); REL(A); REL(A_keep); REL(rhs_p); REL(rhs_sc); REL(gn_p);
   REL(gn_l); REL(step_p); REL(step_l); REL(invdiag); REL(partials); REL(scalars_out); REL(hist);
   REL(flags); REL(pivot_floor);
@@ -560,6 +560,7 @@ int ba_hip_get_camera_fov(ba_hip_engine* h, uint32_t n, double* w) {
 
 int ba_hip_set_pose_cam_params(ba_hip_engine* h, uint32_t n, const double* params4) {
   ENG(h);
+  e->err_cache_clear();   // (uploaded without a rebuild: the residuals change)
   if (n == 0 || !params4) {
     e->prob.pose_cam_params.clear();
     return 0;
@@ -853,6 +854,7 @@ int ba_hip_set_gravity(ba_hip_engine* h, const double g3[3]) {
 int ba_hip_finalize(ba_hip_engine* h) {
   ENG(h);
   e->dog_jrhs_valid = false;  // the factor rows are rebuilt: no cached sum survives
+  e->err_cache_clear();
   BAE_HIP(hipSetDevice(e->device));
   Problem& pb = e->prob;
   if (pb.pose_active.size() != pb.num_poses) pb.pose_active.assign(pb.num_poses, 1);
@@ -882,6 +884,8 @@ int ba_hip_begin_solve(ba_hip_engine* h) {
   ENG(h);
   NEED_FINAL();
   e->dog_jrhs_valid = false;
+  e->err_cache_clear();   // x_s is re-derived from x_w, the cameras may have been re-uploaded
+  e->err_cache_off = getenv("BA_HIP_NO_ERR_CACHE") != nullptr;
   BAE_HIP(hipSetDevice(e->device));
   if (!e->prob.pose_cam_params.empty() && e->prob.pose_cam_params.size() != 4 * (size_t)e->prob.num_poses)
     return e->fail_msg("per-pose camera parameters: one [fx,fy,u0,v0] per pose expected");
@@ -920,7 +924,10 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   // projection errors at the linearisation point -> Huber sigma
   EventTimer t_j(e);
   if ((rc = launch_pose_prep(e))) return rc;
-  if ((rc = launch_residuals(e, 0))) return rc;
+  // the errors of the Huber median: left by the last EvaluateResiduals at this state, or computed now
+  const bool cached = e->err_cache_on() && e->obs_e_valid[e->cur] && e->obs_e_state[e->cur].n >= st.O && st.O > 0;
+  const double* med_in = cached ? e->obs_e_state[e->cur].p : e->obs_e.p;
+  if (!cached && (rc = launch_residuals(e, 0))) return rc;
   t_j.mark();
   EventTimer t_r(e);
   double c_huber = 0.0;
@@ -935,7 +942,7 @@ int ba_hip_linearize(ba_hip_engine* h, ba_hip_errors* out) {
   if (n_total > 0) {
     double med = 0.0;
     // std::nth_element at floor(N * 0.5): the upper median (BundleAdjuster.cpp:1356-1358)
-    if ((rc = select_kth(e, e->obs_e.p, st.O, (uint64_t)std::floor(n_total * 0.5), &med))) return rc;
+    if ((rc = select_kth(e, med_in, st.O, (uint64_t)std::floor(n_total * 0.5), &med))) return rc;
     c_huber = 1.2107 * std::sqrt(med);
   }
   t_r.mark();
@@ -1079,6 +1086,7 @@ int ba_hip_apply_step(ba_hip_engine* h) {
   if (rc) return rc;
   e->cur = 1 - e->cur;
   e->has_snapshot = true;
+  e->obs_e_valid[e->cur] = false;   // a new state in this buffer: no evaluation of it yet
   if (e->calib_dim && !e->calib_tvs && e->st.C > 0) {
     // BundleAdjuster.cpp:46-69: params of camera 0 -= delta_k, then every x_s ray is re-derived from
     // the landmark's reference pixel with the new parameters, keeping its length

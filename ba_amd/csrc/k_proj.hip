@@ -145,7 +145,8 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
                             const double* __restrict__ tsw,
                             const double* __restrict__ tws, double* __restrict__ err,
                             uint32_t* __restrict__ lm_outliers, double* __restrict__ partials,
-                            const uint8_t* __restrict__ cond) {
+                            const uint8_t* __restrict__ cond, const double* __restrict__ w0,
+                            double* __restrict__ err0) {
   __shared__ double red[256];
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   double val = 0.0;
@@ -169,8 +170,11 @@ __global__ void k_residuals(int O, int C, int mode, double outlier_thr,
       err[a] = val;
     } else if (mode == 2) {
       val = cond[a] ? sq : 0.0;  // conditioning residuals: |residual|^2, unweighted (BundleAdjuster.cpp:700-703)
-    } else if (sqrt(sq) > outlier_thr) {
-      atomicAdd(&lm_outliers[l], 1u);
+    } else {
+      // EvaluateResiduals also leaves |r|^2 * original weight — the input of the NEXT linearisation's Huber median at
+      // this very state (mode 0 computes the same product): that pass is then skipped (engine.hip: err_cache)
+      if (err0) err0[a] = sq * w0[a];
+      if (sqrt(sq) > outlier_thr) atomicAdd(&lm_outliers[l], 1u);
     }
   }
   if (mode >= 1) {
@@ -241,11 +245,18 @@ int launch_residuals(Engine* e, int mode) {
   const dim3 grid((O + 255) / 256), block(256);
   if (mode == 1) BAE_HIP(hipMemsetAsync(e->lm_outliers.p, 0, e->lm_outliers.bytes(), e->stream));
   const double* w = mode == 0 ? e->obs_w0.p : e->obs_w.p;
+  // mode 1 at the state in buffer `cur`: the median input of a linearisation at that state rides along
+  double* err0 = nullptr;
+  if (mode == 1 && e->err_cache_on()) {
+    BAE_HIP(e->obs_e_state[e->cur].alloc(std::max<size_t>((size_t)O, 1)));
+    err0 = e->obs_e_state[e->cur].p;
+    e->obs_e_valid[e->cur] = true;
+  }
 #define BAE_ARGS                                                                          \
   O, (int)e->st.C, mode, e->opt.projection_outlier_threshold, e->obs_z.p, e->obs_pose.p,  \
       e->obs_cam.p, e->obs_lm.p, w, e->lm_x[e->cur].p, e->lm_ref_pose.p, e->lm_ref_cam.p, \
       e->cam.p, e->pose_cam_ptr(), e->tsw.p, e->tws.p, e->obs_e.p, e->lm_outliers.p, e->partials.p,     \
-      (const uint8_t*)e->obs_cond.p
+      (const uint8_t*)e->obs_cond.p, (const double*)e->obs_w0.p, err0
   if (e->has_fov) {
     if (e->lm_dim == 1) hipLaunchKernelGGL((k_residuals<1, true>), grid, block, 0, e->stream, BAE_ARGS);
     else hipLaunchKernelGGL((k_residuals<3, true>), grid, block, 0, e->stream, BAE_ARGS);
