@@ -527,6 +527,10 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
     if (NEXT) BAE_LDF(FA0, FB0, ((J) + 1) & 1, 0);                                   \
     BAE_SB; BAE_MM(FA1, FB1); BAE_SB;                                                \
   }
+#ifdef BAE_TIME128   // measurement build: cycle stamps of one workgroup in 257 (scratch/gpu_r03_time128.sh)
+  const unsigned long long tt0 = __builtin_readcyclecounter();
+  const int tt_cols = __builtin_popcountll(mask);
+#endif
   uint32_t kcur = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
   mask &= mask - 1;
   BAE_GLOAD(kcur);
@@ -534,6 +538,9 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   BAE_GLOAD(kcur + KC2);
   __syncthreads();
   BAE_LDF(FA0, FB0, 0, 0);
+#ifdef BAE_TIME128
+  const unsigned long long tt1 = __builtin_readcyclecounter();
+#endif
   while (mask) {
     const uint32_t knext = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
     mask &= mask - 1;
@@ -564,6 +571,9 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   BAE_CHUNK(1, true, BAE_GLOAD(kcur + 3 * KC2), true);
   BAE_CHUNK(2, true, , true);
   BAE_CHUNK(3, false, BAE_CLOAD(cva, 0), false);
+#ifdef BAE_TIME128
+  const unsigned long long tt2 = __builtin_readcyclecounter();
+#endif
   if (diag && wave == 1) return;  // the strictly upper 64-tile of a diagonal block (computed, not stored)
   BAE_SB;
   BAE_CLOAD(cvb, 1);
@@ -578,6 +588,13 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   BAE_SB;
   BAE_CSTORE(cva, 2);
   BAE_CSTORE(cvb, 3);
+#ifdef BAE_TIME128
+  if (tid == 0 && (blockIdx.x % 257u) == 100u && !RECT) {
+    const unsigned long long tt3 = __builtin_readcyclecounter();
+    printf("T128 cols %d prologue %llu loop %llu epilogue %llu per_chunk %llu\n", tt_cols, tt1 - tt0, tt2 - tt1, tt3 - tt2,
+           (tt2 - tt1) / (unsigned long long)(4 * tt_cols));
+  }
+#endif
 #undef BAE_CLOAD
 #undef BAE_CSTORE
 #undef BAE_SB
