@@ -793,6 +793,8 @@ __device__ __forceinline__ void subst_rows(double4_t R[4], const double op[NOPV]
   }
 }
 
+// FACTOR = false: every tile takes the plain update (the diagonal tiles are factorised by k_square)
+template <bool FACTOR>
 __global__ void __launch_bounds__(256, 2)
 k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t kb0,
               uint32_t kb1, double* __restrict__ dsgn, double* __restrict__ opbuf,
@@ -809,7 +811,7 @@ k_step_update(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, u
   // rowlist (distributed solve): the row tiles this rank works on, ascending, instead of all rows from c on
   const uint32_t i = rowlist ? rowlist[blockIdx.x] : c + blockIdx.x;
   if (i > nblk || i >= row_end || i < c) return;  // row_end: rows from there on belong to a k_update128 launch
-  const bool special = (i == c0 && c == c0);  // the diagonal tile (c0,c0): first workgroup of the launch
+  const bool special = FACTOR && (i == c0 && c == c0);  // the diagonal tile (c0,c0): first workgroup of the launch
   if (!special) {  // every other tile: the plain trailing update
     update_tile(A, ld, nblk, i, c, kb0, kb1, dsgn, colneg, nz, u.X, u.Y, klist);
     return;
@@ -942,6 +944,367 @@ k_trsm_op(double* __restrict__ A, uint32_t ld, uint32_t d, uint32_t nblk,
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + lk + 4 * reg] = R[c][reg];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Small systems (chain-bound: 94 tile columns at configs[1]): the diagonal SQUARE of a sub-panel — w <= 4
+// tile columns, the lower triangle of w x w tiles — is factorised by ONE workgroup that never leaves the CU
+// between its tile columns: no launch and no packet round trip between the factorisation of tile d, the
+// substitution of the tiles below it and the update that completes tile d + 1.  Per tile column d = J + j:
+//   factor   wave 0 factorises the diagonal tile in LDS (factor_tile_wave0); the other waves have their
+//            strips of column d in flight meanwhile;
+//   phase A  the tiles (r, d) below it inside the square: X = A L^-T D, operands straight from LDS, a 16-row
+//            strip per task; X goes to global memory (the factor) and stays in LDS for phase B;
+//   phase B  right-looking: every remaining tile (r, c), d < c <= r, takes the K = 64 update with column d,
+//            operands from LDS, a 16-row strip per task, in the TRANSPOSED fragment layout of the
+//            substitution (target strip = C/D fragments, X(r, d) strip = B fragments, X(c, d) = A operands);
+//            the next diagonal tile (d+1, d+1) lands in LDS for its factorisation.
+// A strip (tile, quarter) belongs to ONE wave for the whole kernel (sq_owner): its read-modify-write sequence
+// through global memory is program order of that wave, so no barrier waits for a store to be acknowledged
+// (lds_barrier: LDS traffic only) and loads are issued a phase ahead of their use.
+// The factor packets, pivot signs and flags are published exactly as k_step_update does (k_rowpanel,
+// k_linvT and the trailing updates read them).  The tiles of the square must carry every earlier
+// panel's update when the kernel starts (k_step_update<false>).
+struct SquareLds {
+  TileLds t;
+  double X[3][NB][LDT];  // X(d+1.., d) of the current tile column
+};
+
+// workgroup barrier that orders LDS traffic only: global stores stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// substitution with the operands computed from the factorised tile in LDS (subst_rows reads a packet)
+__device__ __forceinline__ void subst_rows_lds(double4_t R[4], const TileLds& t, int li, int lk) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double4_t Zc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      Zc = __builtin_amdgcn_mfma_f64_16x16x4f64(subst_operand(t, 4 * c + ks, li, lk, true), R[c][ks], Zc, 0, 0, 0);
+#pragma unroll
+    for (int c2 = c + 1; c2 < 4; ++c2) {
+      const int pi = (c2 == 1 ? 0 : (c2 == 2 ? 1 : 3)) + c;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        R[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(subst_operand(t, 16 + 4 * pi + ks, li, lk, true), Zc[ks], R[c2], 0, 0, 0);
+    }
+    R[c] = Zc;
+  }
+}
+
+// Strip ownership: entry = r | c << 2 | q << 4 (tile (r, c) of the square, relative indices, quarter q), 255 = none.
+// SQ_A[wave][j]: the strips of column j below the diagonal tile (phase A of step j) — waves 1..7 only: wave 0
+// factorises meanwhile and holds nothing across the factorisation; SQ_B[wave][j]: the strips right of column j
+// (phase B of step j; the diagonal tiles' strips included).  At most two / three strips per wave and phase.
+__constant__ uint8_t SQ_A[8][4][2] = {{{255, 255}, {255, 255}, {255, 255}, {255, 255}}, {{1, 50}, {6, 55}, {255, 255}, {255, 255}}, {{17, 3}, {22, 255}, {11, 255}, {255, 255}}, {{33, 19}, {38, 255}, {27, 255}, {255, 255}}, {{49, 35}, {54, 255}, {43, 255}, {255, 255}}, {{2, 51}, {7, 255}, {59, 255}, {255, 255}}, {{18, 255}, {23, 255}, {255, 255}, {255, 255}}, {{34, 255}, {39, 255}, {255, 255}, {255, 255}}};
+__constant__ uint8_t SQ_B[8][4][3] = {{{5, 10, 15}, {10, 15, 255}, {15, 255, 255}, {255, 255, 255}}, {{6, 55, 58}, {58, 255, 255}, {255, 255, 255}, {255, 255, 255}}, {{22, 11, 63}, {11, 63, 255}, {63, 255, 255}, {255, 255, 255}}, {{21, 38, 27}, {27, 255, 255}, {255, 255, 255}, {255, 255, 255}}, {{37, 54, 43}, {43, 255, 255}, {255, 255, 255}, {255, 255, 255}}, {{53, 7, 59}, {59, 255, 255}, {255, 255, 255}, {255, 255, 255}}, {{23, 26, 31}, {26, 31, 255}, {31, 255, 255}, {255, 255, 255}}, {{39, 42, 47}, {42, 47, 255}, {47, 255, 255}, {255, 255, 255}}};
+
+__global__ void __launch_bounds__(512)
+k_square(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t w, double* __restrict__ dsgn,
+         double* __restrict__ opbuf, int* __restrict__ colneg, int* __restrict__ status,
+         const uint8_t* __restrict__ nz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sq_smem[];
+  SquareLds& sh = *reinterpret_cast<SquareLds*>(sq_smem);
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* floors = *reinterpret_cast<const double* const*>(status + 2);
+#ifdef BAE_TIME_SQ
+  const unsigned long long tsq_start = __builtin_readcyclecounter();
+#endif
+  {
+    const double* T0 = A + ((size_t)J * NB) * ld + (size_t)J * NB;
+    for (int el = tid; el < NB * NB; el += 512) {
+      const int r = el >> 6, c = el & 63;
+      sh.t.T[r][c] = (c <= r) ? T0[(size_t)r * ld + c] : 0.0;
+    }
+    if (tid == 0) sh.t.bad = 0;
+  }
+#ifdef BAE_TIME_SQ  // measurement build: cycle stamps of the phases (scratch/gpu_r03_square_time.sh)
+  __shared__ unsigned long long tsq[16];
+#define BAE_TSQ(k) if (tid == 0) tsq[k] = __builtin_readcyclecounter()
+#else
+#define BAE_TSQ(k)
+#endif
+  lds_barrier();
+#ifdef BAE_TIME_SQ
+  if (tid == 0) { tsq[0] = tsq_start; tsq[1] = __builtin_readcyclecounter(); }
+#endif
+#define BAE_SLOAD(R, ptr)                          \
+  _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) R[c_][g_] = (ptr)[16 * c_ + 4 * g_]
+#define BAE_SSTORE_G(R, ptr)                       \
+  _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) (ptr)[16 * c_ + 4 * g_] = R[c_][g_]
+  for (uint32_t j = 0; j < w; ++j) {
+    const uint32_t d = J + j, nb = w - 1 - j;  // nb: tiles below (d, d) inside the square
+    // (the lane index is made opaque per step: hoisted out of the loop, the address and predicate
+    // arithmetic of all four phases — 64 column predicates of the factorisation alone — would spill)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, lk = lane >> 4;
+    // strip `e` (table entry) in the fragment layout of the substitution: this lane's base address
+    auto strip_ptr = [&](uint32_t e) {
+      const uint32_t r = e & 3u, c = (e >> 2) & 3u, q = e >> 4;
+      return A + ((size_t)(J + r) * NB + 16 * q + li) * ld + (size_t)(J + c) * NB + lk;
+    };
+    // a table entry names a strip of THIS square (w < 4: the table of the 4-column square, filtered) whose
+    // tile is structurally nonzero
+    auto strip_on = [&](uint32_t e) {
+      if (e == 255u || (e & 3u) >= w) return false;
+      return !nz || nz[(size_t)(J + (e & 3u)) * nblk + J + ((e >> 2) & 3u)] != 0;
+    };
+    double4_t Ra[2][4];
+    uint32_t ea[2];
+    bool ona[2] = {false, false};
+    if (wave == 0) {
+      factor_tile_wave0(sh.t, lane, floors ? floors + (size_t)d * NB : nullptr);
+    } else {
+      // this wave's strips of column j: in flight while wave 0 factorises
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        ea[a] = SQ_A[wave][j][a];
+        ona[a] = strip_on(ea[a]);
+        if (ona[a]) {
+          const double* ptr = strip_ptr(ea[a]);
+          BAE_SLOAD(Ra[a], ptr);
+        }
+      }
+    }
+    lds_barrier();
+    BAE_TSQ(2 + 3 * j);
+    if (wave < 4) {  // the factor packet of tile column d
+      double* ob = opbuf + (size_t)d * NOPV * 64;
+#pragma unroll
+      for (int q = 0; q < NOPV / 4; ++q) {
+        const int v = wave * (NOPV / 4) + q;
+        ob[(size_t)v * 64 + lane] = subst_operand(sh.t, v, li, lk, true);
+      }
+    } else if (wave == 4) {
+      dsgn[(size_t)d * NB + lane] = sh.t.sg[lane];
+      if (lane == 0) colneg[d] = sh.t.neg;
+    }
+    if (nb == 0) break;  // (uniform)
+    // phase B's first strip: loaded now, the others one strip ahead of their update.  A strip whose tile is
+    // structurally zero is skipped, except the next diagonal tile's (it has to reach LDS).
+    // (w < 4: the entries of the 4-column table that lie outside the square are skipped)
+    int bslot = 0;
+    auto b_next = [&]() -> uint32_t {
+      while (bslot < 3) {
+        const uint32_t e = SQ_B[wave][j][bslot++];
+        if (e != 255u && (e & 3u) < w) return e;
+      }
+      return 255u;
+    };
+    double4_t Rb[4];
+    uint32_t eb = b_next();
+    if (eb != 255u) {
+      const double* ptr = strip_ptr(eb);
+      BAE_SLOAD(Rb, ptr);
+    }
+    // ---- phase A: substitution of this wave's strips of column d ----
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      if (ona[a]) {
+        const uint32_t t = (ea[a] & 3u) - j - 1, q = ea[a] >> 4;
+        subst_rows_lds(Ra[a], sh.t, li, lk);
+        double* ptr = strip_ptr(ea[a]);
+        BAE_SSTORE_G(Ra[a], ptr);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) sh.X[t][16 * q + li][16 * c + lk + 4 * reg] = Ra[a][c][reg];
+      }
+    }
+    lds_barrier();
+    BAE_TSQ(3 + 3 * j);
+    // ---- phase B: column d applied to this wave's strips of the rest of the square ----
+    while (eb != 255u) {
+      const uint32_t en = b_next();
+      double4_t Rn[4];
+      if (en != 255u) {  // next strip: its loads are issued before this one's MFMAs
+        const double* ptr = strip_ptr(en);
+        BAE_SLOAD(Rn, ptr);
+      }
+      const uint32_t rr = eb & 3u, cr = (eb >> 2) & 3u, q = eb >> 4;
+      const uint32_t tr = rr - j - 1, tc = cr - j - 1;
+      const bool next_diag = rr == j + 1;  // (then cr == j + 1 too)
+      const bool on = !nz || (nz[(size_t)(J + rr) * nblk + d] && nz[(size_t)(J + cr) * nblk + d]);
+      if (on) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int kk = 16 * cc + 4 * reg + lk;
+            const double b = sh.X[tr][16 * q + li][kk];
+            const double nsg = -sh.t.sg[kk];
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp)
+              Rb[cp] = __builtin_amdgcn_mfma_f64_16x16x4f64(nsg * sh.X[tc][16 * cp + li][kk], b, Rb[cp], 0, 0, 0);
+          }
+      }
+      if (next_diag) {
+        const int row = 16 * q + li;
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            const int col = 16 * cp + lk + 4 * reg;
+            sh.t.T[row][col] = (col <= row) ? Rb[cp][reg] : 0.0;
+          }
+      } else if (on) {
+        double* ptr = strip_ptr(eb);
+        BAE_SSTORE_G(Rb, ptr);
+      }
+#pragma unroll
+      for (int cp = 0; cp < 4; ++cp) Rb[cp] = Rn[cp];
+      eb = en;
+    }
+    lds_barrier();
+    BAE_TSQ(4 + 3 * j);
+  }
+  __syncthreads();
+#ifdef BAE_TIME_SQ
+  if (tid == 0 && J == 40 && w == 4) {
+    const unsigned long long te = __builtin_readcyclecounter();
+    printf("TSQ load %llu | f0 %llu a0 %llu b0 %llu | f1 %llu a1 %llu b1 %llu | f2 %llu a2 %llu b2 %llu | f3 %llu | total %llu\n",
+           tsq[1] - tsq[0], tsq[2] - tsq[1], tsq[3] - tsq[2], tsq[4] - tsq[3], tsq[5] - tsq[4], tsq[6] - tsq[5],
+           tsq[7] - tsq[6], tsq[8] - tsq[7], tsq[9] - tsq[8], tsq[10] - tsq[9], tsq[11] - tsq[10], te - tsq[0]);
+  }
+#endif
+#undef BAE_TSQ
+#undef BAE_SLOAD
+#undef BAE_SSTORE_G
+  if (tid == 0 && sh.t.bad) atomicExch(status, 1);
+}
+
+// The rows below a square (row tiles from row0 on; the last block is the rhs row): one workgroup per row
+// tile, a 16-row strip per wave, LEFT-looking over the w tile columns of the square — the strip of column
+// jj takes the updates with the columns before it (its own earlier strips from registers as B fragments,
+// the square's tiles X(J+jj, J+k), signed and staged through LDS once per workgroup, as A operands) and then
+// the substitution with packet jj (staged through LDS as well).  No workgroup depends on another one: every
+// operand outside the strip was finished by k_square.
+struct RowPanelLds {
+  double S[2][NB][LDT];    // -D_k X(J+jj, J+k), double-buffered over the (jj, k) pairs
+  double pk[NOPV * 64];    // factor packet jj
+};
+
+__global__ void __launch_bounds__(256)
+k_rowpanel(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t w, uint32_t row0,
+           const double* __restrict__ opbuf, const double* __restrict__ dsgn, const uint8_t* __restrict__ nz,
+           const uint32_t* __restrict__ rowlist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rp_smem[];
+  RowPanelLds& sh = *reinterpret_cast<RowPanelLds*>(rp_smem);
+  __builtin_amdgcn_s_setprio(3);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const uint32_t i = rowlist ? rowlist[blockIdx.x] : row0 + blockIdx.x;
+  if (i > nblk) return;
+  const int rows = (i == nblk) ? 1 : NB;
+  const int myrow = 16 * wave + li;
+  // staging of a square tile: thread t moves columns sc, sc + 1 of the rows sr + 8 it
+  const int sr = tid >> 5, sc = (tid & 31) * 2;
+  double2 P[8];
+  double2 psg;
+  auto tile_load = [&](uint32_t jj, uint32_t k) {
+    const double* T = A + ((size_t)(J + jj) * NB + sr) * ld + (size_t)(J + k) * NB + sc;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) P[it] = *reinterpret_cast<const double2*>(T + (size_t)(8 * it) * ld);
+    psg = *reinterpret_cast<const double2*>(dsgn + (size_t)(J + k) * NB + sc);
+  };
+  auto tile_store = [&](int b) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      sh.S[b][sr + 8 * it][sc] = -psg.x * P[it].x;
+      sh.S[b][sr + 8 * it][sc + 1] = -psg.y * P[it].y;
+    }
+  };
+  double pkr[NOPV * 64 / 256];
+  auto packet_load = [&](uint32_t jj) {
+    const double* ob = opbuf + (size_t)(J + jj) * NOPV * 64 + tid;
+#pragma unroll
+    for (int it = 0; it < NOPV * 64 / 256; ++it) pkr[it] = ob[256 * it];
+  };
+  auto packet_store = [&]() {
+#pragma unroll
+    for (int it = 0; it < NOPV * 64 / 256; ++it) sh.pk[256 * it + tid] = pkr[it];
+  };
+  double4_t Rk[4][4];
+  bool onk[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    onk[jj] = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Rk[jj][c] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  }
+  packet_load(0);
+  if (w > 1) tile_load(1, 0);
+  int np = 0;  // pairs staged so far
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    if ((uint32_t)jj < w) {
+      const uint32_t d = J + jj;
+      const bool on = !nz || i == nblk || nz[(size_t)i * nblk + d];
+      onk[jj] = on;
+      double* Xrow = A + ((size_t)i * NB + (myrow < rows ? myrow : 0)) * ld + (size_t)d * NB + lk;
+      double4_t R[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) R[c][reg] = on ? Xrow[16 * c + 4 * reg] : 0.0;
+#pragma unroll
+      for (int k = 0; k < jj; ++k) {
+        const int b = np & 1;
+        ++np;
+        tile_store(b);
+        lds_barrier();
+        // the next pair's tile: in flight during this pair's MFMAs
+        if (k + 1 < jj) tile_load(jj, k + 1);
+        else if ((uint32_t)jj + 1 < w) tile_load(jj + 1, 0);
+        if (on && onk[k] && (!nz || nz[(size_t)d * nblk + J + k])) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+              const int kk = 16 * cc + 4 * reg + lk;
+              const double bf = Rk[k][cc][reg];
+#pragma unroll
+              for (int cp = 0; cp < 4; ++cp)
+                R[cp] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.S[b][16 * cp + li][kk], bf, R[cp], 0, 0, 0);
+            }
+        }
+      }
+      packet_store();
+      lds_barrier();
+      if ((uint32_t)jj + 1 < w) packet_load(jj + 1);
+      if (on) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double4_t Zc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            Zc = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.pk[(4 * c + ks) * 64 + lane], R[c][ks], Zc, 0, 0, 0);
+#pragma unroll
+          for (int c2 = c + 1; c2 < 4; ++c2) {
+            const int pi = (c2 == 1 ? 0 : (c2 == 2 ? 1 : 3)) + c;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+              R[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sh.pk[(16 + 4 * pi + ks) * 64 + lane], Zc[ks], R[c2], 0, 0, 0);
+          }
+          R[c] = Zc;
+        }
+        if (myrow < rows) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Xrow[16 * c + 4 * reg] = R[c][reg];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Rk[jj][c] = R[c];
+      // (the packet buffer is rewritten after the next column's first pair barrier, or — w == 1 — never)
+    }
   }
 }
 
@@ -1209,7 +1572,8 @@ k_copy_panel_rows(double* __restrict__ A, uint32_t ld, const uint32_t* __restric
 static const uint32_t KIN = 4;
 static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t J, uint32_t Jend,
                                double* dsgn, double* opbuf, int* colneg, int* flags, const uint8_t* nz,
-                               const uint32_t* rl = nullptr, uint32_t rl_n = 0, bool rl_square = false) {
+                               const uint32_t* rl = nullptr, uint32_t rl_n = 0, bool rl_square = false,
+                               bool sq = false) {
   // Large systems (the chain's tile updates are bandwidth-bound there and cost the bulk update their
   // full duration): sub-panels of 8, left-looking inside — every column is read and written once
   // per sub-panel instead of once per earlier column.  Small systems are latency-bound on the
@@ -1223,6 +1587,26 @@ static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t 
     *lp = rl + skip; *cnt = rl_n - skip;
   };
   if (rl && rl_n == 0) return;
+  if (sq) {
+    // small systems: the square of every sub-panel in one workgroup (k_square), the rows below it
+    // left-looking (k_rowpanel), then the sub-panel applied to the rest of the outer panel
+    const char* swe = getenv("BA_HIP_SQ_W");
+    const uint32_t SW = swe ? std::min(4u, std::max(1u, (uint32_t)atoi(swe))) : KIN;
+    for (uint32_t sub = J; sub < Jend; sub += SW) {
+      const uint32_t sub_end = std::min(sub + SW, Jend);
+      hipLaunchKernelGGL(k_square, dim3(1), dim3(512), sizeof(SquareLds), s, dA, ld, nblk, sub, sub_end - sub, dsgn,
+                         opbuf, colneg, flags, nz);
+      const uint32_t* lp; uint32_t cnt;
+      rows_from(sub_end, &lp, &cnt);
+      if (!cnt) continue;
+      hipLaunchKernelGGL(k_rowpanel, dim3(cnt), dim3(256), sizeof(RowPanelLds), s, dA, ld, nblk, sub, sub_end - sub, sub_end,
+                         (const double*)opbuf, (const double*)dsgn, nz, lp);
+      if (sub_end < Jend)
+        hipLaunchKernelGGL(k_step_update<false>, dim3(cnt, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk, sub_end,
+                           sub, sub_end, dsgn, opbuf, colneg, flags, nz, nblk + 1u, lp);
+    }
+    return;
+  }
   for (uint32_t sub = J; sub < Jend; sub += KINv) {
     const uint32_t sub_end = std::min(sub + KINv, Jend);
     for (uint32_t jj = sub; jj < sub_end; ++jj) {
@@ -1231,17 +1615,17 @@ static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t 
       if (cnt) hipLaunchKernelGGL(k_trsm_op, dim3(cnt), dim3(256), 0, s, dA, ld, jj, nblk, (const double*)opbuf, nz, lp);
       if (jj + 1 < sub_end && cnt) {
         if (left)  // column jj + 1 alone, with every earlier column of the sub-panel at once
-          hipLaunchKernelGGL(k_step_update, dim3(cnt, 1), dim3(256), 0, s, dA, ld, nblk, jj + 1, sub,
+          hipLaunchKernelGGL(k_step_update<true>, dim3(cnt, 1), dim3(256), 0, s, dA, ld, nblk, jj + 1, sub,
                              jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u, lp);
         else       // the rest of the sub-panel with column jj
-          hipLaunchKernelGGL(k_step_update, dim3(cnt, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
+          hipLaunchKernelGGL(k_step_update<true>, dim3(cnt, sub_end - (jj + 1)), dim3(256), 0, s, dA, ld,
                              nblk, jj + 1, jj, jj + 1, dsgn, opbuf, colneg, flags, nz, nblk + 1u, lp);
       }
     }
     if (sub_end < Jend) {
       const uint32_t* lp; uint32_t cnt;
       rows_from(sub_end, &lp, &cnt);
-      if (cnt) hipLaunchKernelGGL(k_step_update, dim3(cnt, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk,
+      if (cnt) hipLaunchKernelGGL(k_step_update<true>, dim3(cnt, Jend - sub_end), dim3(256), 0, s, dA, ld, nblk,
                                   sub_end, sub, sub_end, dsgn, opbuf, colneg, flags, nz, nblk + 1u, lp);
     }
   }
@@ -1253,22 +1637,23 @@ static void launch_panel_chain(hipStream_t s, double* dA, uint32_t ld, uint32_t 
 // it is big enough.
 static void launch_next_panel_update(hipStream_t s, double* dA, uint32_t ld, uint32_t nblk, uint32_t c0,
                                      uint32_t ncols, uint32_t kb0, uint32_t kb1, double* dsgn, double* opbuf,
-                                     int* colneg, int* flags, const uint8_t* nz) {
+                                     int* colneg, int* flags, const uint8_t* nz, bool factor = true) {
   static const bool no128 = getenv("BA_HIP_NO128") != nullptr;
   const uint32_t r0 = c0 + ncols;
+  auto step_update = factor ? k_step_update<true> : k_step_update<false>;
   // (a second launch on the serial chain: only where the chain is not the bottleneck)
   static const uint32_t min_rows =
       getenv("BA_HIP_BULK_FULL_M") ? (uint32_t)std::max(16, atoi(getenv("BA_HIP_BULK_FULL_M"))) : 128u;
   if (!no128 && r0 + min_rows <= nblk && ncols % 2u == 0 && c0 % 2u == 0) {
     const uint32_t m = nblk - r0, m2 = m / 2, rect_cols = ncols / 2;
-    hipLaunchKernelGGL(k_step_update, dim3(ncols, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn, opbuf,
+    hipLaunchKernelGGL(step_update, dim3(ncols, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn, opbuf,
                        colneg, flags, nz, r0, (const uint32_t*)nullptr);
     const uint32_t nrow64 = (ncols * (1 + (m & 1u)) + 7) / 8 * 8;
     hipLaunchKernelGGL(k_update128<true>, dim3(nrow64 + m2 * rect_cols), dim3(256), 0, s, dA, ld, nblk, c0, m2, kb0, kb1,
                        (const double*)dsgn, (const int*)colneg, 0u, nz, own_map_single(), nrow64, r0, rect_cols);
     return;
   }
-  hipLaunchKernelGGL(k_step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn,
+  hipLaunchKernelGGL(step_update, dim3(nblk - c0 + 1, ncols), dim3(256), 0, s, dA, ld, nblk, c0, kb0, kb1, dsgn,
                      opbuf, colneg, flags, nz, nblk + 1u, (const uint32_t*)nullptr);
 }
 
@@ -1729,7 +2114,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
   BAE_HIP(hipStreamWaitEvent(s2, e->ev_dist[1], 0));
   BAE_HIP(hipStreamWaitEvent(s3, e->ev_dist[1], 0));
   if (rank == pl.panels[0].diag_owner)  // factor packet of tile 0
-    hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
+    hipLaunchKernelGGL(k_step_update<true>, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
                        colneg, e->flags.p, nz, nblk + 1u, (const uint32_t*)nullptr);
   // row list of a square: its tiles, then the rhs row — one small device array per plan (ensure_dist_plan)
   DBuf<uint32_t>& sq_list = e->dist_sq_list;
@@ -1818,7 +2203,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
     const uint32_t n1 = std::min(c1 + KOUT, nblk);  // end of column block J+1
     if (rank == pl.panels[J + 1].diag_owner) {
       if (J > 0) BAE_HIP(hipStreamWaitEvent(s0, EV(J - 1, 4), 0));  // the bulk updates of its tiles by the panels < J
-      hipLaunchKernelGGL(k_step_update, dim3(n1 - c1 + 1, n1 - c1), dim3(256), 0, s0, dA, ld, nblk, c1, c0, c1, dsgn, opbuf,
+      hipLaunchKernelGGL(k_step_update<true>, dim3(n1 - c1 + 1, n1 - c1), dim3(256), 0, s0, dA, ld, nblk, c1, c0, c1, dsgn, opbuf,
                          colneg, e->flags.p, nz, nblk + 1u, (const uint32_t*)(sq_list.p + sq_off));
     }
     // ---- panel stream: the other own rows of panel J, their messages -----------------------------------
@@ -1847,7 +2232,7 @@ int cholesky_solve_dist(Engine* e, double* dA, uint32_t ld, double* dx, int* sta
         const DistPanel& pq = pl.panels[J + 1];
         const uint32_t cnt = pq.own_u_count[rank] + pq.own_r_count[rank];
         if (cnt)
-          hipLaunchKernelGGL(k_step_update, dim3(cnt, ncols), dim3(256), 0, s1, dA, ld, nblk, c1, c0, c1, dsgn, opbuf,
+          hipLaunchKernelGGL(k_step_update<true>, dim3(cnt, ncols), dim3(256), 0, s1, dA, ld, nblk, c1, c0, c1, dsgn, opbuf,
                              colneg, e->flags.p, nz, nblk + 1u, dtiles + pq.own_u_first[rank]);
       }
     }
@@ -2000,9 +2385,27 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     e->ev_bulk.push_back(b);
   }
   { const int src = setup_status_block(e, dA, ld, s0); if (src) return src; }
-  // factor packet of tile 0 (nothing to update: one workgroup)
-  hipLaunchKernelGGL(k_step_update, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
+  // BA_HIP_SQUARE=1 (measurement switch, read on every call): the diagonal squares of the sub-panels go to
+  // k_square / k_rowpanel — one workgroup per square instead of two launches per tile column.  Measured
+  // SLOWER than the per-column chain at configs[1] (5.07 / 4.38 ms at widths 4 / 2 against 3.73 ms: the chain
+  // overlaps every factorisation with the other tiles' updates of the same launch, a single workgroup
+  // serialises them on one CU's matrix pipes — profiles/r03_square_kernel.txt).
+  const char* sqe = getenv("BA_HIP_SQUARE");
+  const bool sq = nblk < 512 && sqe && atoi(sqe) != 0;
+  if (sq) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      BAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_square), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sizeof(SquareLds)));
+      BAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpanel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sizeof(RowPanelLds)));
+      attr_set = true;
+    }
+  } else {
+    // factor packet of tile 0 (nothing to update: one workgroup)
+    hipLaunchKernelGGL(k_step_update<true>, dim3(1, 1), dim3(256), 0, s0, dA, ld, nblk, 0u, 0u, 0u, dsgn, opbuf,
                        colneg, e->flags.p, nz, nblk + 1u, (const uint32_t*)nullptr);
+  }
   // Look-ahead: the trailing update of panel J is split into (a) the columns of the NEXT
   // panel — on the critical path, stream s0 — and (b) everything right of it — stream s1,
   // overlapping the serial factorisation of the next panel.
@@ -2010,13 +2413,13 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   uint32_t pj = 0;
   for (uint32_t J = 0; J < nblk; J += KOUT, ++pj) {
     const uint32_t Jend = J + KOUT < nblk ? J + KOUT : nblk;
-    launch_panel_chain(s0, dA, ld, nblk, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
+    launch_panel_chain(s0, dA, ld, nblk, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz, nullptr, 0, false, sq);
     if (Jend >= nblk) break;
     BAE_HIP(hipEventRecord(e->ev_panel[pj], s0));
     const uint32_t a_end = Jend + KOUT < nblk ? Jend + KOUT : nblk;  // columns of the next panel
     // (a) next panel's columns: needs every earlier bulk update of those columns
     if (prev_bulk >= 0) BAE_HIP(hipStreamWaitEvent(s0, e->ev_bulk[prev_bulk], 0));
-    launch_next_panel_update(s0, dA, ld, nblk, Jend, a_end - Jend, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz);
+    launch_next_panel_update(s0, dA, ld, nblk, Jend, a_end - Jend, J, Jend, dsgn, opbuf, colneg, e->flags.p, nz, !sq);
     // (b) the rest, concurrently with the next panel's factorisation
     if (a_end < nblk) {
       BAE_HIP(hipStreamWaitEvent(s1, e->ev_panel[pj], 0));
