@@ -394,6 +394,11 @@ k_update2(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint3
 // The blocks cover the even part of the trailing matrix; the rhs row and an odd last tile row are
 // 64-tiles taken by the first workgroups of the same launch.
 static const int NB2 = 128;
+#ifdef BAE_TIME128  // measurement build: every 128-block of the bulk launches leaves a record (scratch/gpu_r03_time128.sh)
+__device__ unsigned long long* g_t128_buf = nullptr;
+__device__ unsigned int g_t128_n = 0;
+static const unsigned int T128_CAP = 1u << 21, T128_REC = 6;
+#endif
 template <bool RECT, bool LIST = false>  // RECT: the rectangle variant (separate kernel name in profiles); LIST: own.pairs
 __global__ void __launch_bounds__(256, 2)
 k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uint32_t m2, uint32_t kb0,
@@ -529,6 +534,7 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   }
 #ifdef BAE_TIME128   // measurement build: cycle stamps of one workgroup in 257 (scratch/gpu_r03_time128.sh)
   const unsigned long long tt0 = __builtin_readcyclecounter();
+  const unsigned long long tw0 = wall_clock64();
   const int tt_cols = __builtin_popcountll(mask);
 #endif
   uint32_t kcur = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
@@ -540,6 +546,7 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   BAE_LDF(FA0, FB0, 0, 0);
 #ifdef BAE_TIME128
   const unsigned long long tt1 = __builtin_readcyclecounter();
+  const unsigned long long tw1 = wall_clock64();  // constant 100 MHz: the tick rate of the cycle counter follows
 #endif
   while (mask) {
     const uint32_t knext = (kb0 + (uint32_t)__builtin_ctzll(mask)) * NB;
@@ -573,6 +580,7 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
   BAE_CHUNK(3, false, BAE_CLOAD(cva, 0), false);
 #ifdef BAE_TIME128
   const unsigned long long tt2 = __builtin_readcyclecounter();
+  const unsigned long long tw2 = wall_clock64();
 #endif
   if (diag && wave == 1) return;  // the strictly upper 64-tile of a diagonal block (computed, not stored)
   BAE_SB;
@@ -591,8 +599,17 @@ k_update128(double* __restrict__ A, uint32_t ld, uint32_t nblk, uint32_t c0, uin
 #ifdef BAE_TIME128
   if (tid == 0 && (blockIdx.x % 257u) == 100u && !RECT) {
     const unsigned long long tt3 = __builtin_readcyclecounter();
-    printf("T128 cols %d prologue %llu loop %llu epilogue %llu per_chunk %llu\n", tt_cols, tt1 - tt0, tt2 - tt1, tt3 - tt2,
-           (tt2 - tt1) / (unsigned long long)(4 * tt_cols));
+    printf("T128 cols %d prologue %llu loop %llu epilogue %llu per_chunk %llu loop_100MHz %llu\n", tt_cols, tt1 - tt0,
+           tt2 - tt1, tt3 - tt2, (tt2 - tt1) / (unsigned long long)(4 * tt_cols), tw2 - tw1);
+  }
+  if (tid == 0 && !RECT && g_t128_buf) {  // one record per 128-block: scratch/analyze_t128.py
+    const unsigned int idx = atomicAdd(&g_t128_n, 1u);
+    if (idx < T128_CAP) {
+      unsigned long long* r = g_t128_buf + (size_t)idx * T128_REC;
+      r[0] = tw0; r[1] = tw1; r[2] = tw2; r[3] = wall_clock64();
+      r[4] = ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32) | (unsigned int)__builtin_amdgcn_s_getreg(63492);
+      r[5] = (unsigned long long)blockIdx.x | ((unsigned long long)tt_cols << 32) | ((unsigned long long)kb0 << 40);
+    }
   }
 #endif
 #undef BAE_CLOAD
@@ -2385,6 +2402,17 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
     e->ev_bulk.push_back(b);
   }
   { const int src = setup_status_block(e, dA, ld, s0); if (src) return src; }
+#ifdef BAE_TIME128
+  static unsigned long long* t128_dev = nullptr;
+  if (getenv("BA_HIP_TRACE_FILE")) {
+    if (!t128_dev) {
+      BAE_HIP(hipMalloc(&t128_dev, (size_t)T128_CAP * T128_REC * sizeof(unsigned long long)));
+      BAE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_t128_buf), &t128_dev, sizeof(t128_dev)));
+    }
+    const unsigned int zero = 0;
+    BAE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_t128_n), &zero, sizeof(zero)));
+  }
+#endif
   // BA_HIP_SQUARE=1 (measurement switch, read on every call): the diagonal squares of the sub-panels go to
   // k_square / k_rowpanel — one workgroup per square instead of two launches per tile column.  Measured
   // SLOWER than the per-column chain at configs[1] (5.07 / 4.38 ms at widths 4 / 2 against 3.73 ms: the chain
@@ -2455,6 +2483,20 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   BAE_HIP(hipMemcpyAsync(&st, e->flags.p, sizeof(int), hipMemcpyDeviceToHost, s0));
   BAE_HIP(hipStreamSynchronize(s0));
   *status = st;
+#ifdef BAE_TIME128
+  if (t128_dev && getenv("BA_HIP_TRACE_FILE")) {
+    BAE_HIP(hipDeviceSynchronize());
+    unsigned int n = 0;
+    BAE_HIP(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_t128_n), sizeof(n)));
+    n = std::min(n, T128_CAP);
+    std::vector<unsigned long long> rec((size_t)n * T128_REC);
+    if (n) BAE_HIP(hipMemcpy(rec.data(), t128_dev, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(getenv("BA_HIP_TRACE_FILE"), "wb")) {
+      fwrite(rec.data(), sizeof(unsigned long long), rec.size(), f);
+      fclose(f);
+    }
+  }
+#endif
   return 0;
 }
 
