@@ -1415,26 +1415,92 @@ __device__ __forceinline__ void matvec64(const double* __restrict__ M, size_t st
 __global__ void __launch_bounds__(256)
 k_backward2(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
             const double* __restrict__ linvT, double* __restrict__ x, const uint8_t* __restrict__ nz, uint32_t col0) {
-  __shared__ double x1[NB], x0[NB], y0[NB];
+  __shared__ double x1[NB], x0[NB], y0[NB], y1[NB];
   __shared__ double part[4][NB];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
   const double* yrow = A + ((size_t)nblk * NB) * ld;
+  const uint32_t col = col0 + blockIdx.x * 256 + tid;
+  const bool incol = col < i * NB;
+  // A launch of this kernel is a chain of memory round trips (~1-2 us each) around a few hundred flops.  Everything
+  // that depends on nothing computed here is requested at once: the operands of the first two mat-vecs, both y
+  // blocks, the pattern flags and the rows of block row i + 1 in this thread's column; the operands of the third
+  // mat-vec and the rows of block row i follow as soon as registers are free, each a full phase ahead of its use.
+  // Same sums in the same order as the staged version (k_backward): results are bitwise unchanged.
+  bool on1 = false, on0 = false;
+  if (incol) {
+    on1 = !nz || nz[(size_t)(i + 1) * nblk + (col >> 6)];
+    on0 = !nz || nz[(size_t)i * nblk + (col >> 6)];
+  }
+  double m1[16], m2[16];
+  {
+    const double* M1 = linvT + (size_t)(i + 1) * NB * NB + (size_t)r * NB + 16 * q;           // L_(i+1)(i+1)^-T, row r
+    const double* M2 = A + ((size_t)(i + 1) * NB + 16 * q) * ld + (size_t)i * NB + r;         // L_(i+1)i, column r
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      m1[k] = M1[k];
+      m2[k] = M2[(size_t)k * ld];
+    }
+  }
+  double yi1 = 0.0, yi0 = 0.0;
+  if (tid < NB) {
+    yi1 = yrow[(size_t)(i + 1) * NB + tid];
+    yi0 = yrow[(size_t)i * NB + tid];
+  }
+  double lr[NB];
+  if (on1) {
+    const double* L1 = A + ((size_t)(i + 1) * NB) * ld + col;
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) lr[rr] = L1[(size_t)rr * ld];
+  }
+  if (tid < NB) y1[tid] = yi1;
+  __syncthreads();
   // x1 = L_(i+1)(i+1)^-T y_(i+1)
-  matvec64(linvT + (size_t)(i + 1) * NB * NB, NB, 1, yrow + (size_t)(i + 1) * NB, part, tid);
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += m1[k] * y1[16 * q + k];
+    part[q][r] = s;
+  }
   __syncthreads();
   if (tid < NB) {
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     x1[tid] = v;
     if (blockIdx.x == 0) x[(size_t)(i + 1) * NB + tid] = v;
   }
+  double m3[16];
+  {
+    const double* M3 = linvT + (size_t)i * NB * NB + (size_t)r * NB + 16 * q;                 // L_ii^-T, row r
+#pragma unroll
+    for (int k = 0; k < 16; ++k) m3[k] = M3[k];
+  }
   __syncthreads();
-  // y0 = y_i - L_(i+1)i^T x1   (element c: sum over rows r of L[(i+1)*64 + r][i*64 + c] x1[r])
-  matvec64(A + ((size_t)(i + 1) * NB) * ld + (size_t)i * NB, 1, ld, x1, part, tid);
+  // y0 = y_i - L_(i+1)i^T x1
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += m2[k] * x1[16 * q + k];
+    part[q][r] = s;
+  }
+  double s1 = 0.0, s0 = 0.0;
+  if (on1) {
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) s1 += lr[rr] * x1[rr];
+  }
+  if (on0) {
+    const double* L0 = A + ((size_t)i * NB) * ld + col;
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) lr[rr] = L0[(size_t)rr * ld];
+  }
   __syncthreads();
-  if (tid < NB) y0[tid] = yrow[(size_t)i * NB + tid] - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+  if (tid < NB) y0[tid] = yi0 - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
   __syncthreads();
   // x0 = L_ii^-T y0
-  matvec64(linvT + (size_t)i * NB * NB, NB, 1, y0, part, tid);
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += m3[k] * y0[16 * q + k];
+    part[q][r] = s;
+  }
   __syncthreads();
   if (tid < NB) {
     const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
@@ -1442,22 +1508,11 @@ k_backward2(double* __restrict__ A, uint32_t ld, uint32_t i, uint32_t nblk,
     if (blockIdx.x == 0) x[(size_t)i * NB + tid] = v;
   }
   __syncthreads();
-  const uint32_t col = col0 + blockIdx.x * 256 + tid;
-  if (col < i * NB) {
-    const double* L1 = A + ((size_t)(i + 1) * NB) * ld + col;
-    const double* L0 = A + ((size_t)i * NB) * ld + col;
-    double s1 = 0.0, s0 = 0.0;
-    const bool on1 = !nz || nz[(size_t)(i + 1) * nblk + (col >> 6)], on0 = !nz || nz[(size_t)i * nblk + (col >> 6)];
-    if (on1) {
-#pragma unroll 16
-      for (int r = 0; r < NB; ++r) s1 += L1[(size_t)r * ld] * x1[r];
-    }
-    if (on0) {
-#pragma unroll 16
-      for (int r = 0; r < NB; ++r) s0 += L0[(size_t)r * ld] * x0[r];
-    }
-    if (on1 || on0) A[((size_t)nblk * NB) * ld + col] -= (s1 + s0);
+  if (on0) {
+#pragma unroll
+    for (int rr = 0; rr < NB; ++rr) s0 += lr[rr] * x0[rr];
   }
+  if (on1 || on0) A[((size_t)nblk * NB) * ld + col] -= (s1 + s0);
 }
 
 // the backward substitution over the block rows [lo, hi), last first, updating the columns from tile lo on:
