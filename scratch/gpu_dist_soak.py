@@ -2,7 +2,7 @@
 counts 2..8, ownership layouts, panel widths, landmark shards contiguous or dealt along the trajectory.  Every
 trial: the step is bitwise equal across the ranks, errors / step norms agree with ONE engine on the whole scene to
 1e-8, final poses to 1e-9, and the bytes the ranks moved equal the message plan.
-    python scratch/gpu_dist_soak.py <seed> <trials>
+    python scratch/gpu_dist_soak.py <seed> <trials> [mid]      (mid: 1000-2600 poses, 94-244 tiles: the 128-block kernels)
 (test infrastructure for DESIGN section 6a; the pytest case test_distributed_solve_matches_single is the fixed-seed form)"""
 import os
 import sys
@@ -16,6 +16,7 @@ from ba_amd import hipapi, scene, sharding  # noqa: E402
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+MID = len(sys.argv) > 3 and sys.argv[3] == "mid"
 
 
 def rel_err(a, b):
@@ -48,10 +49,10 @@ bad = 0
 t_start = time.time()
 for trial in range(N):
     nranks = int(rng.choice([2, 3, 4, 5, 6, 8]))
-    P = int(rng.integers(60, 420))
+    P = int(rng.integers(1000, 2600)) if MID else int(rng.integers(60, 420))
     k = int(rng.integers(4, 9))
     L = int(rng.integers(6, 14)) * P
-    kout = int(rng.choice([2, 3, 4, 5, 6]))
+    kout = int(rng.choice([4, 6, 8, 16] if MID else [2, 3, 4, 5, 6]))
     lay = str(rng.choice(["auto", "auto", "row", "col", "grid"]))
     along = bool(rng.integers(0, 2))
     seed = int(rng.integers(1, 10**6))
