@@ -226,6 +226,7 @@ struct Engine {
   double eval_h[4];                      // ... of the evaluation sums (ba_hip_eval_residuals)
   DBuf<unsigned long long> hist;         // selection histograms
   DBuf<int32_t> flags;                   // factorisation status block (k_chol.hip: setup_status_block)
+  bool square_attr_set = false;          // k_square / k_rowpanel: dynamic LDS limit raised on this engine's device
   DBuf<double> pivot_floor;              // tol * |S_jj| per row (ba_hip_options::pivot_rel_tolerance)
 
   // optional per-kernel timing (ba_hip_set_profiling)

@@ -2476,13 +2476,12 @@ int cholesky_solve(Engine* e, double* dA, uint32_t n, uint32_t ld, double* dx, i
   const char* sqe = getenv("BA_HIP_SQUARE");
   const bool sq = nblk < 512 && sqe && atoi(sqe) != 0;
   if (sq) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!e->square_attr_set) {  // (per engine = per device: function attributes belong to the device)
       BAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_square), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sizeof(SquareLds)));
       BAE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowpanel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sizeof(RowPanelLds)));
-      attr_set = true;
+      e->square_attr_set = true;
     }
   } else {
     // factor packet of tile 0 (nothing to update: one workgroup)
